@@ -1,0 +1,26 @@
+# Builds the MI355X engine: edlib_amd/libedlib.so (the drop-in shared library,
+# exporting the five edlib.h symbols plus include/edlib_amd.h) for gfx950.
+HIPCC   ?= /opt/rocm/bin/hipcc
+ARCH    ?= gfx950
+CSRC    := edlib_amd/csrc
+OBJDIR  := build/obj
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -Wall -Wno-unused-function
+
+SRCS := $(CSRC)/reads_kernels.hip $(CSRC)/pair_kernels.hip $(CSRC)/engine.hip $(CSRC)/api.hip
+OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
+
+all: edlib_amd/libedlib.so
+
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hpp) include/edlib.h include/edlib_amd.h
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+edlib_amd/libedlib.so: $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle all
+
+clean:
+	rm -rf build edlib_amd/libedlib.so
+.PHONY: all oracle clean

@@ -1,0 +1,393 @@
+"""edlib_amd -- Python front of the MI355X edit-distance engine (ctypes over the C ABI).
+
+Mirrors the reference's Python binding (bindings/python/edlib.pyx): ``align()`` and
+``getNiceAlignment()`` have the same arguments, defaults, result dictionary and
+error behaviour (edlib.pyx:56-155, 158-238), so the reference's own binding tests
+(bindings/python/test.py) read the same against this package.  Additive:
+``align_batch()`` / ``align_pairs()`` and the resident ``SharedBatch`` / ``PairBatch``
+sessions over include/edlib_amd.h.
+
+There is no CPU path in here: everything calls ``libedlib.so`` (built by
+``__graft_entry__.build()`` / ``make``), and a missing library or a missing GPU
+raises.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libedlib.so")
+
+EDLIB_MODE = {"NW": 0, "SHW": 1, "HW": 2}
+EDLIB_TASK = {"distance": 0, "locations": 1, "path": 2}
+
+
+class EqualityPair(C.Structure):          # edlib.h:92-95
+    _fields_ = [("first", C.c_char), ("second", C.c_char)]
+
+
+class AlignConfig(C.Structure):           # edlib.h:100-140
+    _fields_ = [("k", C.c_int), ("mode", C.c_int), ("task", C.c_int),
+                ("additionalEqualities", C.POINTER(EqualityPair)),
+                ("additionalEqualitiesLength", C.c_int)]
+
+
+class AlignResult(C.Structure):           # edlib.h:162-218
+    _fields_ = [("status", C.c_int), ("editDistance", C.c_int),
+                ("endLocations", C.POINTER(C.c_int)),
+                ("startLocations", C.POINTER(C.c_int)),
+                ("numLocations", C.c_int),
+                ("alignment", C.POINTER(C.c_ubyte)),
+                ("alignmentLength", C.c_int), ("alphabetLength", C.c_int)]
+
+
+class BatchStats(C.Structure):            # edlib_amd.h EdlibAmdBatchStats
+    _fields_ = [("run_ms", C.c_double), ("scan_ms", C.c_double), ("scan_launches", C.c_int),
+                ("cells", C.c_longlong), ("word_steps", C.c_longlong), ("algo_bytes", C.c_longlong),
+                ("path", C.c_int), ("overflow_units", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library (raises if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError("%s not found: build it with `make` or __graft_entry__.build() "
+                          "(there is no Python/CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.edlibAlign.restype = AlignResult
+        L.edlibAlign.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, AlignConfig]
+        L.edlibNewAlignConfig.restype = AlignConfig
+        L.edlibNewAlignConfig.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(EqualityPair), C.c_int]
+        L.edlibDefaultAlignConfig.restype = AlignConfig
+        L.edlibFreeAlignResult.argtypes = [AlignResult]
+        L.edlibAlignmentToCigar.restype = C.c_void_p
+        L.edlibAlignmentToCigar.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        L.edlibAmdDeviceCount.restype = C.c_int
+        L.edlibAmdLastError.restype = C.c_char_p
+        L.edlibAmdVersion.restype = C.c_char_p
+        L.edlibAmdBatchCreateShared.restype = C.c_void_p
+        L.edlibAmdBatchCreateShared.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                AlignConfig, C.c_int]
+        L.edlibAmdBatchCreatePairs.restype = C.c_void_p
+        L.edlibAmdBatchCreatePairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                               AlignConfig, C.c_int]
+        L.edlibAmdBatchRun.argtypes = [C.c_void_p]
+        L.edlibAmdBatchResults.argtypes = [C.c_void_p, C.POINTER(AlignResult)]
+        L.edlibAmdBatchStats.argtypes = [C.c_void_p, C.POINTER(BatchStats)]
+        L.edlibAmdBatchDestroy.argtypes = [C.c_void_p]
+        L.edlibAmdBatchDestroy.restype = None
+        L.libc = C.CDLL(None)
+        L.libc.free.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def device_count():
+    return lib().edlibAmdDeviceCount()
+
+
+def last_error():
+    return lib().edlibAmdLastError().decode()
+
+
+# --------------------------------------------------------------- helpers
+
+class NeedsAlphabetMapping(Exception):
+    pass
+
+
+def _map_ascii_string(s):
+    if isinstance(s, (bytes, bytearray)):
+        return bytes(s)
+    if isinstance(s, np.ndarray) and s.dtype == np.uint8:
+        return s.tobytes()
+    if isinstance(s, str):
+        b = s.encode("utf-8")
+        if len(b) == len(s):
+            return b
+    raise NeedsAlphabetMapping()
+
+
+def _map_to_bytes(query, target, additional_equalities):
+    """Arbitrary hashable symbols -> single bytes (edlib.pyx:22-53)."""
+    try:
+        return _map_ascii_string(query), _map_ascii_string(target), additional_equalities
+    except NeedsAlphabetMapping:
+        alphabet = set(query).union(set(target))
+        if len(alphabet) > 256:
+            raise ValueError("query and target combined have more than 256 unique values, "
+                             "this is not supported.")
+        mapping = {c: bytes([i]) for i, c in enumerate(alphabet)}
+        q = b"".join(mapping[c] for c in query)
+        t = b"".join(mapping[c] for c in target)
+        if additional_equalities is not None:
+            additional_equalities = [(mapping[a], mapping[b]) for a, b in additional_equalities
+                                     if a in mapping and b in mapping]
+        return q, t, additional_equalities
+
+
+def _one_byte(x):
+    if isinstance(x, (bytes, bytearray)):
+        return bytes(x[:1])
+    return x.encode("utf-8")[:1]
+
+
+def _make_config(mode, task, k, additionalEqualities):
+    cfg = lib().edlibDefaultAlignConfig()
+    if k is not None:
+        cfg.k = k
+    if mode in EDLIB_MODE:
+        cfg.mode = EDLIB_MODE[mode]
+    elif isinstance(mode, int):
+        cfg.mode = mode
+    if task in EDLIB_TASK:
+        cfg.task = EDLIB_TASK[task]
+    elif isinstance(task, int):
+        cfg.task = task
+    keep = None
+    if additionalEqualities:
+        keep = (EqualityPair * len(additionalEqualities))()
+        for i, (a, b) in enumerate(additionalEqualities):
+            keep[i].first = _one_byte(a)
+            keep[i].second = _one_byte(b)
+        cfg.additionalEqualities = C.cast(keep, C.POINTER(EqualityPair))
+        cfg.additionalEqualitiesLength = len(additionalEqualities)
+    return cfg, keep
+
+
+def cigar_from_alignment(ops, extended=True):
+    """edlibAlignmentToCigar (edlib.h:268-271) on a bytes object of op codes."""
+    L = lib()
+    p = L.edlibAlignmentToCigar(bytes(ops), len(ops), 1 if extended else 0)
+    if not p:
+        return None
+    s = C.string_at(p).decode()
+    L.libc.free(p)
+    return s
+
+
+def _raw_result(r):
+    """EdlibAlignResult -> dict with every C field (used by the parity tests)."""
+    n = r.numLocations
+    return {
+        "status": r.status,
+        "editDistance": r.editDistance,
+        "endLocations": [r.endLocations[i] for i in range(n)] if r.endLocations else None,
+        "startLocations": [r.startLocations[i] for i in range(n)] if r.startLocations else None,
+        "numLocations": n,
+        "alignment": bytes(bytearray(r.alignment[:r.alignmentLength])) if r.alignment else None,
+        "alignmentLength": r.alignmentLength,
+        "alphabetLength": r.alphabetLength,
+    }
+
+
+def _nice_result(raw):
+    """The reference binding's dictionary (edlib.pyx:136-153)."""
+    locations = []
+    for i in range(max(raw["numLocations"], 0)):
+        locations.append((raw["startLocations"][i] if raw["startLocations"] is not None else None,
+                          raw["endLocations"][i] if raw["endLocations"] is not None else None))
+    cigar = cigar_from_alignment(raw["alignment"]) if raw["alignment"] is not None else None
+    return {"editDistance": raw["editDistance"], "alphabetLength": raw["alphabetLength"],
+            "locations": locations, "cigar": cigar}
+
+
+# ----------------------------------------------------------- public API
+
+def align_raw(query, target, mode="NW", task="distance", k=-1, additionalEqualities=None):
+    """edlibAlign() with every field of EdlibAlignResult returned (bytes in)."""
+    L = lib()
+    cfg, keep = _make_config(mode, task, k, additionalEqualities)
+    r = L.edlibAlign(query, len(query), target, len(target), cfg)
+    raw = _raw_result(r)
+    L.edlibFreeAlignResult(r)
+    return raw
+
+
+def align(query, target, mode="NW", task="distance", k=-1, additionalEqualities=None):
+    """Align query with target using edit distance (same contract as the reference's
+    ``edlib.align``, edlib.pyx:56-155).  Returns {editDistance, alphabetLength,
+    locations: [(start, end)], cigar}; raises on status == 1."""
+    q, t, eqs = _map_to_bytes(query, target, additionalEqualities)
+    raw = align_raw(q, t, mode, task, k, eqs)
+    if raw["status"] == 1:
+        raise Exception("There was an error.")
+    return _nice_result(raw)
+
+
+def getNiceAlignment(alignResult, query, target, gapSymbol="-"):
+    """Human-readable three-line alignment (edlib.pyx:158-238)."""
+    if type(alignResult) is not dict:
+        raise Exception("The object alignResult is expected to be a python dictionary. "
+                        "Please check the input alignResult.")
+    if "locations" not in alignResult:
+        raise Exception("The object alignResult is expected to contain a field 'locations'. "
+                        "Please check the input alignResult.")
+    target_pos = alignResult["locations"][0][0]
+    if target_pos is None:
+        target_pos = 0
+    query_pos = 0
+    target_aln = match_aln = query_aln = ""
+    if "cigar" not in alignResult:
+        raise Exception("The object alignResult is expected to contain a CIGAR string. "
+                        "Please check the input alignResult.")
+    cigar = alignResult["cigar"]
+    if cigar == "" or cigar is None:
+        raise Exception("The object alignResult contains an empty CIGAR string. Users must run "
+                        "align() with task='path'. Please check the input alignResult.")
+    for num, op in re.findall(r"(\d+)(\D)", cigar):
+        num = int(num)
+        if op in "=X":
+            target_aln += target[target_pos:target_pos + num]
+            target_pos += num
+            query_aln += query[query_pos:query_pos + num]
+            query_pos += num
+            match_aln += ("|" if op == "=" else ".") * num
+        elif op == "D":
+            target_aln += target[target_pos:target_pos + num]
+            target_pos += num
+            query_aln += gapSymbol * num
+            match_aln += gapSymbol * num
+        elif op == "I":
+            target_aln += gapSymbol * num
+            query_aln += query[query_pos:query_pos + num]
+            query_pos += num
+            match_aln += gapSymbol * num
+        else:
+            raise Exception("The CIGAR string from alignResult contains a symbol not '=', 'X', 'D', 'I'. "
+                            "Please check the validity of alignResult and alignResult.cigar")
+    return {"query_aligned": query_aln, "matched_aligned": match_aln, "target_aligned": target_aln}
+
+
+# ------------------------------------------------------------ batches
+
+def _pack(seqs):
+    """list of bytes / uint8 arrays (or one 2-D uint8 array) -> (contiguous uint8, int64 offsets)."""
+    if isinstance(seqs, np.ndarray) and seqs.ndim == 2 and seqs.dtype == np.uint8:
+        n, m = seqs.shape
+        return np.ascontiguousarray(seqs).reshape(-1), np.arange(n + 1, dtype=np.int64) * m
+    arrs = [np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray)) else np.asarray(s, dtype=np.uint8)
+            for s in seqs]
+    off = np.zeros(len(arrs) + 1, dtype=np.int64)
+    if arrs:
+        off[1:] = np.cumsum([len(a) for a in arrs])
+    data = np.concatenate(arrs) if arrs and off[-1] > 0 else np.zeros(1, dtype=np.uint8)
+    return np.ascontiguousarray(data), off
+
+
+class _Batch:
+    """A batch resident in HBM: create (upload) once, run() many times, results()."""
+
+    def __init__(self, handle, n, keep):
+        if not handle:
+            raise RuntimeError("edlib_amd: batch creation failed: " + last_error())
+        self._h = handle
+        self.n = n
+        self._keep = keep
+
+    def run(self):
+        if lib().edlibAmdBatchRun(self._h) != 0:
+            raise RuntimeError("edlib_amd: run failed: " + last_error())
+        return self.stats()
+
+    def stats(self):
+        s = BatchStats()
+        lib().edlibAmdBatchStats(self._h, C.byref(s))
+        return {f: getattr(s, f) for f, _ in BatchStats._fields_}
+
+    def results(self, raw=True):
+        L = lib()
+        arr = (AlignResult * max(self.n, 1))()
+        if L.edlibAmdBatchResults(self._h, arr) != 0:
+            raise RuntimeError("edlib_amd: results failed: " + last_error())
+        out = []
+        for i in range(self.n):
+            d = _raw_result(arr[i])
+            L.edlibFreeAlignResult(arr[i])
+            out.append(d if raw else _nice_result(d))
+        return out
+
+    def results_arrays(self):
+        """editDistance / numLocations / first end location as numpy arrays (large batches)."""
+        L = lib()
+        arr = (AlignResult * max(self.n, 1))()
+        if L.edlibAmdBatchResults(self._h, arr) != 0:
+            raise RuntimeError("edlib_amd: results failed: " + last_error())
+        ed = np.empty(self.n, dtype=np.int32); nl = np.empty(self.n, dtype=np.int32)
+        first = np.full(self.n, -2, dtype=np.int64); alpha = np.empty(self.n, dtype=np.int32)
+        ends = []
+        for i in range(self.n):
+            r = arr[i]
+            ed[i] = r.editDistance; nl[i] = r.numLocations; alpha[i] = r.alphabetLength
+            if r.endLocations and r.numLocations > 0:
+                first[i] = r.endLocations[0]
+                ends.append(np.ctypeslib.as_array(r.endLocations, shape=(r.numLocations,)).copy())
+            else:
+                ends.append(np.zeros(0, dtype=np.int32))
+            L.edlibFreeAlignResult(r)
+        return {"editDistance": ed, "numLocations": nl, "firstEnd": first, "alphabetLength": alpha, "ends": ends}
+
+    def close(self):
+        if self._h:
+            lib().edlibAmdBatchDestroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SharedBatch(_Batch):
+    """Many queries against one target (the loop of apps/aligner/aligner.cpp:162-225)."""
+
+    def __init__(self, queries, target, mode="HW", task="distance", k=-1, additionalEqualities=None, device=0):
+        qd, qo = _pack(queries)
+        t = np.frombuffer(target, dtype=np.uint8) if isinstance(target, (bytes, bytearray)) else np.asarray(target, dtype=np.uint8)
+        t = np.ascontiguousarray(t) if len(t) else np.zeros(1, dtype=np.uint8)
+        tlen = len(target)
+        cfg, keep = _make_config(mode, task, k, additionalEqualities)
+        h = lib().edlibAmdBatchCreateShared(qd.ctypes.data, qo.ctypes.data, len(qo) - 1,
+                                            t.ctypes.data, tlen, cfg, device)
+        super().__init__(h, len(qo) - 1, keep)
+
+
+class PairBatch(_Batch):
+    """Independent (query, target) pairs."""
+
+    def __init__(self, queries, targets, mode="NW", task="distance", k=-1, additionalEqualities=None, device=0):
+        qd, qo = _pack(queries)
+        td, to = _pack(targets)
+        if len(qo) != len(to):
+            raise ValueError("queries and targets differ in count")
+        cfg, keep = _make_config(mode, task, k, additionalEqualities)
+        h = lib().edlibAmdBatchCreatePairs(qd.ctypes.data, qo.ctypes.data, td.ctypes.data, to.ctypes.data,
+                                           len(qo) - 1, cfg, device)
+        super().__init__(h, len(qo) - 1, keep)
+
+
+def align_batch(queries, target, mode="HW", task="distance", k=-1, additionalEqualities=None, raw=False):
+    """[align(q, target, ...) for q in queries] in one device batch."""
+    b = SharedBatch(queries, target, mode, task, k, additionalEqualities)
+    try:
+        b.run()
+        return b.results(raw=raw)
+    finally:
+        b.close()
+
+
+def align_pairs(queries, targets, mode="NW", task="distance", k=-1, additionalEqualities=None, raw=False):
+    """[align(q, t, ...) for q, t in zip(queries, targets)] in one device batch."""
+    b = PairBatch(queries, targets, mode, task, k, additionalEqualities)
+    try:
+        b.run()
+        return b.results(raw=raw)
+    finally:
+        b.close()

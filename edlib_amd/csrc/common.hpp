@@ -1,0 +1,55 @@
+// common.hpp -- error plumbing and small RAII helpers shared by the host side.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string>
+#include <vector>
+
+namespace edlib_amd {
+
+// Thread-local text of the last failure (edlibAmdLastError()).
+std::string& last_error();
+void set_error(const char* fmt, ...);
+
+#define EDLIB_AMD_HIP(expr)                                                            \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            ::edlib_amd::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                   __FILE__, __LINE__);                                \
+            return 1;                                                                  \
+        }                                                                              \
+    } while (0)
+
+// Device allocation that frees itself.  Never holds host-visible result memory:
+// everything handed to the caller is libc malloc() (reference ownership rules,
+// edlib.h:177-205).
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    hipError_t alloc(size_t count) {
+        release();
+        if (count == 0) count = 1;
+        n = count;
+        return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    }
+    // grow-only
+    hipError_t ensure(size_t count) { return (count <= n && p) ? hipSuccess : alloc(count); }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+struct Event {
+    hipEvent_t e = nullptr;
+    ~Event() { if (e) (void)hipEventDestroy(e); }
+    hipError_t create() { return e ? hipSuccess : hipEventCreate(&e); }
+};
+
+}  // namespace edlib_amd

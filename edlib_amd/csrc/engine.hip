@@ -1,0 +1,721 @@
+// engine.hip -- batch orchestration (host) for the MI355X edit-distance engine.
+//
+// The reference does, per call (edlib.cpp:146-301): transform -> Peq -> k-doubling
+// scan -> (start locations) -> (path).  Here the same phases run once per BATCH:
+//   phase 1  distance + end locations   reads-per-lane kernel (shared target, <= 4
+//                                       target symbols, query <= 256) or
+//                                       block-per-lane kernel (everything else)
+//   phase 2  HW start locations         reverse SHW units on the block-per-lane kernel
+//                                       (edlib.cpp:230-266)
+//   phase 3  alignment path             NW units with column store + traceback kernel
+//                                       (edlib.cpp:276-289, 1161-1213)
+// There is no k-doubling and no band: the kernels compute the full matrix and the
+// user's k only filters the result (SURVEY.md §7 "results are band-independent").
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstring>
+#include <mutex>
+
+namespace edlib_amd {
+
+// ------------------------------------------------------------------- errors
+
+std::string& last_error() { static thread_local std::string s; return s; }
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    last_error() = buf;
+}
+
+int device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+// ------------------------------------------------------------------- tables
+
+static void build_tables(Tables& tab, const uint8_t* targets, long long totalTargetBytes,
+                         const EdlibEqualityPair* eqs, int neq) {
+    memset(tab.presence, 0, sizeof tab.presence);
+    memset(tab.tlut, 0, sizeof tab.tlut);
+    memset(tab.idToByte, 0, sizeof tab.idToByte);
+    bool seen[256] = {false};
+    tab.sigmaT = 0;
+    for (long long i = 0; i < totalTargetBytes; ++i) {
+        const uint8_t b = targets[i];
+        if (!seen[b]) {
+            seen[b] = true;
+            tab.tlut[b] = (uint8_t)tab.sigmaT;
+            tab.idToByte[tab.sigmaT] = b;
+            tab.presence[b >> 5] |= 1u << (b & 31);
+            ++tab.sigmaT;
+        }
+    }
+    // EqualityDefinition (edlib.cpp:63-94) on raw bytes.  The reference keeps a pair only
+    // when both characters occur in that call's alphabet; a pair whose characters do not
+    // occur can never be consulted, so the byte-level relation gives identical DP matrices.
+    tab.eq8.assign(256 * 256, 0);
+    for (int a = 0; a < 256; ++a) tab.eq8[a * 256 + a] = 1;
+    for (int i = 0; i < neq; ++i) {
+        const int a = (uint8_t)eqs[i].first, b = (uint8_t)eqs[i].second;
+        tab.eq8[a * 256 + b] = tab.eq8[b * 256 + a] = 1;
+    }
+    for (int q = 0; q < 256; ++q) {
+        uint8_t mask = 0;
+        for (int s = 0; s < tab.sigmaT && s < 4; ++s)
+            if (tab.eq8[q * 256 + tab.idToByte[s]]) mask |= (uint8_t)(1u << s);
+        tab.eqtbl4[q] = mask;
+    }
+}
+
+// --------------------------------------------------------- alphabetLength
+
+// Number of distinct byte values in query (and, for non-shared batches, target):
+// the alphabetLength field (edlib.cpp:162, transformSequences :1417-1462).
+// One wave per unit, 256-bit presence set OR-reduced across lanes.
+__global__ void __launch_bounds__(64)
+alphabet_count_kernel(const uint8_t* __restrict__ qpool, const long long* __restrict__ qoff,
+                      const uint8_t* __restrict__ tpool, const long long* __restrict__ toff,
+                      int shared, const uint32_t* __restrict__ basePresence,
+                      const int* __restrict__ unitIdx, int* __restrict__ out)
+{
+    const int u = unitIdx[blockIdx.x];
+    const int lane = threadIdx.x;
+    unsigned long long s[4] = {0, 0, 0, 0};
+    auto add = [&](uint32_t b) {
+        const unsigned long long bit = 1ull << (b & 63);
+        const uint32_t w = b >> 6;
+        s[0] |= (w == 0) ? bit : 0ull; s[1] |= (w == 1) ? bit : 0ull;
+        s[2] |= (w == 2) ? bit : 0ull; s[3] |= (w == 3) ? bit : 0ull;
+    };
+    const long long q0 = qoff[u], q1 = qoff[u + 1];
+    for (long long i = q0 + lane; i < q1; i += 64) add(qpool[i]);
+    if (!shared) {
+        const long long t0 = toff[u], t1 = toff[u + 1];
+        for (long long i = t0 + lane; i < t1; i += 64) add(tpool[i]);
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        for (int k = 0; k < 4; ++k) s[k] |= __shfl_xor(s[k], off);
+    if (shared)
+        for (int k = 0; k < 4; ++k)
+            s[k] |= ((unsigned long long)basePresence[2 * k + 1] << 32) | basePresence[2 * k];
+    if (lane == 0) out[blockIdx.x] = __popcll(s[0]) + __popcll(s[1]) + __popcll(s[2]) + __popcll(s[3]);
+}
+
+// overflow census of the reads path: how many slots need the exact second pass
+__global__ void __launch_bounds__(256)
+count_flags_kernel(const int* __restrict__ flags, int n, int* __restrict__ counter)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flags[i]) atomicAdd(counter, 1);
+}
+
+// --------------------------------------------------------------- Batch: init
+
+Batch::~Batch() {
+    (void)hipSetDevice(device_);
+    for (auto& p : scanEvents_) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+static int roundup(int x, int q) { return (x + q - 1) / q * q; }
+
+int Batch::init(const char* queries, const long long* qoff, int n, const char* targets,
+                const long long* toff, int numTargets, EdlibAlignConfig cfg, int device)
+{
+    if (n < 0 || (numTargets != 1 && numTargets != n)) { set_error("bad batch shape"); return 1; }
+    const int ndev = device_count();
+    if (ndev == 0) { set_error("no usable HIP device (this library has no CPU fallback)"); return 1; }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d devices)", device, ndev); return 1; }
+    cfg_ = cfg;
+    if (cfg.additionalEqualities && cfg.additionalEqualitiesLength > 0)
+        eqs_.assign(cfg.additionalEqualities, cfg.additionalEqualities + cfg.additionalEqualitiesLength);
+    cfg_.additionalEqualities = eqs_.empty() ? nullptr : eqs_.data();
+    cfg_.additionalEqualitiesLength = (int)eqs_.size();
+    device_ = device;
+    n_ = n;
+    shared_ = (numTargets == 1);
+    qoff_.assign(qoff, qoff + n + 1);
+    toff_.assign(toff, toff + numTargets + 1);
+    for (int u = 0; u < n; ++u) {
+        if (qoff_[u + 1] < qoff_[u] || qoff_[u + 1] - qoff_[u] > 0x7fffffffLL) { set_error("bad query offsets"); return 1; }
+    }
+    for (int u = 0; u < numTargets; ++u) {
+        if (toff_[u + 1] < toff_[u] || toff_[u + 1] - toff_[u] > 0x7fffffffLL) { set_error("bad target offsets"); return 1; }
+    }
+    const long long qbytes = qoff_[n] - qoff_[0], tbytes = toff_[numTargets] - toff_[0];
+    build_tables(tab_, reinterpret_cast<const uint8_t*>(targets) + toff_[0], tbytes,
+                 eqs_.data(), (int)eqs_.size());
+
+    EDLIB_AMD_HIP(hipSetDevice(device_));
+    EDLIB_AMD_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    EDLIB_AMD_HIP(evRun0_.create()); EDLIB_AMD_HIP(evRun1_.create());
+
+    // resident inputs (pools are rebased to offset 0)
+    const long long qb = qoff_[0], tb = toff_[0];
+    for (auto& v : qoff_) v -= qb;
+    for (auto& v : toff_) v -= tb;
+    EDLIB_AMD_HIP(d_qpool_.alloc((size_t)qbytes + 16));
+    EDLIB_AMD_HIP(d_tpool_.alloc((size_t)tbytes + 16));
+    EDLIB_AMD_HIP(d_qoff_.alloc(qoff_.size()));
+    EDLIB_AMD_HIP(d_toff_.alloc(toff_.size()));
+    EDLIB_AMD_HIP(d_tlut_.alloc(256)); EDLIB_AMD_HIP(d_idToByte_.alloc(256));
+    EDLIB_AMD_HIP(d_eq8_.alloc(65536)); EDLIB_AMD_HIP(d_eqtbl4_.alloc(256));
+    EDLIB_AMD_HIP(d_presence_.alloc(8));
+    if (qbytes) EDLIB_AMD_HIP(hipMemcpy(d_qpool_.p, queries + qb, (size_t)qbytes, hipMemcpyHostToDevice));
+    if (tbytes) EDLIB_AMD_HIP(hipMemcpy(d_tpool_.p, targets + tb, (size_t)tbytes, hipMemcpyHostToDevice));
+    EDLIB_AMD_HIP(hipMemcpy(d_qoff_.p, qoff_.data(), qoff_.size() * sizeof(long long), hipMemcpyHostToDevice));
+    EDLIB_AMD_HIP(hipMemcpy(d_toff_.p, toff_.data(), toff_.size() * sizeof(long long), hipMemcpyHostToDevice));
+    EDLIB_AMD_HIP(hipMemcpy(d_tlut_.p, tab_.tlut, 256, hipMemcpyHostToDevice));
+    EDLIB_AMD_HIP(hipMemcpy(d_idToByte_.p, tab_.idToByte, 256, hipMemcpyHostToDevice));
+    EDLIB_AMD_HIP(hipMemcpy(d_eq8_.p, tab_.eq8.data(), 65536, hipMemcpyHostToDevice));
+    EDLIB_AMD_HIP(hipMemcpy(d_eqtbl4_.p, tab_.eqtbl4, 256, hipMemcpyHostToDevice));
+    EDLIB_AMD_HIP(hipMemcpy(d_presence_.p, tab_.presence, 32, hipMemcpyHostToDevice));
+
+    // classification of the units for phase 1
+    const int mode = (int)cfg_.mode;
+    const bool readsOk = shared_ && tab_.sigmaT <= 4 && tlen(0) > 0;
+    std::vector<std::vector<int>> byWords(kMaxReadWords + 1);
+    for (int u = 0; u < n; ++u) {
+        const int m = qlen(u), T = tlen(u);
+        if (m == 0 || T == 0) emptyUnits_.push_back(u);
+        else if (readsOk && m <= 32 * kMaxReadWords) { readUnits_.push_back(u); byWords[(m + 31) / 32].push_back(u); }
+        else pairUnits_.push_back(u);
+    }
+    stats.cells = 0;
+    for (int u = 0; u < n; ++u) stats.cells += (long long)qlen(u) * tlen(u);
+
+    // reads-per-lane groups: one per query word count, slots padded to whole waves
+    const int T = shared_ ? tlen(0) : 0;
+    for (int w = 1; w <= kMaxReadWords; ++w) {
+        if (byWords[w].empty()) continue;
+        std::unique_ptr<ReadGroup> g(new ReadGroup);
+        g->nwords = w;
+        g->nslots = roundup((int)byWords[w].size(), 64);
+        g->perm.assign(g->nslots, -1);
+        std::copy(byWords[w].begin(), byWords[w].end(), g->perm.begin());
+        const int nrblk = g->nslots / 64;
+        if (mode == EDLIB_MODE_HW) {
+            // enough waves to fill 256 CUs x 4 SIMDs several times over, segments >= 4096 columns
+            long long S = (65536 + nrblk - 1) / nrblk;
+            const long long maxS = std::max(1, T / 4096);
+            S = std::max(1LL, std::min(S, maxS));
+            g->segLen = roundup((int)((T + S - 1) / S), 16);
+            g->numSegments = (T + g->segLen - 1) / g->segLen;
+            g->warm = 2 * 32 * w - 1;                        // 2m-1 columns
+        } else {
+            g->numSegments = 1; g->segLen = roundup(T, 16); g->warm = 0;
+        }
+        const size_t ns = (size_t)g->nslots, S = (size_t)g->numSegments;
+        EDLIB_AMD_HIP(g->d_perm.alloc(ns));
+        EDLIB_AMD_HIP(hipMemcpy(g->d_perm.p, g->perm.data(), ns * sizeof(int), hipMemcpyHostToDevice));
+        EDLIB_AMD_HIP(g->d_qlen.alloc(ns)); EDLIB_AMD_HIP(g->d_kinit.alloc(ns));
+        EDLIB_AMD_HIP(g->d_alphaExtra.alloc(ns));
+        EDLIB_AMD_HIP(g->d_peq.alloc(ns * 4 * w));
+        EDLIB_AMD_HIP(g->d_segBest.alloc(ns * S)); EDLIB_AMD_HIP(g->d_segCnt.alloc(ns * S));
+        EDLIB_AMD_HIP(g->d_segPos.alloc(ns * S * 8));
+        EDLIB_AMD_HIP(g->d_best.alloc(ns)); EDLIB_AMD_HIP(g->d_total.alloc(ns));
+        EDLIB_AMD_HIP(g->d_pos.alloc(ns * 16)); EDLIB_AMD_HIP(g->d_flags.alloc(ns + 1));
+        groups_.push_back(std::move(g));
+    }
+    if (!groups_.empty()) EDLIB_AMD_HIP(d_tpk_.alloc((size_t)(T + 15) / 16 + 4));
+    return 0;
+}
+
+// ------------------------------------------------------------- scan timing
+
+void Batch::scanTimerStart() {
+    if (scanEventsUsed_ == scanEvents_.size()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        scanEvents_.push_back({a, b});
+    }
+    (void)hipEventRecord(scanEvents_[scanEventsUsed_].first, stream_);
+}
+void Batch::scanTimerStop() {
+    (void)hipEventRecord(scanEvents_[scanEventsUsed_].second, stream_);
+    ++scanEventsUsed_;
+    ++stats.scan_launches;
+}
+
+// ------------------------------------------------- result semantics (host)
+
+// End locations of HW / SHW from the exact best bottom-row score over the target
+// columns and the complete ascending list of columns attaining it:
+//  * candidates are columns scoring <= min(k, m) (HW clamps k to m, edlib.cpp:566-568;
+//    SHW's best never exceeds m either);
+//  * the empty target prefix (position -1, score m) takes part exactly when the
+//    reference's padded last block would see it, i.e. when W = 64*ceil(m/64)-m > 0
+//    (edlib.cpp:661,670,681-693; oracle-verified: m=64 all-mismatch has no -1).
+static void finalize_semiglobal(UnitResult& r, int kcfg, int m, int best, const int* pos, long long npos) {
+    const int W = ((m + 63) / 64) * 64 - m;
+    const bool kAllowsM = (kcfg < 0 || kcfg >= m);
+    r.ends.clear();
+    if (best < 0) {
+        if (W > 0 && kAllowsM) { r.editDistance = m; r.ends.push_back(-1); r.hasEnds = true; }
+        else { r.editDistance = -1; r.hasEnds = false; }
+        return;
+    }
+    r.editDistance = best;
+    r.hasEnds = true;
+    if (W > 0 && best == m) r.ends.push_back(-1);
+    r.ends.insert(r.ends.end(), pos, pos + npos);
+}
+
+static void finalize_global(UnitResult& r, int kcfg, int mode, int T, int score) {
+    if (kcfg >= 0 && score > kcfg) { r.editDistance = -1; r.hasEnds = false; return; }   // edlib.cpp:744-747, 917
+    r.editDistance = score;
+    if (mode == EDLIB_MODE_NW) { r.hasEnds = true; r.ends.assign(1, T - 1); }              // edlib.cpp:221-225
+    else r.hasEnds = false;    // unknown mode: distance as NW, no end location
+}
+
+// ------------------------------------------------------- reads-per-lane path
+
+int Batch::runReads(std::vector<UnitResult>& res)
+{
+    if (groups_.empty()) return 0;
+    const int T = tlen(0);
+    // unknown mode values are computed as NW (edlib.cpp:205-215)
+    const int mode = (cfg_.mode == EDLIB_MODE_HW || cfg_.mode == EDLIB_MODE_SHW) ? (int)cfg_.mode : (int)EDLIB_MODE_NW;
+    stats.path |= 1;
+    EDLIB_AMD_HIP(launch_pack_target_2bit(d_tpool_.p, d_tlut_.p, T, d_tpk_.p, stream_));
+    for (auto& gp : groups_) {
+        ReadGroup& g = *gp;
+        EDLIB_AMD_HIP(launch_build_peq_reads(g.nwords, d_qpool_.p, d_qoff_.p, g.d_perm.p, g.nslots,
+                                             d_eqtbl4_.p, d_presence_.p, cfg_.k, g.d_peq.p, g.d_qlen.p,
+                                             g.d_kinit.p, g.d_alphaExtra.p, stream_));
+        ReadScanArgs a{};
+        a.peq = g.d_peq.p; a.tpk = d_tpk_.p; a.targetLength = T;
+        a.qlen = g.d_qlen.p; a.kinit = g.d_kinit.p; a.slotmap = nullptr; a.nlanes = g.nslots;
+        a.numSegments = g.numSegments; a.segLen = g.segLen; a.warm = g.warm;
+        a.segBest = g.d_segBest.p; a.segCnt = g.d_segCnt.p; a.segPos = g.d_segPos.p; a.cap = 8;
+        a.posOff = nullptr; a.posCap = nullptr;
+        scanTimerStart();
+        EDLIB_AMD_HIP(launch_scan_reads(g.nwords, mode, a, stream_));
+        scanTimerStop();
+        stats.word_steps += (long long)g.nslots * g.nwords *
+                            ((long long)T + (long long)(g.numSegments - 1) * g.warm);
+        EDLIB_AMD_HIP(launch_merge_segments(g.d_segBest.p, g.d_segCnt.p, g.d_segPos.p, g.numSegments, 8,
+                                            g.nslots, 16, g.d_best.p, g.d_total.p, g.d_pos.p,
+                                            g.d_flags.p, stream_));
+        // census of slots whose end-location list did not fit
+        int* counter = g.d_flags.p + g.nslots;
+        EDLIB_AMD_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream_));
+        hipLaunchKernelGGL(count_flags_kernel, dim3((g.nslots + 255) / 256), dim3(256), 0, stream_,
+                           g.d_flags.p, g.nslots, counter);
+    }
+    // collect
+    for (auto& gp : groups_) {
+        ReadGroup& g = *gp;
+        const size_t ns = (size_t)g.nslots;
+        std::vector<int> best(ns), total(ns), extra(ns), pos(ns * 16);
+        int novf = 0;
+        EDLIB_AMD_HIP(hipMemcpyAsync(best.data(), g.d_best.p, ns * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        EDLIB_AMD_HIP(hipMemcpyAsync(total.data(), g.d_total.p, ns * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        EDLIB_AMD_HIP(hipMemcpyAsync(extra.data(), g.d_alphaExtra.p, ns * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        EDLIB_AMD_HIP(hipMemcpyAsync(pos.data(), g.d_pos.p, ns * 16 * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        EDLIB_AMD_HIP(hipMemcpyAsync(&novf, g.d_flags.p + g.nslots, sizeof(int), hipMemcpyDeviceToHost, stream_));
+        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+
+        // exact second pass for the (rare) slots with more end locations than the first pass keeps
+        std::vector<int> ovfSlots; std::vector<long long> ovfOff; std::vector<int> ovfPos;
+        if (novf > 0 && mode != EDLIB_MODE_NW) {
+            std::vector<int> flags(ns);
+            EDLIB_AMD_HIP(hipMemcpy(flags.data(), g.d_flags.p, ns * sizeof(int), hipMemcpyDeviceToHost));
+            long long acc = 0;
+            std::vector<int> caps;
+            for (size_t s = 0; s < ns; ++s)
+                if (flags[s] && g.perm[s] >= 0) { ovfSlots.push_back((int)s); ovfOff.push_back(acc); caps.push_back(total[s]); acc += total[s]; }
+            ovfOff.push_back(acc);
+            const size_t no = ovfSlots.size();
+            if (no) {
+                DevBuf<int> d_map, d_caps, d_pool, d_sb, d_sc; DevBuf<long long> d_off;
+                EDLIB_AMD_HIP(d_map.alloc(no)); EDLIB_AMD_HIP(d_caps.alloc(no)); EDLIB_AMD_HIP(d_off.alloc(no));
+                EDLIB_AMD_HIP(d_pool.alloc((size_t)acc)); EDLIB_AMD_HIP(d_sb.alloc(no)); EDLIB_AMD_HIP(d_sc.alloc(no));
+                EDLIB_AMD_HIP(hipMemcpy(d_map.p, ovfSlots.data(), no * sizeof(int), hipMemcpyHostToDevice));
+                EDLIB_AMD_HIP(hipMemcpy(d_caps.p, caps.data(), no * sizeof(int), hipMemcpyHostToDevice));
+                EDLIB_AMD_HIP(hipMemcpy(d_off.p, ovfOff.data(), no * sizeof(long long), hipMemcpyHostToDevice));
+                ReadScanArgs a{};
+                a.peq = g.d_peq.p; a.tpk = d_tpk_.p; a.targetLength = T;
+                a.qlen = g.d_qlen.p; a.kinit = g.d_best.p;          // threshold = the exact best
+                a.slotmap = d_map.p; a.nlanes = (int)no;
+                a.numSegments = 1; a.segLen = roundup(T, 16); a.warm = 0;
+                a.segBest = d_sb.p; a.segCnt = d_sc.p; a.segPos = d_pool.p; a.cap = 0;
+                a.posOff = d_off.p; a.posCap = d_caps.p;
+                scanTimerStart();
+                EDLIB_AMD_HIP(launch_scan_reads(g.nwords, mode, a, stream_));
+                scanTimerStop();
+                stats.word_steps += (long long)roundup((int)no, 64) * g.nwords * (long long)T;
+                ovfPos.resize((size_t)acc);
+                EDLIB_AMD_HIP(hipMemcpyAsync(ovfPos.data(), d_pool.p, (size_t)acc * sizeof(int), hipMemcpyDeviceToHost, stream_));
+                EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+                stats.overflow_units += (int)no;
+            }
+        }
+        size_t oi = 0;
+        for (size_t s = 0; s < ns; ++s) {
+            const int u = g.perm[s];
+            if (u < 0) continue;
+            UnitResult& r = res[u];
+            r.alphabetLength = tab_.sigmaT + extra[s];
+            const int m = qlen(u);
+            if (mode == EDLIB_MODE_HW || mode == EDLIB_MODE_SHW) {
+                if (oi < ovfSlots.size() && ovfSlots[oi] == (int)s) {
+                    finalize_semiglobal(r, cfg_.k, m, best[s], ovfPos.data() + ovfOff[oi], ovfOff[oi + 1] - ovfOff[oi]);
+                    ++oi;
+                } else {
+                    finalize_semiglobal(r, cfg_.k, m, best[s], pos.data() + s * 16, best[s] < 0 ? 0 : total[s]);
+                }
+            } else {
+                finalize_global(r, cfg_.k, (int)cfg_.mode, T, best[s]);
+            }
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------ block-per-lane path
+
+static const int kPosCap = 16;
+
+int Batch::solve(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units, SolveOut& out)
+{
+    const size_t n = units.size();
+    out.score.assign(n, -1); out.count.assign(n, 0); out.last.assign(n, -1);
+    out.posStart.assign(n + 1, 0); out.posFlat.clear();
+    out.opsStart.assign(n + 1, 0); out.ops.clear();
+    if (n == 0) return 0;
+    stats.path |= 2;
+    // chunk so that the Peq pool and (for PATH) the column store stay within a budget
+    const long long peqBudget = 4LL << 30, storeBudget = 12LL << 30;
+    size_t a = 0;
+    while (a < n) {
+        long long peqBytes = 0, storeBytes = 0;
+        size_t b = a;
+        while (b < n) {
+            const long long nb = (units[b].qlen + 63) / 64;
+            const long long pb = nb * tab_.sigmaT * 8;
+            const long long sb = wantPath ? pair_store_entries(units[b].qlen, units[b].tlen) * 20 : 0;
+            if (b > a && (peqBytes + pb > peqBudget || storeBytes + sb > storeBudget)) break;
+            peqBytes += pb; storeBytes += sb; ++b;
+        }
+        if (solveChunk(mode, wantPositions, wantPath, units, a, b, out)) return 1;
+        a = b;
+    }
+    return 0;
+}
+
+int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units,
+                      size_t ua, size_t ub, SolveOut& out)
+{
+    const size_t n = ub - ua;
+    std::vector<PairDesc> descs(n);
+    std::vector<long long> opsOff(n + 1, 0);
+    long long peqWords = 0, auxInts = 0, storeEntries = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const UnitSpec& s = units[ua + i];
+        PairDesc& d = descs[i];
+        const long long nb = (s.qlen + 63) / 64;
+        d.qoff = s.qoff; d.toff = s.toff; d.qlen = s.qlen; d.tlen = s.tlen; d.qstep = s.qstep; d.tstep = s.tstep;
+        d.kinit = s.kinit;
+        d.peqOff = peqWords; peqWords += nb * tab_.sigmaT;
+        d.auxOff = auxInts; if (nb > 64) auxInts += s.tlen;
+        d.storeOff = storeEntries; if (wantPath) storeEntries += pair_store_entries(s.qlen, s.tlen);
+        d.posCap = wantPositions ? kPosCap : 0;
+        d.posOff = (long long)i * kPosCap;
+        opsOff[i + 1] = opsOff[i] + (wantPath ? (long long)s.qlen + s.tlen : 0);
+        stats.word_steps += 2 * nb * (long long)s.tlen;
+    }
+    EDLIB_AMD_HIP(d_descs_.ensure(n));
+    EDLIB_AMD_HIP(d_peq64_.ensure((size_t)peqWords));
+    EDLIB_AMD_HIP(d_aux_.ensure((size_t)auxInts));
+    EDLIB_AMD_HIP(d_outScore_.ensure(n)); EDLIB_AMD_HIP(d_outCount_.ensure(n)); EDLIB_AMD_HIP(d_outLast_.ensure(n));
+    EDLIB_AMD_HIP(d_posPool_.ensure(n * kPosCap));
+    if (wantPath) {
+        EDLIB_AMD_HIP(d_storeP_.ensure((size_t)storeEntries)); EDLIB_AMD_HIP(d_storeM_.ensure((size_t)storeEntries));
+        EDLIB_AMD_HIP(d_storeS_.ensure((size_t)storeEntries));
+        EDLIB_AMD_HIP(d_ops_.ensure((size_t)opsOff[n])); EDLIB_AMD_HIP(d_opsOff_.ensure(n + 1));
+        EDLIB_AMD_HIP(d_opsLen_.ensure(n));
+        EDLIB_AMD_HIP(hipMemcpyAsync(d_opsOff_.p, opsOff.data(), (n + 1) * sizeof(long long), hipMemcpyHostToDevice, stream_));
+    }
+    EDLIB_AMD_HIP(hipMemcpyAsync(d_descs_.p, descs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
+    EDLIB_AMD_HIP(launch_build_peq_pairs(d_descs_.p, (int)n, d_qpool_.p, d_eq8_.p, d_idToByte_.p, tab_.sigmaT,
+                                         d_peq64_.p, stream_));
+    PairScanArgs a{};
+    a.descs = d_descs_.p; a.numUnits = (int)n; a.qpool = d_qpool_.p; a.tpool = d_tpool_.p;
+    a.tlut = d_tlut_.p; a.sigmaT = tab_.sigmaT; a.peq = d_peq64_.p; a.aux = d_aux_.p;
+    a.storeP = d_storeP_.p; a.storeM = d_storeM_.p; a.storeS = d_storeS_.p;
+    a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p; a.posPool = d_posPool_.p;
+    scanTimerStart();
+    EDLIB_AMD_HIP(launch_scan_pairs(mode, wantPath, a, stream_));
+    scanTimerStop();
+    if (wantPath) {
+        TracebackArgs tb{};
+        tb.descs = d_descs_.p; tb.numUnits = (int)n; tb.score = d_outScore_.p;
+        tb.storeP = d_storeP_.p; tb.storeM = d_storeM_.p; tb.storeS = d_storeS_.p;
+        tb.ops = d_ops_.p; tb.opsOff = d_opsOff_.p; tb.opsLen = d_opsLen_.p;
+        EDLIB_AMD_HIP(launch_traceback(tb, stream_));
+    }
+    std::vector<int> score(n), count(n), last(n), pool, opsLen;
+    std::vector<uint8_t> ops;
+    EDLIB_AMD_HIP(hipMemcpyAsync(score.data(), d_outScore_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    EDLIB_AMD_HIP(hipMemcpyAsync(count.data(), d_outCount_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    EDLIB_AMD_HIP(hipMemcpyAsync(last.data(), d_outLast_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    if (wantPositions) {
+        pool.resize(n * kPosCap);
+        EDLIB_AMD_HIP(hipMemcpyAsync(pool.data(), d_posPool_.p, n * kPosCap * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    }
+    if (wantPath) {
+        opsLen.resize(n); ops.resize((size_t)opsOff[n]);
+        EDLIB_AMD_HIP(hipMemcpyAsync(opsLen.data(), d_opsLen_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        if (!ops.empty())
+            EDLIB_AMD_HIP(hipMemcpyAsync(ops.data(), d_ops_.p, ops.size(), hipMemcpyDeviceToHost, stream_));
+    }
+    EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+
+    // exact second pass for units with more end locations than kPosCap
+    std::vector<int> ovf; std::vector<long long> ovfOff(1, 0); std::vector<int> ovfPos;
+    if (wantPositions && mode != EDLIB_MODE_NW) {
+        for (size_t i = 0; i < n; ++i)
+            if (count[i] > kPosCap) { ovf.push_back((int)i); ovfOff.push_back(ovfOff.back() + count[i]); }
+        if (!ovf.empty()) {
+            std::vector<PairDesc> d2(ovf.size());
+            for (size_t j = 0; j < ovf.size(); ++j) {
+                d2[j] = descs[ovf[j]];
+                d2[j].kinit = score[ovf[j]]; d2[j].posCap = count[ovf[j]]; d2[j].posOff = ovfOff[j];
+            }
+            DevBuf<PairDesc> dd; DevBuf<int> pool2, s2, c2, l2;
+            EDLIB_AMD_HIP(dd.alloc(d2.size())); EDLIB_AMD_HIP(pool2.alloc((size_t)ovfOff.back()));
+            EDLIB_AMD_HIP(s2.alloc(d2.size())); EDLIB_AMD_HIP(c2.alloc(d2.size())); EDLIB_AMD_HIP(l2.alloc(d2.size()));
+            EDLIB_AMD_HIP(hipMemcpyAsync(dd.p, d2.data(), d2.size() * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
+            PairScanArgs a2 = a;
+            a2.descs = dd.p; a2.numUnits = (int)d2.size(); a2.posPool = pool2.p;
+            a2.outScore = s2.p; a2.outCount = c2.p; a2.outLast = l2.p;
+            scanTimerStart();
+            EDLIB_AMD_HIP(launch_scan_pairs(mode, false, a2, stream_));
+            scanTimerStop();
+            ovfPos.resize((size_t)ovfOff.back());
+            EDLIB_AMD_HIP(hipMemcpyAsync(ovfPos.data(), pool2.p, ovfPos.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
+            EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+            stats.overflow_units += (int)ovf.size();
+            for (size_t j = 0; j < ovf.size(); ++j) {
+                const PairDesc& d = d2[j];
+                stats.word_steps += 2LL * ((d.qlen + 63) / 64) * d.tlen;
+            }
+        }
+    }
+    size_t oj = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const size_t g = ua + i;
+        out.score[g] = score[i]; out.count[g] = count[i]; out.last[g] = last[i];
+        if (wantPositions && mode != EDLIB_MODE_NW && score[i] >= 0) {
+            if (oj < ovf.size() && ovf[oj] == (int)i) {
+                out.posFlat.insert(out.posFlat.end(), ovfPos.begin() + ovfOff[oj], ovfPos.begin() + ovfOff[oj + 1]);
+                ++oj;
+            } else {
+                out.posFlat.insert(out.posFlat.end(), pool.begin() + i * kPosCap, pool.begin() + i * kPosCap + count[i]);
+            }
+        }
+        out.posStart[g + 1] = (long long)out.posFlat.size();
+        if (wantPath) {
+            const uint8_t* e = ops.data() + opsOff[i + 1];
+            out.ops.insert(out.ops.end(), e - opsLen[i], e);
+        }
+        out.opsStart[g + 1] = (long long)out.ops.size();
+    }
+    return 0;
+}
+
+int Batch::alphabetLengths(const std::vector<int>& units, std::vector<UnitResult>& res)
+{
+    if (units.empty()) return 0;
+    DevBuf<int> d_idx, d_out;
+    EDLIB_AMD_HIP(d_idx.alloc(units.size())); EDLIB_AMD_HIP(d_out.alloc(units.size()));
+    EDLIB_AMD_HIP(hipMemcpyAsync(d_idx.p, units.data(), units.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+    hipLaunchKernelGGL(alphabet_count_kernel, dim3((unsigned)units.size()), dim3(64), 0, stream_,
+                       d_qpool_.p, d_qoff_.p, d_tpool_.p, d_toff_.p, shared_ ? 1 : 0, d_presence_.p,
+                       d_idx.p, d_out.p);
+    EDLIB_AMD_HIP(hipGetLastError());
+    std::vector<int> out(units.size());
+    EDLIB_AMD_HIP(hipMemcpyAsync(out.data(), d_out.p, out.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+    for (size_t i = 0; i < units.size(); ++i) res[units[i]].alphabetLength = out[i];
+    return 0;
+}
+
+// --------------------------------------------------------------------- run
+
+int Batch::run()
+{
+    EDLIB_AMD_HIP(hipSetDevice(device_));
+    const long long cells = stats.cells;
+    stats = EdlibAmdBatchStats{};
+    stats.cells = cells;
+    scanEventsUsed_ = 0;
+    haveResults_ = false;
+    std::vector<UnitResult> res(n_);
+    const int mode = (int)cfg_.mode;
+    const int scanMode = (mode == EDLIB_MODE_HW || mode == EDLIB_MODE_SHW) ? mode : EDLIB_MODE_NW;
+    EDLIB_AMD_HIP(hipEventRecord(evRun0_.e, stream_));
+
+    // ---- empty sequences: answered without any DP (edlib.cpp:166-184)
+    for (int u : emptyUnits_) {
+        UnitResult& r = res[u];
+        const int m = qlen(u), T = tlen(u);
+        if (mode == EDLIB_MODE_NW) { r.editDistance = std::max(m, T); r.ends.assign(1, T - 1); r.hasEnds = true; }
+        else if (mode == EDLIB_MODE_SHW || mode == EDLIB_MODE_HW) { r.editDistance = m; r.ends.assign(1, -1); r.hasEnds = true; }
+        else r.status = EDLIB_STATUS_ERROR;
+    }
+    // ---- phase 1: distance + end locations
+    if (runReads(res)) return 1;
+    if (!pairUnits_.empty()) {
+        std::vector<UnitSpec> units(pairUnits_.size());
+        for (size_t i = 0; i < units.size(); ++i) {
+            const int u = pairUnits_[i], m = qlen(u);
+            units[i] = UnitSpec{qoff_[u], m, 1, tbase(u), tlen(u), 1,
+                                (cfg_.k < 0 || cfg_.k > m) ? m : cfg_.k};
+        }
+        SolveOut so;
+        if (solve(scanMode, true, false, units, so)) return 1;
+        for (size_t i = 0; i < units.size(); ++i) {
+            UnitResult& r = res[pairUnits_[i]];
+            if (scanMode == EDLIB_MODE_NW) finalize_global(r, cfg_.k, mode, units[i].tlen, so.score[i]);
+            else finalize_semiglobal(r, cfg_.k, units[i].qlen, so.score[i], so.posFlat.data() + so.posStart[i],
+                                     so.posStart[i + 1] - so.posStart[i]);
+        }
+    }
+    {   // alphabetLength for everything the reads path did not cover
+        std::vector<int> rest(emptyUnits_);
+        rest.insert(rest.end(), pairUnits_.begin(), pairUnits_.end());
+        if (alphabetLengths(rest, res)) return 1;
+    }
+    std::vector<int> live;                     // non-empty units with a solution
+    for (int u = 0; u < n_; ++u)
+        if (qlen(u) > 0 && tlen(u) > 0 && res[u].editDistance >= 0) live.push_back(u);
+
+    // ---- phase 2: start locations (edlib.cpp:228-272)
+    if (cfg_.task == EDLIB_TASK_LOC || cfg_.task == EDLIB_TASK_PATH) {
+        std::vector<UnitSpec> units; std::vector<std::pair<int, int>> where;
+        for (int u : live) {
+            UnitResult& r = res[u];
+            r.hasStarts = true;
+            r.starts.assign(r.ends.size(), 0);
+            if (mode != EDLIB_MODE_HW) continue;
+            const int m = qlen(u);
+            for (size_t j = 0; j < r.ends.size(); ++j) {
+                const int e = r.ends[j];
+                if (e == -1) continue;                                   // :237-249
+                // reverse query against the reversed prefix target[0..e], prefix mode, k = distance
+                // (:253-257); columns past m+distance cannot score <= distance, so the window stops there
+                const long long win = std::min<long long>((long long)e + 1, (long long)m + r.editDistance);
+                units.push_back(UnitSpec{qoff_[u] + m - 1, m, -1, tbase(u) + e, (int)win, -1, r.editDistance});
+                where.push_back({u, (int)j});
+            }
+        }
+        if (!units.empty()) {
+            SolveOut so;
+            if (solve(EDLIB_MODE_SHW, false, false, units, so)) return 1;
+            for (size_t i = 0; i < units.size(); ++i) {
+                UnitResult& r = res[where[i].first];
+                // last reported position of the reverse scan (:260); -1 when only the empty prefix qualifies
+                r.starts[where[i].second] = r.ends[where[i].second] - so.last[i];
+            }
+        }
+    }
+    // ---- phase 3: alignment path of the first location (edlib.cpp:276-289, 1161-1213)
+    if (cfg_.task == EDLIB_TASK_PATH) {
+        std::vector<UnitSpec> units; std::vector<int> where;
+        for (int u : live) {
+            UnitResult& r = res[u];
+            if (r.ends.empty()) continue;
+            const int m = qlen(u);
+            const int s = r.starts[0], e = r.ends[0];
+            const int len = e - s + 1;
+            if (len <= 0) { r.ops.assign(m, EDLIB_EDOP_INSERT); r.hasAlignment = true; continue; }   // :1168-1175
+            const long long nb = (m + 63) / 64;
+            const long long bytes = (2LL * 8 + 4) * nb * len + 8LL * len;                             // :1188-1189
+            if (bytes >= 1024 * 1024) {
+                r.status = EDLIB_STATUS_ERROR;     // Hirschberg regime: not implemented
+                set_error("TASK_PATH for a %d x %d window needs the Hirschberg branch (not implemented)", m, len);
+                continue;
+            }
+            units.push_back(UnitSpec{qoff_[u], m, 1, tbase(u) + s, len, 1, 0});
+            where.push_back(u);
+        }
+        if (!units.empty()) {
+            SolveOut so;
+            if (solve(EDLIB_MODE_NW, false, true, units, so)) return 1;
+            for (size_t i = 0; i < units.size(); ++i) {
+                UnitResult& r = res[where[i]];
+                r.ops.assign(so.ops.begin() + so.opsStart[i], so.ops.begin() + so.opsStart[i + 1]);
+                r.hasAlignment = true;
+            }
+        }
+    }
+    EDLIB_AMD_HIP(hipEventRecord(evRun1_.e, stream_));
+    EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+    float ms = 0;
+    EDLIB_AMD_HIP(hipEventElapsedTime(&ms, evRun0_.e, evRun1_.e));
+    stats.run_ms = ms;
+    for (size_t i = 0; i < scanEventsUsed_; ++i) {
+        float t = 0;
+        EDLIB_AMD_HIP(hipEventElapsedTime(&t, scanEvents_[i].first, scanEvents_[i].second));
+        stats.scan_ms += t;
+    }
+    // algorithmic bytes: target + query + Peq + result header + end locations
+    stats.algo_bytes = 0;
+    for (int u = 0; u < n_; ++u) {
+        const long long m = qlen(u);
+        stats.algo_bytes += tlen(u) + m + 8LL * (res[u].alphabetLength + 1) * ((m + 63) / 64) + 16
+                            + 4LL * (long long)res[u].ends.size();
+    }
+    results_.swap(res);
+    haveResults_ = true;
+    return 0;
+}
+
+// ------------------------------------------------------------ marshalling
+
+static int* malloc_ints(const std::vector<int>& v) {
+    int* p = static_cast<int*>(malloc(sizeof(int) * std::max<size_t>(v.size(), 1)));
+    if (p && !v.empty()) memcpy(p, v.data(), v.size() * sizeof(int));
+    return p;
+}
+
+int Batch::results(EdlibAlignResult* out)
+{
+    if (!haveResults_) { set_error("results() before a successful run()"); return 1; }
+    for (int u = 0; u < n_; ++u) {
+        const UnitResult& r = results_[u];
+        EdlibAlignResult& o = out[u];
+        o.status = r.status;
+        o.editDistance = r.editDistance;
+        o.endLocations = nullptr; o.startLocations = nullptr; o.numLocations = 0;
+        o.alignment = nullptr; o.alignmentLength = 0;
+        o.alphabetLength = r.alphabetLength;
+        if (r.hasEnds) { o.endLocations = malloc_ints(r.ends); o.numLocations = (int)r.ends.size(); }
+        if (r.hasStarts) o.startLocations = malloc_ints(r.starts);
+        if (r.hasAlignment) {
+            o.alignment = static_cast<unsigned char*>(malloc(std::max<size_t>(r.ops.size(), 1)));
+            if (!r.ops.empty()) memcpy(o.alignment, r.ops.data(), r.ops.size());
+            o.alignmentLength = (int)r.ops.size();
+        }
+    }
+    return 0;
+}
+
+// ----------------------------------------------------------------- one pair
+
+int align_one(const char* q, int qn, const char* t, int tn, EdlibAlignConfig cfg, EdlibAlignResult* out)
+{
+    const long long qoff[2] = {0, qn}, toff[2] = {0, tn};
+    Batch b;
+    if (b.init(q, qoff, 1, t, toff, 1, cfg, 0)) return 1;
+    if (b.run()) return 1;
+    return b.results(out);
+}
+
+}  // namespace edlib_amd

@@ -1,0 +1,125 @@
+// engine.hpp -- host side of the engine: batches of alignment units resident in
+// HBM, scheduled onto the two kernel families.  This is the re-expression of the
+// orchestration in reference edlibAlign() (edlib.cpp:146-301) for a batch.
+#pragma once
+#include "../../include/edlib_amd.h"
+#include "common.hpp"
+#include "pair_kernels.hpp"
+#include "reads_kernels.hpp"
+
+#include <memory>
+#include <vector>
+
+namespace edlib_amd {
+
+// Byte-level tables shared by every unit of a batch:
+// the target alphabet and the equality relation of EqualityDefinition
+// (edlib.cpp:63-94) expressed on raw bytes.
+struct Tables {
+    uint8_t tlut[256];        // target byte -> symbol id (first appearance order)
+    uint8_t idToByte[256];    // symbol id -> byte
+    int sigmaT = 0;           // number of distinct target bytes
+    uint32_t presence[8];     // bitset of the target bytes
+    uint8_t eqtbl4[256];      // query byte -> 4-bit set of target symbols it equals (sigmaT <= 4)
+    std::vector<uint8_t> eq8; // [256*256] eq8[q*256+t] = 1 if bytes q and t are equal
+};
+
+// A unit handed to the block-per-lane kernels (host mirror of PairDesc).
+struct UnitSpec {
+    long long qoff; int qlen; int qstep;
+    long long toff; int tlen; int tstep;
+    int kinit;
+};
+
+struct SolveOut {
+    std::vector<int> score, count, last;
+    std::vector<long long> posStart;      // [units+1] into posFlat (exact, complete lists)
+    std::vector<int> posFlat;
+    std::vector<long long> opsStart;      // [units+1] into ops
+    std::vector<uint8_t> ops;
+};
+
+// Per-unit result assembled on the host before it is marshalled into
+// EdlibAlignResult (malloc'd arrays) by results().
+struct UnitResult {
+    int status = EDLIB_STATUS_OK;
+    int editDistance = -1;
+    int alphabetLength = 0;
+    bool hasEnds = false, hasStarts = false, hasAlignment = false;
+    std::vector<int> ends, starts;
+    std::vector<uint8_t> ops;
+};
+
+class Batch {
+public:
+    virtual ~Batch();
+    // sequences are copied to the device here; nothing of the caller's memory is retained
+    int init(const char* queries, const long long* qoff, int n,
+             const char* targets, const long long* toff, int numTargets,   // numTargets == 1: shared
+             EdlibAlignConfig cfg, int device);
+    int run();
+    int results(EdlibAlignResult* out);
+    EdlibAmdBatchStats stats{};
+
+private:
+    // ---- configuration
+    EdlibAlignConfig cfg_{};
+    std::vector<EdlibEqualityPair> eqs_;
+    int device_ = 0;
+    bool shared_ = false;
+    int n_ = 0;
+    std::vector<long long> qoff_, toff_;
+    Tables tab_;
+    hipStream_t stream_ = nullptr;
+    Event evRun0_, evRun1_, evA_, evB_;
+
+    // ---- resident inputs
+    DevBuf<uint8_t> d_qpool_, d_tpool_, d_tlut_, d_idToByte_, d_eq8_, d_eqtbl4_;
+    DevBuf<uint32_t> d_presence_;
+    DevBuf<long long> d_qoff_, d_toff_;
+
+    // ---- unit classification (phase 1)
+    std::vector<int> emptyUnits_, readUnits_, pairUnits_;
+
+    // ---- reads-per-lane path
+    struct ReadGroup {
+        int nwords = 0, nslots = 0, numSegments = 1, segLen = 0, warm = 0;
+        std::vector<int> perm;                 // slot -> unit (or -1)
+        DevBuf<int> d_perm, d_qlen, d_kinit, d_alphaExtra, d_segBest, d_segCnt, d_segPos;
+        DevBuf<int> d_best, d_total, d_pos, d_flags;
+        DevBuf<uint32_t> d_peq;
+    };
+    std::vector<std::unique_ptr<ReadGroup>> groups_;
+    DevBuf<uint32_t> d_tpk_;
+    int runReads(std::vector<UnitResult>& res);
+
+    // ---- block-per-lane path
+    DevBuf<PairDesc> d_descs_;
+    DevBuf<unsigned long long> d_peq64_, d_storeP_, d_storeM_;
+    DevBuf<int> d_storeS_, d_aux_, d_outScore_, d_outCount_, d_outLast_, d_posPool_, d_opsLen_, d_alpha_;
+    DevBuf<uint8_t> d_ops_;
+    DevBuf<long long> d_opsOff_;
+    int solve(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units, SolveOut& out);
+    int solveChunk(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units,
+                   size_t a, size_t b, SolveOut& out);
+    int alphabetLengths(const std::vector<int>& units, std::vector<UnitResult>& res);
+
+    int qlen(int u) const { return (int)(qoff_[u + 1] - qoff_[u]); }
+    long long tbase(int u) const { return shared_ ? toff_[0] : toff_[u]; }
+    int tlen(int u) const { return shared_ ? (int)(toff_[1] - toff_[0]) : (int)(toff_[u + 1] - toff_[u]); }
+
+    void scanTimerStart();
+    void scanTimerStop();
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> scanEvents_;
+    size_t scanEventsUsed_ = 0;
+
+    std::vector<UnitResult> results_;
+    bool haveResults_ = false;
+};
+
+// single-pair convenience used by edlibAlign()
+int align_one(const char* q, int qn, const char* t, int tn, EdlibAlignConfig cfg, EdlibAlignResult* out);
+
+int device_count();
+
+}  // namespace edlib_amd

@@ -1,0 +1,296 @@
+// pair_kernels.hip -- gfx950 kernels for independent (query, target) units of any
+// length, alphabet and mode: the general engine behind edlibAlign().
+//
+// Replaces myersCalcEditDistanceNW / myersCalcEditDistanceSemiGlobal
+// (edlib.cpp:730-928, 550-704), buildPeq (:358-384), calculateBlock (:412-447),
+// the AlignmentData column store (:22-47, 883-893) and obtainAlignmentTraceback
+// (:942-1141).  Design:
+//
+//   * one wave64 owns one unit.  Lane l holds one 64-row block of the query
+//     column (Pv, Mv as a 64-bit pair in VGPRs).  The only dependency inside a
+//     column is the horizontal delta hout -> hin between vertically adjacent
+//     blocks (edlib.cpp:781-785), so the wave runs the anti-diagonal schedule:
+//     at step t lane l works on column t-l, and {hout, target symbol} move one
+//     lane down per step in ONE v_mov_b32_dpp wave_shr:1 (lane 0 is fed the
+//     next target symbol and the row -1 boundary by the DPP `old` operand).
+//   * queries of more than 64 blocks are processed in strips of 64 blocks; the
+//     bottom row of a strip hands its horizontal deltas to the next strip
+//     through a per-unit buffer in HBM (written by lane 63, read back 64
+//     columns at a time, coalesced).
+//   * Peq rows live in LDS as [symbol][lane] so that a lane's 8-byte read hits a
+//     bank pair that depends on the lane only: conflict-free whatever symbols
+//     the 64 lanes are looking at.  The slice is refilled per strip from the
+//     HBM Peq pool with coalesced loads; the target is read 64 symbols per
+//     coalesced load and handed to lane 0 with v_readlane.
+//   * no Ukkonen band and no k-doubling: all outputs are functions of the full
+//     DP matrix, so every block of every column is computed once.
+//   * PATH: each block-step also stores (Pv, Mv, block score) in anti-diagonal
+//     order ([step][lane], one coalesced line per step); a second kernel walks
+//     back with the reference's candidate order up > left > diagonal.
+#include "pair_kernels.hpp"
+
+namespace edlib_amd {
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+
+__host__ __device__ static inline int num_blocks(int m) { return (m + 63) >> 6; }
+
+// Column store geometry: strip s (64 blocks, the last one maybe fewer) runs
+// T + nbS - 1 steps and writes nbS entries per step.
+__host__ __device__ static inline long long strip_base(int strip, int T) {
+    return (long long)strip * ((long long)T + 63) * 64;
+}
+__host__ __device__ static inline long long store_index(int T, int nb, int c, int b) {
+    const int strip = b >> 6, l = b & 63;
+    const int nbS = (nb - strip * 64) < 64 ? (nb - strip * 64) : 64;
+    return strip_base(strip, T) + (long long)(c + l) * nbS + l;
+}
+long long pair_store_entries(int qlen, int tlen) {
+    const int nb = num_blocks(qlen);
+    const int full = nb / 64, restBlocks = nb - full * 64;
+    long long n = strip_base(full, tlen);
+    if (restBlocks) n += ((long long)tlen + restBlocks - 1) * restBlocks;
+    return n;
+}
+
+// ------------------------------------------------------------------ buildPeq
+
+// One workgroup per unit; thread i handles (symbol, block) items i, i+256, ...
+// bit r of Peq[sym][b] = eq8[query[64b+r]][byte of sym]; rows past the query end are 0
+// (the kernels follow row m-1 explicitly, so the reference's wildcard padding,
+// edlib.cpp:373-375, is not needed).
+__global__ void __launch_bounds__(256)
+build_peq_pairs_kernel(const PairDesc* __restrict__ descs, const uint8_t* __restrict__ qpool,
+                       const uint8_t* __restrict__ eq8, const uint8_t* __restrict__ idToByte,
+                       int sigmaT, u64* __restrict__ peq)
+{
+    const PairDesc d = descs[blockIdx.x];
+    const int nb = num_blocks(d.qlen);
+    const int items = nb * sigmaT;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        const int s = it / nb, b = it - s * nb;
+        const uint8_t* row = eq8 + idToByte[s];            // eq8[q*256 + tbyte]
+        u64 w = 0;
+        const int r0 = b * 64;
+        const int rn = (d.qlen - r0) < 64 ? (d.qlen - r0) : 64;
+        for (int r = 0; r < rn; ++r) {
+            const u32 q = qpool[d.qoff + (long long)(r0 + r) * d.qstep];
+            w |= (u64)(row[q * 256] & 1) << r;
+        }
+        peq[d.peqOff + (long long)s * nb + b] = w;
+    }
+}
+
+hipError_t launch_build_peq_pairs(const PairDesc* descs, int numUnits, const uint8_t* qpool,
+                                  const uint8_t* eq8, const uint8_t* idToByte, int sigmaT,
+                                  u64* peq, hipStream_t stream)
+{
+    if (numUnits == 0) return hipSuccess;
+    hipLaunchKernelGGL(build_peq_pairs_kernel, dim3(numUnits), dim3(256), 0, stream,
+                       descs, qpool, eq8, idToByte, sigmaT, peq);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------- the scan
+
+// reference calculateBlock (edlib.cpp:412-447) on one 64-row block.  ph/mh return
+// the un-shifted horizontal delta vectors (bit r = row r of the block).
+__device__ __forceinline__ int advance_block64(u64& Pv, u64& Mv, u64 Eq, const int hin,
+                                               u64& phOut, u64& mhOut)
+{
+    const u64 hneg = (u64)(hin < 0), hpos = (u64)(hin > 0);
+    const u64 Xv = Eq | Mv;
+    Eq |= hneg;
+    const u64 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+    u64 Ph = Mv | ~(Xh | Pv);
+    u64 Mh = Pv & Xh;
+    phOut = Ph; mhOut = Mh;
+    const int hout = (int)(Ph >> 63) - (int)(Mh >> 63);
+    Ph = (Ph << 1) | hpos;
+    Mh = (Mh << 1) | hneg;
+    Pv = Mh | ~(Xv | Ph);
+    Mv = Ph & Xv;
+    return hout;
+}
+
+// MODE 0 NW, 1 SHW, 2 HW.  STORE: keep the column store.  LDSPEQ: Peq slice in LDS
+// (sigmaT <= 32), else gathered from the HBM pool.
+template <int MODE, bool STORE, bool LDSPEQ>
+__global__ void __launch_bounds__(64)
+scan_pairs_kernel(const PairScanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 s_peq[];     // [sigmaT][64]
+    const int lane = threadIdx.x;
+    const int unit = blockIdx.x;
+    const PairDesc d = a.descs[unit];
+    const int m = d.qlen, T = d.tlen;
+    const int nb = num_blocks(m);
+    const int nstrips = (nb + 63) >> 6;
+    const u32 sh = (u32)(m - 1) & 63u;                               // row m-1 inside the last block
+    const int topCode = (MODE == 2) ? 1 : 2;                         // hin+1 at row -1: HW 0, SHW/NW +1
+
+    int sc = m;                                                      // D[m][-1] (edlib.cpp:575-579)
+    int best = d.kinit, cnt = 0, lastCol = -1;
+    int* pos = a.posPool + d.posOff;
+
+    for (int strip = 0; strip < nstrips; ++strip) {
+        const int nbS = (nb - strip * 64) < 64 ? (nb - strip * 64) : 64;
+        const int b = strip * 64 + lane;
+        const bool laneOn = lane < nbS;
+        const bool lastStrip = strip == nstrips - 1;
+        const bool tracker = lastStrip && (b == nb - 1);             // lane that owns row m-1
+
+        if (LDSPEQ) {
+            __syncthreads();                                         // previous strip done with s_peq
+            for (int s = 0; s < a.sigmaT; ++s)
+                s_peq[s * 64 + lane] = laneOn ? a.peq[d.peqOff + (long long)s * nb + b] : 0ull;
+            __syncthreads();
+        }
+        u64 Pv = ~0ull, Mv = 0ull;                                   // column -1
+        int bscore = (b + 1) * 64;                                   // block bottom score (edlib.cpp:576)
+        int carry = 0;
+        int tchunk = 0, hchunk = topCode;
+        const long long sbase = STORE ? d.storeOff + strip_base(strip, T) : 0;
+        const int nsteps = T + nbS - 1;
+
+        for (int t = 0; t < nsteps; ++t) {
+            if ((t & 63) == 0) {                                     // refill 64 columns of input
+                const int c = t + lane;
+                tchunk = (c < T) ? a.tlut[a.tpool[d.toff + (long long)c * d.tstep]] : 0;
+                if (strip > 0)
+                    hchunk = (c < T) ? __hip_atomic_load(&a.aux[d.auxOff + c], __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT) : 1;
+            }
+            // lane 0 <- {next target symbol, row -1 delta}; lane l <- lane l-1's {symbol, hout}
+            const int in0 = __builtin_amdgcn_readlane(tchunk, t & 63)
+                          | (__builtin_amdgcn_readlane(hchunk, t & 63) << 8);
+            const int x = __builtin_amdgcn_update_dpp(in0, carry, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+            const int col = t - lane;
+            if (laneOn && col >= 0 && col < T) {
+                const int sym = x & 0xff;
+                const int hin = ((x >> 8) & 3) - 1;
+                const u64 eq = LDSPEQ ? s_peq[sym * 64 + lane]
+                                      : a.peq[d.peqOff + (long long)sym * nb + b];
+                u64 ph, mh;
+                const int hout = advance_block64(Pv, Mv, eq, hin, ph, mh);
+                bscore += hout;
+                carry = sym | ((hout + 1) << 8);
+                if (STORE) {
+                    const long long si = sbase + (long long)t * nbS + lane;
+                    a.storeP[si] = Pv; a.storeM[si] = Mv; a.storeS[si] = bscore;
+                }
+                if (!lastStrip && lane == 63) a.aux[d.auxOff + col] = hout + 1;
+                if (tracker) {
+                    sc += (int)((ph >> sh) & 1ull) - (int)((mh >> sh) & 1ull);
+                    if (MODE != 0 && sc <= best) {                   // edlib.cpp:658-673
+                        if (sc < best) { best = sc; cnt = 0; }
+                        if (cnt < d.posCap) pos[cnt] = col;
+                        ++cnt;
+                        lastCol = col;
+                    }
+                }
+            }
+        }
+        if (tracker) {
+            a.outScore[unit] = (MODE == 0) ? sc : (cnt > 0 ? best : -1);
+            a.outCount[unit] = (MODE == 0) ? 1 : cnt;
+            a.outLast[unit] = (MODE == 0) ? T - 1 : lastCol;
+        }
+        if (!lastStrip) __threadfence();                             // hand-off buffer visible to our own reloads
+    }
+}
+
+template <int MODE, bool STORE>
+static hipError_t launch_scan_pairs_t(const PairScanArgs& a, hipStream_t stream)
+{
+    if (a.sigmaT <= 32) {
+        const size_t lds = (size_t)a.sigmaT * 64 * sizeof(u64);
+        hipLaunchKernelGGL((scan_pairs_kernel<MODE, STORE, true>), dim3(a.numUnits), dim3(64), lds, stream, a);
+    } else {
+        hipLaunchKernelGGL((scan_pairs_kernel<MODE, STORE, false>), dim3(a.numUnits), dim3(64), 0, stream, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStream_t stream)
+{
+    if (a.numUnits == 0) return hipSuccess;
+    switch (mode * 2 + (store ? 1 : 0)) {
+        case 0: return launch_scan_pairs_t<0, false>(a, stream);
+        case 1: return launch_scan_pairs_t<0, true>(a, stream);
+        case 2: return launch_scan_pairs_t<1, false>(a, stream);
+        case 3: return launch_scan_pairs_t<1, true>(a, stream);
+        case 4: return launch_scan_pairs_t<2, false>(a, stream);
+        case 5: return launch_scan_pairs_t<2, true>(a, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// --------------------------------------------------------------- traceback
+
+// reference obtainAlignmentTraceback (edlib.cpp:942-1141), one lane per unit.
+// Walks from (m-1, T-1) to the origin on the stored (P, M, score) columns.  A
+// cell's neighbours are decoded on demand: up from the vertical delta bit of
+// the current column (:1007-1013), left from the left column's block score by
+// peeling the rows below it (:986-993, here a popcount), upper-left from left
+// and its vertical delta (:996-1000).  Candidate order up > left > diagonal
+// (:1020, 1054, 1085).  Ops are written back-to-front into the END of the
+// unit's range, so no reversal pass (:1138-1139) is needed.
+__global__ void __launch_bounds__(64)
+traceback_kernel(const TracebackArgs a)
+{
+    const int unit = blockIdx.x * blockDim.x + threadIdx.x;
+    if (unit >= a.numUnits) return;
+    const PairDesc d = a.descs[unit];
+    const int m = d.qlen, T = d.tlen, nb = num_blocks(m);
+    uint8_t* ops = a.ops + a.opsOff[unit];
+    int w = m + T;                                  // next write index is --w
+    int r = m - 1, c = T - 1, cur = a.score[unit];
+    const u64* SP = a.storeP + d.storeOff;
+    const u64* SM = a.storeM + d.storeOff;
+    const int* SS = a.storeS + d.storeOff;
+    for (;;) {
+        const int b = r >> 6, bit = r & 63;
+        const long long ic = store_index(T, nb, c, b);
+        const u64 Pc = SP[ic], Mc = SM[ic];
+        const int u = cur - ((int)((Pc >> bit) & 1ull) - (int)((Mc >> bit) & 1ull));
+        int l, ul;
+        if (c == 0) { l = r + 1; ul = r; }          // column -1 boundary (:976-980)
+        else {
+            const long long il = store_index(T, nb, c - 1, b);
+            const u64 Pl = SP[il], Ml = SM[il];
+            const u64 above = (bit == 63) ? 0ull : (~0ull << (bit + 1));   // rows below r in the block
+            l = SS[il] - __popcll(Pl & above) + __popcll(Ml & above);
+            ul = l - ((int)((Pl >> bit) & 1ull) - (int)((Ml >> bit) & 1ull));
+        }
+        if (u + 1 == cur) {                          // up: INSERT
+            cur = u;
+            ops[--w] = 1;
+            if (r == 0) { for (int i = 0; i < c + 1; ++i) ops[--w] = 2; break; }
+            --r;
+        } else if (l + 1 == cur) {                   // left: DELETE
+            cur = l;
+            ops[--w] = 2;
+            --c;
+            if (c == -1) { for (int i = 0; i < r + 1; ++i) ops[--w] = 1; break; }
+        } else {                                     // diagonal: MATCH / MISMATCH
+            ops[--w] = (ul == cur) ? 0 : 3;
+            cur = ul;
+            --c;
+            if (c == -1) { for (int i = 0; i < r; ++i) ops[--w] = 1; break; }
+            if (r == 0) { for (int i = 0; i < c + 1; ++i) ops[--w] = 2; break; }
+            --r;
+        }
+    }
+    a.opsLen[unit] = m + T - w;
+}
+
+hipError_t launch_traceback(const TracebackArgs& a, hipStream_t stream)
+{
+    if (a.numUnits == 0) return hipSuccess;
+    hipLaunchKernelGGL(traceback_kernel, dim3((a.numUnits + 63) / 64), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace edlib_amd

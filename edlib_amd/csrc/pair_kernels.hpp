@@ -1,0 +1,75 @@
+// pair_kernels.hpp -- launch interface of the "block-per-lane" family: one
+// wave64 owns one (query, target) unit, lanes are 64-row blocks of the query
+// column, the horizontal carry travels lane -> lane+1 by DPP.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace edlib_amd {
+
+// One unit of work.  Sequences are addressed inside device-resident byte pools;
+// step = -1 walks a sequence backwards (used for the reverse scans that find
+// HW start locations, reference edlib.cpp:230-266, without materialising
+// reversed copies).
+struct PairDesc {
+    long long qoff;      // first byte of the query in the query pool (last byte if qstep < 0)
+    long long toff;      // same for the target
+    long long peqOff;    // first word of this unit's Peq in the Peq pool: [sym][numBlocks]
+    long long storeOff;  // first entry of this unit's column store (PATH), in block-steps
+    long long auxOff;    // first int of this unit's strip hand-off buffer (targetLen ints)
+    int qlen;
+    int tlen;
+    int qstep;           // +1 / -1
+    int tstep;           // +1 / -1
+    int kinit;           // SHW/HW: columns scoring <= kinit are end-location candidates
+    int posCap;          // capacity of this unit's end-position list
+    long long posOff;    // first int of that list in the positions pool
+};
+
+struct PairScanArgs {
+    const PairDesc* descs;
+    int numUnits;
+    const uint8_t* qpool;
+    const uint8_t* tpool;
+    const uint8_t* tlut;        // [256] target byte -> symbol id (row of Peq)
+    int sigmaT;                 // number of target symbols (rows of Peq)
+    const unsigned long long* peq;   // Peq pool, built by launch_build_peq_pairs
+    int* aux;                   // strip hand-off pool (horizontal deltas of a strip's bottom row)
+    // column store for the traceback (may be null): anti-diagonal order, see pair_kernels.hip
+    unsigned long long* storeP;
+    unsigned long long* storeM;
+    int* storeS;
+    // outputs
+    int* outScore;              // [units] NW: D[m][T]; SHW/HW: best bottom-row score (or -1)
+    int* outCount;              // [units] SHW/HW: number of columns attaining it
+    int* outLast;               // [units] SHW/HW: last (largest) such column, -1 if none
+    int* posPool;               // end positions
+};
+
+// mode: 0 NW, 1 SHW, 2 HW.  store: also write the column store.
+hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStream_t stream);
+
+// reference buildPeq (edlib.cpp:358-384) for every unit: Peq[sym][block] from the
+// query bytes and the 256x256 byte equality matrix eq8 (identity + additionalEqualities).
+hipError_t launch_build_peq_pairs(const PairDesc* descs, int numUnits, const uint8_t* qpool,
+                                  const uint8_t* eq8, const uint8_t* idToByte, int sigmaT,
+                                  unsigned long long* peq, hipStream_t stream);
+
+struct TracebackArgs {
+    const PairDesc* descs;
+    int numUnits;
+    const int* score;           // [units] D[m][T] (start value of the walk)
+    const unsigned long long* storeP;
+    const unsigned long long* storeM;
+    const int* storeS;
+    uint8_t* ops;               // ops pool; unit u owns [opsOff[u], opsOff[u] + qlen + tlen)
+    const long long* opsOff;
+    int* opsLen;                // [units] number of ops; they occupy the END of the unit's range
+};
+// reference obtainAlignmentTraceback (edlib.cpp:942-1141)
+hipError_t launch_traceback(const TracebackArgs& a, hipStream_t stream);
+
+// number of block-steps the column store of a unit needs
+long long pair_store_entries(int qlen, int tlen);
+
+}  // namespace edlib_amd

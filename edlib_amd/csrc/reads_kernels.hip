@@ -1,0 +1,375 @@
+// reads_kernels.hip -- gfx950 kernels for "many short queries, one shared target".
+//
+// Replaces, for BASELINE.json configs 2/3, the reference's per-query call of
+// myersCalcEditDistanceSemiGlobal (edlib.cpp:550-704) + buildPeq (:358-384) +
+// calculateBlock (:412-447).  Design:
+//
+//   * one wave64 = 64 queries ("slots") x one segment of the target; every
+//     lane owns one query, so the target symbol of a column is WAVE-UNIFORM:
+//     it is fetched with scalar loads from the 2-bit packed target and picks,
+//     by a scalar 4-way branch, which of the lane's four Peq register rows
+//     feeds the column.  No cross-lane traffic, no LDS, no divergence in the
+//     DP itself.
+//   * the query column lives in VGPRs as NWD 32-bit words (Pv, Mv) instead of
+//     the reference's 64-bit blocks: 150 rows need 5 words (160 rows) rather
+//     than 3 blocks (192 rows).  The 64-bit add of calculateBlock becomes a
+//     v_add_co/v_addc_co carry chain, the <<1 a v_alignbit chain, and every
+//     3-input boolean a single v_bitop3_b32 (gfx950).  10 VALU ops per word
+//     per column.
+//   * no Ukkonen band: every output of the reference is a pure function of the
+//     full DP matrix, so the kernel computes all rows of every
+//     column (the reference itself touches 68 % of them on this workload) and
+//     never branches on data.
+//   * the score of the bottom query row is followed directly at bit (m-1) of
+//     the last word, so no wildcard padding (the reference's W) is needed and
+//     end positions are produced un-shifted.
+//   * HW is shift-invariant: a segment that starts 2m-1 columns early from the
+//     fresh state reproduces the exact bottom-row scores of its own columns,
+//     so the target is cut into segments for load balance and for small
+//     batches; merge_segments() joins them.
+#include "reads_kernels.hpp"
+
+namespace edlib_amd {
+
+typedef uint32_t u32;
+
+// ------------------------------------------------------------ target packing
+
+__global__ void __launch_bounds__(256)
+pack_target_2bit_kernel(const uint8_t* __restrict__ raw, const uint8_t* __restrict__ lut,
+                        int T, u32* __restrict__ tpk, int nwords)
+{
+    __shared__ uint8_t s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    const int base = w * 16;
+    u32 out = 0;
+    if (base + 16 <= T) {
+        const uint4 v = *reinterpret_cast<const uint4*>(raw + base);   // 16 B per lane, coalesced
+        const u32 d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            out |= (u32)(s_lut[(d[i >> 2] >> ((i & 3) * 8)) & 0xFF] & 3) << (2 * i);
+    } else {
+        for (int i = 0; i < 16 && base + i < T; ++i)
+            out |= (u32)(s_lut[raw[base + i]] & 3) << (2 * i);
+    }
+    tpk[w] = out;
+}
+
+hipError_t launch_pack_target_2bit(const uint8_t* raw, const uint8_t* lut, int T, u32* tpk,
+                                   hipStream_t stream)
+{
+    const int nwords = (T + 15) / 16;
+    if (nwords == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_target_2bit_kernel, dim3((nwords + 255) / 256), dim3(256), 0, stream,
+                       raw, lut, T, tpk, nwords);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ buildPeq
+
+// reference buildPeq (edlib.cpp:358-384) restricted to the (<= 4) symbols of the
+// target: bit i of row s says "query[i] equals target symbol s".  eqtbl[byte] is
+// the 4-bit set of target symbols a query byte equals (identity plus
+// additionalEqualities, edlib.cpp:63-94).  Rows at or past the query end stay 0.
+// Output layout [readBlock][sym][word][lane]: a wave loads a row as one 256 B line.
+template <int NWD>
+__global__ void __launch_bounds__(256)
+build_peq_reads_kernel(const uint8_t* __restrict__ reads, const long long* __restrict__ qoff,
+                       const int* __restrict__ perm, int nslots,
+                       const uint8_t* __restrict__ eqtbl, const u32* __restrict__ tpres, int kcfg,
+                       u32* __restrict__ peq, int* __restrict__ qlen, int* __restrict__ kinit,
+                       int* __restrict__ alphaExtra)
+{
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nslots) return;
+    const int r = perm[slot];
+    u32 E[4][NWD];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int d = 0; d < NWD; ++d) E[s][d] = 0;
+    int m = 1, extra = 0;
+    if (r >= 0) {
+        const long long off = qoff[r];
+        m = (int)(qoff[r + 1] - off);
+        // distinct query bytes that do not occur in the target (for alphabetLength)
+        unsigned long long seen0 = ((unsigned long long)tpres[1] << 32) | tpres[0];
+        unsigned long long seen1 = ((unsigned long long)tpres[3] << 32) | tpres[2];
+        unsigned long long seen2 = ((unsigned long long)tpres[5] << 32) | tpres[4];
+        unsigned long long seen3 = ((unsigned long long)tpres[7] << 32) | tpres[6];
+#pragma unroll
+        for (int d = 0; d < NWD; ++d) {
+            u32 e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+            for (int j = 0; j < 32; ++j) {
+                const int i = d * 32 + j;
+                if (i >= m) break;
+                const u32 b = reads[off + i];
+                const u32 mask = eqtbl[b];
+                e0 |= (mask & 1u) << j;
+                e1 |= ((mask >> 1) & 1u) << j;
+                e2 |= ((mask >> 2) & 1u) << j;
+                e3 |= ((mask >> 3) & 1u) << j;
+                const unsigned long long bit = 1ull << (b & 63);
+                const u32 w = b >> 6;
+                unsigned long long cur = w == 0 ? seen0 : w == 1 ? seen1 : w == 2 ? seen2 : seen3;
+                if (!(cur & bit)) {
+                    ++extra;
+                    if (w == 0) seen0 |= bit; else if (w == 1) seen1 |= bit;
+                    else if (w == 2) seen2 |= bit; else seen3 |= bit;
+                }
+            }
+            E[0][d] = e0; E[1][d] = e1; E[2][d] = e2; E[3][d] = e3;
+        }
+    }
+    const int blk = slot >> 6, lane = slot & 63;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int d = 0; d < NWD; ++d)
+            peq[((size_t)(blk * 4 + s) * NWD + d) * 64 + lane] = E[s][d];
+    qlen[slot] = m;
+    // candidates are columns scoring <= min(k, m): HW clamps k to m (edlib.cpp:566-568) and
+    // for SHW the best score never exceeds m either (the empty prefix costs m)
+    kinit[slot] = (kcfg < 0 || kcfg > m) ? m : kcfg;
+    alphaExtra[slot] = extra;
+}
+
+template <int NWD>
+static hipError_t launch_build_peq_t(const uint8_t* reads, const long long* qoff, const int* perm,
+                                     int nslots, const uint8_t* eqtbl, const u32* tpres, int kcfg,
+                                     u32* peq, int* qlen, int* kinit, int* alphaExtra,
+                                     hipStream_t stream)
+{
+    hipLaunchKernelGGL(build_peq_reads_kernel<NWD>, dim3((nslots + 255) / 256), dim3(256), 0, stream,
+                       reads, qoff, perm, nslots, eqtbl, tpres, kcfg, peq, qlen, kinit, alphaExtra);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_peq_reads(int nwords, const uint8_t* reads, const long long* qoff,
+                                  const int* perm, int nslots, const uint8_t* eqtbl,
+                                  const u32* tpres, int kcfg, u32* peq, int* qlen, int* kinit,
+                                  int* alphaExtra, hipStream_t stream)
+{
+    if (nslots == 0) return hipSuccess;
+    switch (nwords) {
+#define CASE(N) case N: return launch_build_peq_t<N>(reads, qoff, perm, nslots, eqtbl, tpres, kcfg, peq, qlen, kinit, alphaExtra, stream);
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------- the scan
+
+// One column of the Myers recurrence over NWD 32-bit words held in VGPRs
+// (reference calculateBlock, edlib.cpp:412-447, with hin fixed by the top
+// boundary: 0 for HW, +1 for SHW/NW -- hin is never negative at row -1, so the
+// "Eq |= hinIsNeg" term vanishes).  Also advances the bottom-row score by the
+// horizontal delta of row m-1 (bit `sh` of the last word).
+template <int NWD, int MODE>
+__device__ __forceinline__ void column_step(const u32 (&Eq)[NWD], u32 (&Pv)[NWD], u32 (&Mv)[NWD],
+                                            int& score, const u32 sh)
+{
+    u32 Ph[NWD], Mh[NWD];
+    u32 carry = 0;
+#pragma unroll
+    for (int i = 0; i < NWD; ++i) {
+        const u32 t = Eq[i] & Pv[i];
+        u32 cout;
+        const u32 s = __builtin_addc(t, Pv[i], carry, &cout);     // v_add_co / v_addc_co chain
+        carry = cout;
+        const u32 Xh = (s ^ Pv[i]) | Eq[i];
+        Ph[i] = Mv[i] | ~(Xh | Pv[i]);
+        Mh[i] = Pv[i] & Xh;
+    }
+    score += (int)__builtin_amdgcn_ubfe(Ph[NWD - 1], sh, 1) + __builtin_amdgcn_sbfe(Mh[NWD - 1], sh, 1);
+#pragma unroll
+    for (int i = NWD - 1; i >= 0; --i) {
+        u32 ph, mh;
+        if (i > 0) {
+            ph = __builtin_amdgcn_alignbit(Ph[i], Ph[i - 1], 31);   // (Ph << 1) across words
+            mh = __builtin_amdgcn_alignbit(Mh[i], Mh[i - 1], 31);
+        } else {
+            ph = (Ph[0] << 1) | (MODE == 2 ? 0u : 1u);             // row -1: HW 0, SHW/NW +1 (edlib.cpp:584,779)
+            mh = Mh[0] << 1;
+        }
+        const u32 Xv = Eq[i] | Mv[i];
+        Pv[i] = mh | ~(Xv | ph);
+        Mv[i] = ph & Xv;
+    }
+}
+
+// The distinct asm comments keep the four bodies from being tail-merged back
+// into one body fed by v_mov/v_cndmask of the Peq row.
+#define EDLIB_AMD_DISPATCH_COLUMN(sym)                                                     \
+    switch (sym) {                                                                         \
+        case 0:  column_step<NWD, MODE>(E0, Pv, Mv, score, sh); asm volatile("; sym0"); break; \
+        case 1:  column_step<NWD, MODE>(E1, Pv, Mv, score, sh); asm volatile("; sym1"); break; \
+        case 2:  column_step<NWD, MODE>(E2, Pv, Mv, score, sh); asm volatile("; sym2"); break; \
+        default: column_step<NWD, MODE>(E3, Pv, Mv, score, sh); asm volatile("; sym3"); break; \
+    }
+
+// Record column `col` if it ties or improves the best bottom-row score
+// (reference edlib.cpp:658-673: "colScore <= k", "positions.clear()", "k = bestScore").
+#define EDLIB_AMD_TRACK(col)                                   \
+    if (score <= best) {                                       \
+        if (score < best) { best = score; cnt = 0; }           \
+        if (cnt < cap) pos[cnt] = (col);                       \
+        ++cnt;                                                 \
+    }
+
+template <int NWD, int MODE>
+__global__ void __launch_bounds__(256)
+scan_reads_kernel(const ReadScanArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int rblk = blockIdx.x * 4 + (threadIdx.x >> 6);          // 4 waves / workgroup
+    const int seg = blockIdx.y;
+    const int idx = rblk * 64 + lane;                              // lane index in this launch
+    if (rblk * 64 >= a.nlanes) return;                             // whole wave out of range
+    const bool live = idx < a.nlanes;
+    const int slot = live ? (a.slotmap ? a.slotmap[idx] : idx) : 0;
+
+    u32 E0[NWD], E1[NWD], E2[NWD], E3[NWD], Pv[NWD], Mv[NWD];
+    {
+        const size_t pb = (size_t)(slot >> 6) * 4 * NWD * 64 + (slot & 63);
+#pragma unroll
+        for (int d = 0; d < NWD; ++d) {
+            E0[d] = a.peq[pb + (size_t)(0 * NWD + d) * 64];
+            E1[d] = a.peq[pb + (size_t)(1 * NWD + d) * 64];
+            E2[d] = a.peq[pb + (size_t)(2 * NWD + d) * 64];
+            E3[d] = a.peq[pb + (size_t)(3 * NWD + d) * 64];
+            Pv[d] = ~0u;                                           // column -1: D[i][-1] = i+1 (edlib.cpp:575-579)
+            Mv[d] = 0u;
+        }
+    }
+    const int m = a.qlen[slot];
+    const u32 sh = (u32)(m - 1) & 31u;
+    int score = m;
+    int best = a.kinit[slot];
+    int cnt = 0;
+    int cap = a.posCap ? a.posCap[idx] : a.cap;
+    int* pos = a.segPos + (a.posOff ? a.posOff[idx] : ((long long)idx * a.numSegments + seg) * a.cap);
+    if (!live) cap = 0;
+
+    const int T = a.targetLength;
+    const int c0 = seg * a.segLen;                                 // multiple of 16
+    int c1 = c0 + a.segLen; if (c1 > T) c1 = T;
+    int cw = c0 - a.warm; if (cw < 0) cw = 0;
+    cw &= ~15;
+
+    // warm-up columns [cw, c0): state only, nothing is recorded (HW segments)
+    for (int w = cw >> 4; w < (c0 >> 4); ++w) {
+        const u32 tw = a.tpk[w];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const u32 sym = (tw >> (2 * j)) & 3u;
+            EDLIB_AMD_DISPATCH_COLUMN(sym)
+        }
+    }
+    // full words of the segment
+    const int wend = c1 >> 4;
+    for (int w = c0 >> 4; w < wend; ++w) {
+        const u32 tw = a.tpk[w];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const u32 sym = (tw >> (2 * j)) & 3u;
+            EDLIB_AMD_DISPATCH_COLUMN(sym)
+            if (MODE != 0) { EDLIB_AMD_TRACK(w * 16 + j) }
+        }
+    }
+    // ragged tail of the target (last segment only)
+    const int rem = c1 - (wend << 4);
+    if (rem > 0) {
+        u32 tw = a.tpk[wend];
+        for (int j = 0; j < rem; ++j) {
+            const u32 sym = tw & 3u;
+            tw >>= 2;
+            EDLIB_AMD_DISPATCH_COLUMN(sym)
+            if (MODE != 0) { EDLIB_AMD_TRACK(wend * 16 + j) }
+        }
+    }
+    if (live) {
+        const size_t o = (size_t)idx * a.numSegments + seg;
+        a.segBest[o] = (MODE == 0) ? score : best;                 // NW: D[m][T] (edlib.cpp:914-917)
+        a.segCnt[o] = (MODE == 0) ? 1 : cnt;
+    }
+}
+
+template <int NWD>
+static hipError_t launch_scan_mode(int mode, const ReadScanArgs& a, hipStream_t stream)
+{
+    const int nrblk = (a.nlanes + 63) / 64;
+    dim3 grid((nrblk + 3) / 4, a.numSegments), block(256);
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((scan_reads_kernel<NWD, 0>), grid, block, 0, stream, a); break;
+        case 1: hipLaunchKernelGGL((scan_reads_kernel<NWD, 1>), grid, block, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((scan_reads_kernel<NWD, 2>), grid, block, 0, stream, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_reads(int nwords, int mode, const ReadScanArgs& a, hipStream_t stream)
+{
+    if (a.nlanes == 0) return hipSuccess;
+    switch (nwords) {
+#define CASE(N) case N: return launch_scan_mode<N>(mode, a, stream);
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------- the merge
+
+// Joins the per-segment records of a slot: global best, number of columns
+// attaining it, and the first capFinal positions in ascending order
+// (reference semantics of positions_, edlib.cpp:662-671).  flags bit0 = the
+// list is incomplete (a segment or the final list overflowed): the host runs
+// the exact second pass for that slot.
+__global__ void __launch_bounds__(256)
+merge_segments_kernel(const int* __restrict__ segBest, const int* __restrict__ segCnt,
+                      const int* __restrict__ segPos, int S, int cap, int nslots, int capFinal,
+                      int* __restrict__ best, int* __restrict__ total, int* __restrict__ pos,
+                      int* __restrict__ flags)
+{
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nslots) return;
+    const size_t base = (size_t)slot * S;
+    int b = 0x7fffffff;
+    for (int s = 0; s < S; ++s)
+        if (segCnt[base + s] > 0 && segBest[base + s] < b) b = segBest[base + s];
+    int n = 0, ovf = 0;
+    if (b != 0x7fffffff) {
+        for (int s = 0; s < S; ++s) {
+            const int c = segCnt[base + s];
+            if (c <= 0 || segBest[base + s] != b) continue;
+            if (c > cap) ovf = 1;
+            const int take = c < cap ? c : cap;
+            for (int i = 0; i < take; ++i)
+                if (n + i < capFinal) pos[(size_t)slot * capFinal + n + i] = segPos[(base + s) * cap + i];
+            n += c;
+        }
+        if (n > capFinal) ovf = 1;
+    }
+    best[slot] = (b == 0x7fffffff) ? -1 : b;
+    total[slot] = n;
+    flags[slot] = ovf;
+}
+
+hipError_t launch_merge_segments(const int* segBest, const int* segCnt, const int* segPos, int S,
+                                 int cap, int nslots, int capFinal, int* best, int* total, int* pos,
+                                 int* flags, hipStream_t stream)
+{
+    if (nslots == 0) return hipSuccess;
+    hipLaunchKernelGGL(merge_segments_kernel, dim3((nslots + 255) / 256), dim3(256), 0, stream,
+                       segBest, segCnt, segPos, S, cap, nslots, capFinal, best, total, pos, flags);
+    return hipGetLastError();
+}
+
+}  // namespace edlib_amd

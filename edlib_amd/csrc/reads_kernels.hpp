@@ -1,0 +1,50 @@
+// reads_kernels.hpp -- launch interface of the "reads-per-lane" scan family
+// (many short queries against one shared target; BASELINE.json configs 2/3).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace edlib_amd {
+
+constexpr int kMaxReadWords = 8;      // queries up to 256 symbols stay in VGPRs
+constexpr int kLanes = 64;            // wave64, hard-coded (gfx950)
+
+// Everything the scan kernel needs; plain pointers into HBM.
+struct ReadScanArgs {
+    const uint32_t* peq;      // [readBlock][4 symbols][NWD words][64 lanes]
+    const uint32_t* tpk;      // target, 2 bits / symbol, 16 symbols / dword, LSB first
+    int targetLength;
+    const int* qlen;          // [slots] query length of the read in that slot (>= 1)
+    const int* kinit;         // [slots] initial threshold: columns scoring <= kinit are candidates
+    const int* slotmap;       // optional [lanes] lane -> slot indirection (second, exact pass)
+    int nlanes;               // number of lanes to run (slots, or entries of slotmap)
+    int numSegments;          // target split into this many segments (HW only; else 1)
+    int segLen;               // columns per segment, multiple of 16
+    int warm;                 // warm-up columns before a segment (2*maxQueryLen-1 for HW)
+    int* segBest;             // [lanes][numSegments] best score seen in the segment (NW: final score)
+    int* segCnt;              // [lanes][numSegments] number of columns attaining it
+    int* segPos;              // positions pool
+    int cap;                  // positions kept per (lane, segment) when posOff == nullptr
+    const long long* posOff;  // optional [lanes] offset into segPos (exact pass)
+    const int* posCap;        // optional [lanes] capacity (exact pass)
+};
+
+// mode: 0 NW, 1 SHW, 2 HW (values of EdlibAlignMode).  Returns hipSuccess or the launch error.
+hipError_t launch_scan_reads(int nwords, int mode, const ReadScanArgs& a, hipStream_t stream);
+
+hipError_t launch_pack_target_2bit(const uint8_t* raw, const uint8_t* lut, int targetLength,
+                                   uint32_t* tpk, hipStream_t stream);
+
+// Builds Peq for every slot (reference buildPeq, edlib.cpp:358-384, for the <=4 target symbols),
+// the per-slot query length and the number of query byte values absent from the target.
+hipError_t launch_build_peq_reads(int nwords, const uint8_t* reads, const long long* qoff,
+                                  const int* perm, int nslots, const uint8_t* eqtbl,
+                                  const uint32_t* targetPresence /*8 dwords*/, int kcfg,
+                                  uint32_t* peq, int* qlen, int* kinit, int* alphaExtra,
+                                  hipStream_t stream);
+
+hipError_t launch_merge_segments(const int* segBest, const int* segCnt, const int* segPos,
+                                 int numSegments, int cap, int nslots, int capFinal,
+                                 int* best, int* total, int* pos, int* flags, hipStream_t stream);
+
+}  // namespace edlib_amd

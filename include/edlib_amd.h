@@ -1,0 +1,96 @@
+/*
+ * edlib_amd.h -- additive batch surface of the MI355X edit-distance engine.
+ *
+ * edlib.h (the reference's five symbols) stays untouched; everything here is
+ * new.  The natural batching site in the reference is the per-query loop of
+ * its CLI (apps/aligner/aligner.cpp:162-225: one edlibAlign() per query
+ * against the same target) and, for pairwise work, any caller that loops over
+ * edlibAlign() (bindings/python/edlib.pyx:128-129).  These entry points take
+ * the whole loop at once so the GPU sees a batch.
+ *
+ * All functions are plain C ABI: pointers + sizes, no C++ or torch types.
+ * Return value: EDLIB_STATUS_OK (0) / EDLIB_STATUS_ERROR (1) unless stated;
+ * edlibAmdLastError() gives the reason.  There is no CPU fallback: without a
+ * usable HIP device every compute entry point fails with EDLIB_STATUS_ERROR.
+ */
+#ifndef EDLIB_AMD_H
+#define EDLIB_AMD_H
+
+#include "edlib.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- process */
+
+/* Number of usable HIP devices (0 when the runtime or a device is missing). */
+EDLIB_API int edlibAmdDeviceCount(void);
+/* Message of the last failing call on this thread ("" if none). */
+EDLIB_API const char* edlibAmdLastError(void);
+EDLIB_API const char* edlibAmdVersion(void);
+
+/* ------------------------------------------------------- one-shot batches */
+
+/* numQueries queries against ONE target: replaces the loop
+ * `for q: results[q] = edlibAlign(queries[q], .., target, .., config)`
+ * (apps/aligner/aligner.cpp:162-172).  results[] must hold numQueries
+ * entries; each is exactly what edlibAlign() would have returned and is
+ * released the same way (edlibFreeAlignResult / free). */
+EDLIB_API int edlibAlignBatchSharedTarget(
+    const char* const* queries, const int* queryLengths, int numQueries,
+    const char* target, int targetLength,
+    EdlibAlignConfig config, EdlibAlignResult* results);
+
+/* numPairs independent (query, target) pairs: replaces
+ * `for i: results[i] = edlibAlign(queries[i], .., targets[i], .., config)`. */
+EDLIB_API int edlibAlignBatchPairs(
+    const char* const* queries, const int* queryLengths,
+    const char* const* targets, const int* targetLengths, int numPairs,
+    EdlibAlignConfig config, EdlibAlignResult* results);
+
+/* ------------------------------------------- resident batches (sessions) */
+/* Upload once, run many times with everything resident in HBM; this is what
+ * bench.py times.  Sequences are passed packed: `queries` is the
+ * concatenation of all query bytes and queryOffsets[i]..queryOffsets[i+1]
+ * delimits query i (numQueries+1 offsets). */
+
+typedef struct EdlibAmdBatch EdlibAmdBatch;
+
+EDLIB_API EdlibAmdBatch* edlibAmdBatchCreateShared(
+    const char* queries, const long long* queryOffsets, int numQueries,
+    const char* target, int targetLength,
+    EdlibAlignConfig config, int device);
+
+EDLIB_API EdlibAmdBatch* edlibAmdBatchCreatePairs(
+    const char* queries, const long long* queryOffsets,
+    const char* targets, const long long* targetOffsets, int numPairs,
+    EdlibAlignConfig config, int device);
+
+/* One pass of the device path over the resident batch (encode target, build
+ * the query profiles, scan, merge; for LOC/PATH also start locations and
+ * traceback), then wait for it.  Results stay on the device. */
+EDLIB_API int edlibAmdBatchRun(EdlibAmdBatch* batch);
+
+/* Copy the results of the last Run to the host as EdlibAlignResult[numQueries]
+ * (malloc'd arrays, caller frees each with edlibFreeAlignResult). */
+EDLIB_API int edlibAmdBatchResults(EdlibAmdBatch* batch, EdlibAlignResult* results);
+
+typedef struct {
+    double run_ms;          /* HIP-event time of the whole last Run on its stream           */
+    double scan_ms;         /* HIP-event time of the dominant scan kernel(s) in that Run     */
+    int scan_launches;      /* number of scan-kernel launches in that Run                    */
+    long long cells;        /* sum over units of queryLength * targetLength (GCUPS numerator)*/
+    long long word_steps;   /* 32-row word-column updates the scan kernels executed          */
+    long long algo_bytes;   /* algorithmic bytes: target+query+Peq+results    */
+    int path;               /* 1 = reads-per-lane kernel, 2 = block-per-lane kernel, 3 = both*/
+    int overflow_units;     /* units whose end-location list needed the exact second pass    */
+} EdlibAmdBatchStats;
+
+EDLIB_API int edlibAmdBatchStats(EdlibAmdBatch* batch, EdlibAmdBatchStats* out);
+EDLIB_API void edlibAmdBatchDestroy(EdlibAmdBatch* batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDLIB_AMD_H */
