@@ -320,35 +320,60 @@ int Batch::runReads(std::vector<UnitResult>& res)
         EDLIB_AMD_HIP(hipMemcpyAsync(&novf, g.d_flags.p + g.nslots, sizeof(int), hipMemcpyDeviceToHost, stream_));
         EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
 
-        // exact second pass for the (rare) slots with more end locations than the first pass keeps
+        // Exact second pass for the (rare) slots with more end locations than the first pass
+        // keeps.  Their best score b is already exact, so "score <= b" selects exactly the end
+        // locations: (a) a counting scan over fine segments gives the number of hits of every
+        // (slot, segment), (b) after a prefix sum the same scan writes them to their final place.
+        // Fine segments keep the pass parallel (a handful of slots still fills the chip).
         std::vector<int> ovfSlots; std::vector<long long> ovfOff; std::vector<int> ovfPos;
         if (novf > 0 && mode != EDLIB_MODE_NW) {
             std::vector<int> flags(ns);
             EDLIB_AMD_HIP(hipMemcpy(flags.data(), g.d_flags.p, ns * sizeof(int), hipMemcpyDeviceToHost));
-            long long acc = 0;
-            std::vector<int> caps;
             for (size_t s = 0; s < ns; ++s)
-                if (flags[s] && g.perm[s] >= 0) { ovfSlots.push_back((int)s); ovfOff.push_back(acc); caps.push_back(total[s]); acc += total[s]; }
-            ovfOff.push_back(acc);
+                if (flags[s] && g.perm[s] >= 0) ovfSlots.push_back((int)s);
             const size_t no = ovfSlots.size();
             if (no) {
+                int S2 = 1, segLen2 = roundup(T, 16), warm2 = 0;
+                if (mode == EDLIB_MODE_HW) {
+                    const long long nrblk2 = ((long long)no + 63) / 64;
+                    long long want = (16384 + nrblk2 - 1) / nrblk2;
+                    want = std::max(1LL, std::min<long long>(want, std::max(1, T / 4096)));
+                    segLen2 = roundup((int)((T + want - 1) / want), 16);
+                    S2 = (T + segLen2 - 1) / segLen2;
+                    warm2 = g.warm;
+                }
+                const size_t items = no * (size_t)S2;
                 DevBuf<int> d_map, d_caps, d_pool, d_sb, d_sc; DevBuf<long long> d_off;
-                EDLIB_AMD_HIP(d_map.alloc(no)); EDLIB_AMD_HIP(d_caps.alloc(no)); EDLIB_AMD_HIP(d_off.alloc(no));
-                EDLIB_AMD_HIP(d_pool.alloc((size_t)acc)); EDLIB_AMD_HIP(d_sb.alloc(no)); EDLIB_AMD_HIP(d_sc.alloc(no));
+                EDLIB_AMD_HIP(d_map.alloc(no)); EDLIB_AMD_HIP(d_sb.alloc(items)); EDLIB_AMD_HIP(d_sc.alloc(items));
                 EDLIB_AMD_HIP(hipMemcpy(d_map.p, ovfSlots.data(), no * sizeof(int), hipMemcpyHostToDevice));
-                EDLIB_AMD_HIP(hipMemcpy(d_caps.p, caps.data(), no * sizeof(int), hipMemcpyHostToDevice));
-                EDLIB_AMD_HIP(hipMemcpy(d_off.p, ovfOff.data(), no * sizeof(long long), hipMemcpyHostToDevice));
                 ReadScanArgs a{};
                 a.peq = g.d_peq.p; a.tpk = d_tpk_.p; a.targetLength = T;
                 a.qlen = g.d_qlen.p; a.kinit = g.d_best.p;          // threshold = the exact best
                 a.slotmap = d_map.p; a.nlanes = (int)no;
-                a.numSegments = 1; a.segLen = roundup(T, 16); a.warm = 0;
-                a.segBest = d_sb.p; a.segCnt = d_sc.p; a.segPos = d_pool.p; a.cap = 0;
-                a.posOff = d_off.p; a.posCap = d_caps.p;
+                a.numSegments = S2; a.segLen = segLen2; a.warm = warm2;
+                a.segBest = d_sb.p; a.segCnt = d_sc.p; a.segPos = d_sb.p /*unused*/; a.cap = 0;
+                a.posOff = nullptr; a.posCap = nullptr;
                 scanTimerStart();
-                EDLIB_AMD_HIP(launch_scan_reads(g.nwords, mode, a, stream_));
+                EDLIB_AMD_HIP(launch_scan_reads(g.nwords, mode, a, stream_));      // (a) count
                 scanTimerStop();
-                stats.word_steps += (long long)roundup((int)no, 64) * g.nwords * (long long)T;
+                std::vector<int> cnts(items);
+                EDLIB_AMD_HIP(hipMemcpyAsync(cnts.data(), d_sc.p, items * sizeof(int), hipMemcpyDeviceToHost, stream_));
+                EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+                std::vector<long long> offs(items);
+                long long acc = 0;
+                ovfOff.assign(no + 1, 0);
+                for (size_t i = 0; i < no; ++i) {
+                    for (int sg = 0; sg < S2; ++sg) { offs[i * S2 + sg] = acc; acc += cnts[i * S2 + sg]; }
+                    ovfOff[i + 1] = acc;
+                }
+                EDLIB_AMD_HIP(d_caps.alloc(items)); EDLIB_AMD_HIP(d_off.alloc(items)); EDLIB_AMD_HIP(d_pool.alloc((size_t)acc));
+                EDLIB_AMD_HIP(hipMemcpyAsync(d_caps.p, cnts.data(), items * sizeof(int), hipMemcpyHostToDevice, stream_));
+                EDLIB_AMD_HIP(hipMemcpyAsync(d_off.p, offs.data(), items * sizeof(long long), hipMemcpyHostToDevice, stream_));
+                a.segPos = d_pool.p; a.posOff = d_off.p; a.posCap = d_caps.p;
+                scanTimerStart();
+                EDLIB_AMD_HIP(launch_scan_reads(g.nwords, mode, a, stream_));      // (b) write
+                scanTimerStop();
+                stats.word_steps += 2LL * roundup((int)no, 64) * g.nwords * ((long long)T + (long long)(S2 - 1) * warm2);
                 ovfPos.resize((size_t)acc);
                 EDLIB_AMD_HIP(hipMemcpyAsync(ovfPos.data(), d_pool.p, (size_t)acc * sizeof(int), hipMemcpyDeviceToHost, stream_));
                 EDLIB_AMD_HIP(hipStreamSynchronize(stream_));

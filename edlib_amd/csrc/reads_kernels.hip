@@ -252,8 +252,9 @@ scan_reads_kernel(const ReadScanArgs a)
     int score = m;
     int best = a.kinit[slot];
     int cnt = 0;
-    int cap = a.posCap ? a.posCap[idx] : a.cap;
-    int* pos = a.segPos + (a.posOff ? a.posOff[idx] : ((long long)idx * a.numSegments + seg) * a.cap);
+    const long long item = (long long)idx * a.numSegments + seg;   // (lane, segment) record
+    int cap = a.posCap ? a.posCap[item] : a.cap;
+    int* pos = a.segPos + (a.posOff ? a.posOff[item] : item * a.cap);
     if (!live) cap = 0;
 
     const int T = a.targetLength;

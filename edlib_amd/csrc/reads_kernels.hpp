@@ -25,8 +25,8 @@ struct ReadScanArgs {
     int* segCnt;              // [lanes][numSegments] number of columns attaining it
     int* segPos;              // positions pool
     int cap;                  // positions kept per (lane, segment) when posOff == nullptr
-    const long long* posOff;  // optional [lanes] offset into segPos (exact pass)
-    const int* posCap;        // optional [lanes] capacity (exact pass)
+    const long long* posOff;  // optional [lanes][numSegments] offset into segPos (exact pass)
+    const int* posCap;        // optional [lanes][numSegments] capacity (exact pass)
 };
 
 // mode: 0 NW, 1 SHW, 2 HW (values of EdlibAlignMode).  Returns hipSuccess or the launch error.

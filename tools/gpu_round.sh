@@ -1,0 +1,16 @@
+#!/bin/bash
+# one GPU visit: tests, smoke, bench, kernel-trace profile
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/pytest_gpu.log; cat gpurun_out/pytest_gpu.log
+python __graft_entry__.py smoke 2>&1 | tail -3 | tee gpurun_out/smoke.log
+python bench.py ${BENCH_ARGS:-} 2> gpurun_out/bench.err | tee gpurun_out/bench.json
+tail -5 gpurun_out/bench.err
+if [ -n "$PROFILE" ]; then
+  rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
+  ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o r01 -- python $OLDPWD/bench.py --reads 262144 --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/gpurun_out/prof_bench.json 2> $OLDPWD/gpurun_out/prof.err )
+  tail -3 gpurun_out/prof.err; cat gpurun_out/prof_bench.json
+  find gpurun_out/prof -name "*stats*" | head; 
+  for f in $(find gpurun_out/prof -name "*kernel_stats.csv"); do head -12 $f; done
+fi
