@@ -130,13 +130,10 @@ def main():
         launches += st["scan_launches"]
     sync()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    cells_per_rank = st["cells"]
-    value = world * cells_per_rank * args.steps / dt / 1e9
+    from edlib_amd.parallel import aggregate_throughput
+    # whole-job cells (SUM over ranks) and the slowest rank's time (MAX over ranks)
+    cells_all, dt = aggregate_throughput(st["cells"] * args.steps, dt, dist, "cuda" if dist is not None else None)
+    value = cells_all / dt / 1e9
     out = None
     if rank == 0:
         # dominant kernel: the first scan launch of a step covers the whole batch

@@ -1,0 +1,48 @@
+"""Multi-GPU sharding of a batch: the units of a batch are independent,
+so each rank (one process per GPU) owns a contiguous slice, the shared target is
+replicated, and there is NO collective on the data path.  The only communication is
+bookkeeping: a barrier around the timed region, MAX over ranks of the elapsed time,
+SUM of the work, and (optionally) a gather of per-unit results to rank 0.  The
+backend is whatever torch.distributed was initialised with: "nccl" (= RCCL over xGMI)
+on the GPU box, "gloo" in the CPU tests.
+"""
+import numpy as np
+
+
+def shard_range(n_units, rank, world):
+    """Contiguous slice [lo, hi) of rank `rank`: ceil(n/world) units each, last ranks may get fewer."""
+    per = (n_units + world - 1) // world
+    lo = min(n_units, rank * per)
+    return lo, min(n_units, lo + per)
+
+
+def aggregate_throughput(cells_local, seconds_local, dist=None, device=None):
+    """(sum of cells over ranks, max of seconds over ranks)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return int(cells_local), float(seconds_local)
+    import torch
+    t = torch.tensor([float(seconds_local)], dtype=torch.float64, device=device)
+    c = torch.tensor([float(cells_local)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    return int(c.item()), float(t.item())
+
+
+def gather_int_results(local, n_units, dist=None, device=None):
+    """Concatenate per-rank int32 result arrays (in shard order) on every rank."""
+    local = np.asarray(local, dtype=np.int32)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    import torch
+    world = dist.get_world_size()
+    per = (n_units + world - 1) // world
+    buf = torch.full((per,), -2, dtype=torch.int32, device=device)
+    buf[:len(local)] = torch.from_numpy(local).to(buf.device)
+    outs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    full = torch.cat(outs).cpu().numpy()
+    keep = []
+    for r in range(world):
+        lo, hi = shard_range(n_units, r, world)
+        keep.append(full[r * per: r * per + (hi - lo)])
+    return np.concatenate(keep)
