@@ -4,7 +4,10 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
 CSRC    := edlib_amd/csrc
 OBJDIR  := build/obj
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -Wall -Wno-unused-function
+# -disable-promote-alloca-to-vector: keep the per-lane word arrays (Pv[], Mv[], Peq rows) as separate
+# VGPRs; as <N x i32> tuples every partial update (banded kernel) costs a whole-tuple copy.
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -Wall -Wno-unused-function \
+            -mllvm -disable-promote-alloca-to-vector
 
 SRCS := $(CSRC)/reads_kernels.hip $(CSRC)/pair_kernels.hip $(CSRC)/engine.hip $(CSRC)/api.hip
 OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))

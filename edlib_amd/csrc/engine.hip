@@ -221,7 +221,16 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
         EDLIB_AMD_HIP(g->d_pos.alloc(ns * 16)); EDLIB_AMD_HIP(g->d_flags.alloc(ns + 1));
         groups_.push_back(std::move(g));
     }
-    if (!groups_.empty()) EDLIB_AMD_HIP(d_tpk_.alloc((size_t)(T + 15) / 16 + 4));
+    if (!groups_.empty()) {
+        EDLIB_AMD_HIP(d_tpk_.alloc((size_t)(T + 15) / 16 + 4));
+        EDLIB_AMD_HIP(hipMemset(d_tpk_.p, 0, d_tpk_.bytes()));       // the banded kernel reads whole dwords
+        EDLIB_AMD_HIP(d_trash_.alloc(64));
+        EDLIB_AMD_HIP(d_wordSteps_.alloc(1));
+    }
+    {
+        const char* env = getenv("EDLIB_AMD_BAND");
+        banded_ = (mode == EDLIB_MODE_HW) && !(env && env[0] == '0');
+    }
     return 0;
 }
 
@@ -274,33 +283,94 @@ static void finalize_global(UnitResult& r, int kcfg, int mode, int T, int score)
 
 // ------------------------------------------------------- reads-per-lane path
 
+// One scan launch over a group's slots (or a subset through d_slotmap), banded or not.
+int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, int kcap, const int* d_kinit,
+                     int numSegments, int segLen, int warm, int* segBest, int* segCnt, int* segPos, int cap,
+                     const long long* posOff, const int* posCap)
+{
+    ReadScanArgs a{};
+    a.peq = g.d_peq.p; a.tpk = d_tpk_.p; a.targetLength = tlen(0);
+    a.qlen = g.d_qlen.p; a.kinit = d_kinit; a.slotmap = d_slotmap; a.nlanes = nlanes;
+    a.numSegments = numSegments; a.segLen = segLen; a.warm = warm;
+    a.segBest = segBest; a.segCnt = segCnt; a.segPos = segPos; a.cap = cap;
+    a.posOff = posOff; a.posCap = posCap;
+    a.kcap = kcap; a.trash = d_trash_.p; a.wordSteps = d_wordSteps_.p;
+    scanTimerStart();
+    if (banded_ && mode == EDLIB_MODE_HW) EDLIB_AMD_HIP(launch_scan_reads_banded(g.nwords, a, stream_));
+    else {
+        EDLIB_AMD_HIP(launch_scan_reads(g.nwords, mode, a, stream_));
+        stats.word_steps += (long long)((nlanes + 63) / 64 * 64) * g.nwords *
+                            ((long long)a.targetLength + (long long)(numSegments - 1) * warm);
+    }
+    scanTimerStop();
+    return 0;
+}
+
+// segmentation of a launch over `nlanes` lanes: enough waves to fill the chip, segments >= 4096 columns
+static void plan_segments(int nlanes, int T, int mode, int warmFull, long long wantWaves,
+                          int& S, int& segLen, int& warm)
+{
+    S = 1; segLen = roundup(T, 16); warm = 0;
+    if (mode != EDLIB_MODE_HW) return;
+    const long long nrblk = ((long long)nlanes + 63) / 64;
+    long long want = (wantWaves + nrblk - 1) / nrblk;
+    want = std::max(1LL, std::min<long long>(want, std::max(1, T / 4096)));
+    segLen = roundup((int)((T + want - 1) / want), 16);
+    S = (T + segLen - 1) / segLen;
+    warm = warmFull;
+}
+
 int Batch::runReads(std::vector<UnitResult>& res)
 {
     if (groups_.empty()) return 0;
     const int T = tlen(0);
     // unknown mode values are computed as NW (edlib.cpp:205-215)
     const int mode = (cfg_.mode == EDLIB_MODE_HW || cfg_.mode == EDLIB_MODE_SHW) ? (int)cfg_.mode : (int)EDLIB_MODE_NW;
+    const bool banded = banded_ && mode == EDLIB_MODE_HW;
+    const int kFirst = 8;                   // first threshold of the k-doubling (edlib.cpp:197-217 starts at 64)
+    const int kNoCap = 0x3fffffff;
     stats.path |= 1;
+    EDLIB_AMD_HIP(hipMemsetAsync(d_wordSteps_.p, 0, sizeof(unsigned long long), stream_));
     EDLIB_AMD_HIP(launch_pack_target_2bit(d_tpool_.p, d_tlut_.p, T, d_tpk_.p, stream_));
     for (auto& gp : groups_) {
         ReadGroup& g = *gp;
         EDLIB_AMD_HIP(launch_build_peq_reads(g.nwords, d_qpool_.p, d_qoff_.p, g.d_perm.p, g.nslots,
                                              d_eqtbl4_.p, d_presence_.p, cfg_.k, g.d_peq.p, g.d_qlen.p,
                                              g.d_kinit.p, g.d_alphaExtra.p, stream_));
-        ReadScanArgs a{};
-        a.peq = g.d_peq.p; a.tpk = d_tpk_.p; a.targetLength = T;
-        a.qlen = g.d_qlen.p; a.kinit = g.d_kinit.p; a.slotmap = nullptr; a.nlanes = g.nslots;
-        a.numSegments = g.numSegments; a.segLen = g.segLen; a.warm = g.warm;
-        a.segBest = g.d_segBest.p; a.segCnt = g.d_segCnt.p; a.segPos = g.d_segPos.p; a.cap = 8;
-        a.posOff = nullptr; a.posCap = nullptr;
-        scanTimerStart();
-        EDLIB_AMD_HIP(launch_scan_reads(g.nwords, mode, a, stream_));
-        scanTimerStop();
-        stats.word_steps += (long long)g.nslots * g.nwords *
-                            ((long long)T + (long long)(g.numSegments - 1) * g.warm);
+        // ---- pass 1: all slots; banded: threshold min(k, kFirst)
+        const bool twoPass = banded && (cfg_.k < 0 || cfg_.k > kFirst) && 32 * g.nwords > kFirst;
+        if (scanGroup(g, mode, nullptr, g.nslots, twoPass ? kFirst : kNoCap, g.d_kinit.p, g.numSegments, g.segLen,
+                      g.warm, g.d_segBest.p, g.d_segCnt.p, g.d_segPos.p, 8, nullptr, nullptr)) return 1;
         EDLIB_AMD_HIP(launch_merge_segments(g.d_segBest.p, g.d_segCnt.p, g.d_segPos.p, g.numSegments, 8,
-                                            g.nslots, 16, g.d_best.p, g.d_total.p, g.d_pos.p,
+                                            g.nslots, nullptr, 16, g.d_best.p, g.d_total.p, g.d_pos.p,
                                             g.d_flags.p, stream_));
+        // ---- pass 2 (k-doubling): slots with nothing <= kFirst are rescanned with their full threshold
+        if (twoPass) {
+            std::vector<int> total(g.nslots);
+            EDLIB_AMD_HIP(hipMemcpyAsync(total.data(), g.d_total.p, (size_t)g.nslots * sizeof(int), hipMemcpyDeviceToHost, stream_));
+            EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+            std::vector<int> todo;
+            for (int s = 0; s < g.nslots; ++s) {
+                const int u = g.perm[s];
+                if (u < 0 || total[s] > 0) continue;
+                if (qlen(u) > kFirst) todo.push_back(s);       // its threshold min(k, m) is above kFirst
+            }
+            if (!todo.empty()) {
+                const size_t no = todo.size();
+                int S2, segLen2, warm2;
+                plan_segments((int)no, T, mode, g.warm, 65536, S2, segLen2, warm2);
+                const size_t items = no * (size_t)S2;
+                DevBuf<int> d_map, d_sb, d_sc, d_sp;
+                EDLIB_AMD_HIP(d_map.alloc(no)); EDLIB_AMD_HIP(d_sb.alloc(items)); EDLIB_AMD_HIP(d_sc.alloc(items));
+                EDLIB_AMD_HIP(d_sp.alloc(items * 8));
+                EDLIB_AMD_HIP(hipMemcpyAsync(d_map.p, todo.data(), no * sizeof(int), hipMemcpyHostToDevice, stream_));
+                if (scanGroup(g, mode, d_map.p, (int)no, kNoCap, g.d_kinit.p, S2, segLen2, warm2,
+                              d_sb.p, d_sc.p, d_sp.p, 8, nullptr, nullptr)) return 1;
+                EDLIB_AMD_HIP(launch_merge_segments(d_sb.p, d_sc.p, d_sp.p, S2, 8, (int)no, d_map.p, 16,
+                                                    g.d_best.p, g.d_total.p, g.d_pos.p, g.d_flags.p, stream_));
+                EDLIB_AMD_HIP(hipStreamSynchronize(stream_));            // temporaries die here
+            }
+        }
         // census of slots whose end-location list did not fit
         int* counter = g.d_flags.p + g.nslots;
         EDLIB_AMD_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream_));
@@ -333,29 +403,15 @@ int Batch::runReads(std::vector<UnitResult>& res)
                 if (flags[s] && g.perm[s] >= 0) ovfSlots.push_back((int)s);
             const size_t no = ovfSlots.size();
             if (no) {
-                int S2 = 1, segLen2 = roundup(T, 16), warm2 = 0;
-                if (mode == EDLIB_MODE_HW) {
-                    const long long nrblk2 = ((long long)no + 63) / 64;
-                    long long want = (16384 + nrblk2 - 1) / nrblk2;
-                    want = std::max(1LL, std::min<long long>(want, std::max(1, T / 4096)));
-                    segLen2 = roundup((int)((T + want - 1) / want), 16);
-                    S2 = (T + segLen2 - 1) / segLen2;
-                    warm2 = g.warm;
-                }
+                int S2, segLen2, warm2;
+                plan_segments((int)no, T, mode, g.warm, 16384, S2, segLen2, warm2);
                 const size_t items = no * (size_t)S2;
                 DevBuf<int> d_map, d_caps, d_pool, d_sb, d_sc; DevBuf<long long> d_off;
                 EDLIB_AMD_HIP(d_map.alloc(no)); EDLIB_AMD_HIP(d_sb.alloc(items)); EDLIB_AMD_HIP(d_sc.alloc(items));
                 EDLIB_AMD_HIP(hipMemcpy(d_map.p, ovfSlots.data(), no * sizeof(int), hipMemcpyHostToDevice));
-                ReadScanArgs a{};
-                a.peq = g.d_peq.p; a.tpk = d_tpk_.p; a.targetLength = T;
-                a.qlen = g.d_qlen.p; a.kinit = g.d_best.p;          // threshold = the exact best
-                a.slotmap = d_map.p; a.nlanes = (int)no;
-                a.numSegments = S2; a.segLen = segLen2; a.warm = warm2;
-                a.segBest = d_sb.p; a.segCnt = d_sc.p; a.segPos = d_sb.p /*unused*/; a.cap = 0;
-                a.posOff = nullptr; a.posCap = nullptr;
-                scanTimerStart();
-                EDLIB_AMD_HIP(launch_scan_reads(g.nwords, mode, a, stream_));      // (a) count
-                scanTimerStop();
+                // (a) count; threshold = the exact best (d_best), so the band is as narrow as it gets
+                if (scanGroup(g, mode, d_map.p, (int)no, kNoCap, g.d_best.p, S2, segLen2, warm2,
+                              d_sb.p, d_sc.p, d_sb.p /*unused*/, 0, nullptr, nullptr)) return 1;
                 std::vector<int> cnts(items);
                 EDLIB_AMD_HIP(hipMemcpyAsync(cnts.data(), d_sc.p, items * sizeof(int), hipMemcpyDeviceToHost, stream_));
                 EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
@@ -369,11 +425,9 @@ int Batch::runReads(std::vector<UnitResult>& res)
                 EDLIB_AMD_HIP(d_caps.alloc(items)); EDLIB_AMD_HIP(d_off.alloc(items)); EDLIB_AMD_HIP(d_pool.alloc((size_t)acc));
                 EDLIB_AMD_HIP(hipMemcpyAsync(d_caps.p, cnts.data(), items * sizeof(int), hipMemcpyHostToDevice, stream_));
                 EDLIB_AMD_HIP(hipMemcpyAsync(d_off.p, offs.data(), items * sizeof(long long), hipMemcpyHostToDevice, stream_));
-                a.segPos = d_pool.p; a.posOff = d_off.p; a.posCap = d_caps.p;
-                scanTimerStart();
-                EDLIB_AMD_HIP(launch_scan_reads(g.nwords, mode, a, stream_));      // (b) write
-                scanTimerStop();
-                stats.word_steps += 2LL * roundup((int)no, 64) * g.nwords * ((long long)T + (long long)(S2 - 1) * warm2);
+                // (b) write
+                if (scanGroup(g, mode, d_map.p, (int)no, kNoCap, g.d_best.p, S2, segLen2, warm2,
+                              d_sb.p, d_sc.p, d_pool.p, 0, d_off.p, d_caps.p)) return 1;
                 ovfPos.resize((size_t)acc);
                 EDLIB_AMD_HIP(hipMemcpyAsync(ovfPos.data(), d_pool.p, (size_t)acc * sizeof(int), hipMemcpyDeviceToHost, stream_));
                 EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
@@ -398,6 +452,11 @@ int Batch::runReads(std::vector<UnitResult>& res)
                 finalize_global(r, cfg_.k, (int)cfg_.mode, T, best[s]);
             }
         }
+    }
+    if (banded) {
+        unsigned long long ws = 0;
+        EDLIB_AMD_HIP(hipMemcpy(&ws, d_wordSteps_.p, sizeof ws, hipMemcpyDeviceToHost));
+        stats.word_steps += (long long)ws;
     }
     return 0;
 }

@@ -91,7 +91,13 @@ private:
     };
     std::vector<std::unique_ptr<ReadGroup>> groups_;
     DevBuf<uint32_t> d_tpk_;
+    DevBuf<int> d_trash_;
+    DevBuf<unsigned long long> d_wordSteps_;
+    bool banded_ = false;        // HW groups use the Ukkonen-banded kernel with k-doubling
     int runReads(std::vector<UnitResult>& res);
+    int scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, int kcap, const int* d_kinit,
+                  int numSegments, int segLen, int warm, int* segBest, int* segCnt, int* segPos, int cap,
+                  const long long* posOff, const int* posCap);
 
     // ---- block-per-lane path
     DevBuf<PairDesc> d_descs_;

@@ -326,6 +326,217 @@ hipError_t launch_scan_reads(int nwords, int mode, const ReadScanArgs& a, hipStr
     return hipErrorInvalidValue;
 }
 
+// ------------------------------------------------- the banded HW scan (k-doubling)
+
+// Ukkonen band + k-doubling of the reference (edlib.cpp:197-217, 562, 602-630) re-expressed per WAVE:
+//   * the wave computes only the first `nw` words of the column (nw is wave-uniform, 1..NWD); rows
+//     below are known to exceed every lane's threshold k = best-so-far (<= min(kinit, kcap));
+//   * nw is re-evaluated once per packed target dword (16 columns) from the exact score S of the
+//     last active word's bottom row (popcounts of Pv/Mv: with HW's zero row -1, D[r] = sum of the
+//     vertical deltas above r).  A cell changes by at most 1 per column, so
+//        S >  k+16        -> no row below becomes <= k within the next 16 columns (no growth needed)
+//        S <= k+16 (any lane) -> take one more word, entering as "+1 per row" like the reference's
+//                               new block (edlib.cpp:605-608: P = ~0, M = 0)
+//        all lanes: every cell of the last word and the 16 rows above it exceed k -> drop the word
+//                               (edlib.cpp:610-612; bound from both neighbouring word scores)
+//   * the bottom query row (bit (m-1)%32 of the last word) is only in the band while nw == NWD, so
+//     its score is only followed then; e = score - best - 1 is tracked instead of score, its sign bit is
+//     OR-ed into `flag`, and once per 4 columns a WAVE-UNIFORM test (ballot) enters the rare path,
+//     which is branch-free per lane (selects + a store that non-hit lanes aim at a trash word).
+//     The loop therefore contains only wave-uniform branches.
+// Op selection follows tools/valu_ubench.hip: x+x instead of v_lshlrev (half rate on gfx950),
+// v_lshrrev + v_and instead of v_bfe, no SGPR operands in the hot VALU ops.
+template <int NA, int NWD>
+__device__ __forceinline__ void column_step_hw(const u32 (&Eq)[NWD], u32 (&Pv)[NWD], u32 (&Mv)[NWD],
+                                               int& e, int& flag, const u32 sh)
+{
+    u32 Ph[NA], Mh[NA];
+    u32 carry = 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const u32 t = Eq[i] & Pv[i];
+        u32 cout;
+        const u32 s = __builtin_addc(t, Pv[i], carry, &cout);
+        carry = cout;
+        const u32 Xh = (s ^ Pv[i]) | Eq[i];
+        Ph[i] = Mv[i] | ~(Xh | Pv[i]);
+        Mh[i] = Pv[i] & Xh;
+    }
+    if (NA == NWD) {                                   // bottom row is in the band: follow its score
+        e += (int)((Ph[NA - 1] >> sh) & 1u);
+        e -= (int)((Mh[NA - 1] >> sh) & 1u);
+        flag |= e;
+    }
+#pragma unroll
+    for (int i = NA - 1; i >= 0; --i) {
+        u32 ph, mh;
+        if (i > 0) {
+            ph = __builtin_amdgcn_alignbit(Ph[i], Ph[i - 1], 31);
+            mh = __builtin_amdgcn_alignbit(Mh[i], Mh[i - 1], 31);
+        } else {                                        // << 1 with a zero shifted in (HW row -1)
+            asm("v_add_u32 %0, %1, %1" : "=v"(ph) : "v"(Ph[0]));
+            asm("v_add_u32 %0, %1, %1" : "=v"(mh) : "v"(Mh[0]));
+        }
+        const u32 Xv = Eq[i] | Mv[i];
+        Pv[i] = mh | ~(Xv | ph);
+        Mv[i] = ph & Xv;
+    }
+}
+
+#define EDLIB_AMD_DISPATCH_HW(sym)                                                              \
+    switch (sym) {                                                                              \
+        case 0:  column_step_hw<NA, NWD>(E0, Pv, Mv, e, flag, sh); asm volatile("; sym0"); break;  \
+        case 1:  column_step_hw<NA, NWD>(E1, Pv, Mv, e, flag, sh); asm volatile("; sym1"); break;  \
+        case 2:  column_step_hw<NA, NWD>(E2, Pv, Mv, e, flag, sh); asm volatile("; sym2"); break;  \
+        default: column_step_hw<NA, NWD>(E3, Pv, Mv, e, flag, sh); asm volatile("; sym3"); break;  \
+    }
+
+struct HwTrack {            // per-lane tracking state of the banded kernel
+    int best, cnt, cap;
+    int* pos;
+    int* trash;
+};
+
+// 16 columns (one packed dword) with NA active words, then the band checkpoint.  Returns the new nw.
+template <int NA, int NWD>
+__device__ __forceinline__ int band_dword(const u32 tw, const int colBase, const int colEnd, const bool track,
+                                          const u32 (&E0)[NWD], const u32 (&E1)[NWD], const u32 (&E2)[NWD],
+                                          const u32 (&E3)[NWD], u32 (&Pv)[NWD], u32 (&Mv)[NWD],
+                                          int& e, int& flag, HwTrack& tr, const u32 sh, const int lastRows)
+{
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+        int eh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32 sym = (tw >> (2 * (blk * 4 + j))) & 3u;
+            EDLIB_AMD_DISPATCH_HW(sym)
+            eh[j] = e;
+        }
+        if (NA == NWD) {
+            if (track && __builtin_amdgcn_ballot_w64(flag < 0) != 0ull) {   // wave-uniform
+                const int bestIn = tr.best;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = colBase + blk * 4 + j;
+                    const int sc = eh[j] + bestIn + 1;
+                    const bool hit = (sc <= tr.best) && (col < colEnd);     // edlib.cpp:658-673
+                    const bool better = hit && (sc < tr.best);
+                    tr.cnt = better ? 0 : tr.cnt;
+                    tr.best = better ? sc : tr.best;
+                    int* p = (hit && tr.cnt < tr.cap) ? (tr.pos + tr.cnt) : tr.trash;
+                    *p = col;
+                    tr.cnt += hit ? 1 : 0;
+                }
+                e = eh[3] + bestIn - tr.best;                               // rebase e on the new best
+                flag = 0;
+            }
+        }
+    }
+    // ---- band checkpoint: scores of the bottom rows of the last two active words (computed values:
+    // exact when <= k, otherwise upper bounds that still exceed k, which is all the rules below use)
+    int Sprev = 0;
+#pragma unroll
+    for (int i = 0; i + 1 < NA; ++i) Sprev += __popc(Pv[i]) - __popc(Mv[i]);
+    const int S = Sprev + __popc(Pv[NA - 1]) - __popc(Mv[NA - 1]);
+    if (NA < NWD) {
+        // grow unless the bottom 16 rows of the band all exceed k (adjacent rows differ by <= 1, so
+        // S > k+15 is sufficient); cells <= k descend at most one row per column, hence nothing below
+        // the band can reach k before the next checkpoint
+        if (__builtin_amdgcn_ballot_w64(S <= tr.best + 16) != 0ull) {
+            Pv[NA] = ~0u; Mv[NA] = 0u;                                      // "+1 per row", edlib.cpp:605-608
+            if (NA + 1 == NWD) { e = S + lastRows - tr.best - 1; flag = 0; } // row m-1 is lastRows rows below
+            return NA + 1;
+        }
+    }
+    if (NA > 1) {
+        // drop the last word when (a) every cell of it exceeds k: a cell j rows below Sprev's row is
+        // >= max(Sprev - j, S - (32 - j)) >= (Sprev + S - 32) / 2, and (b) the new bottom 16 rows do too
+        const bool keep = (Sprev <= tr.best + 16) || (Sprev + S <= 2 * tr.best + 34);
+        if (__builtin_amdgcn_ballot_w64(keep) == 0ull) return NA - 1;
+    }
+    return NA;
+}
+
+template <int NWD>
+__global__ void __launch_bounds__(256)
+scan_reads_banded_kernel(const ReadScanArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int rblk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int seg = blockIdx.y;
+    const int idx = rblk * 64 + lane;
+    if (rblk * 64 >= a.nlanes) return;
+    const bool live = idx < a.nlanes;
+    const int slot = live ? (a.slotmap ? a.slotmap[idx] : idx) : 0;
+
+    u32 E0[NWD], E1[NWD], E2[NWD], E3[NWD], Pv[NWD], Mv[NWD];
+    const int m = a.qlen[slot];
+    const u32 sh = (u32)(m - 1) & 31u;                                // row m-1 inside the last word
+    const int lastRows = m - 32 * (NWD - 1);                          // query rows in the last word
+    {
+        const size_t pb = (size_t)(slot >> 6) * 4 * NWD * 64 + (slot & 63);
+#pragma unroll
+        for (int d = 0; d < NWD; ++d) {
+            E0[d] = a.peq[pb + (size_t)(0 * NWD + d) * 64];
+            E1[d] = a.peq[pb + (size_t)(1 * NWD + d) * 64];
+            E2[d] = a.peq[pb + (size_t)(2 * NWD + d) * 64];
+            E3[d] = a.peq[pb + (size_t)(3 * NWD + d) * 64];
+            Pv[d] = ~0u;                                             // column -1: D[i][-1] = i+1
+            Mv[d] = 0u;
+        }
+    }
+    const long long item = (long long)idx * a.numSegments + seg;
+    HwTrack tr;
+    {
+        const int k0 = a.kinit[slot];
+        tr.best = k0 < a.kcap ? k0 : a.kcap;
+    }
+    tr.cnt = 0;
+    tr.cap = live ? (a.posCap ? a.posCap[item] : a.cap) : 0;
+    tr.pos = a.segPos + (a.posOff ? a.posOff[item] : item * a.cap);
+    tr.trash = a.trash;
+    int e = m - tr.best - 1;                                          // score at column -1 is m
+    int flag = 0;
+
+    const int T = a.targetLength;
+    const int c0 = seg * a.segLen;
+    int c1 = c0 + a.segLen; if (c1 > T) c1 = T;
+    int cw = c0 - a.warm; if (cw < 0) cw = 0;
+    const int w0 = cw >> 4, wmain = c0 >> 4, wend = (c1 + 15) >> 4;
+    int nw = NWD;
+    unsigned int bandWork = 0;                                        // sum of nw over the dwords (wave-uniform)
+    for (int w = w0; w < wend; ++w) {
+        const u32 tw = a.tpk[w];
+        const bool track = w >= wmain;                                // warm-up columns record nothing
+        bandWork += (unsigned int)nw;
+        switch (nw) {
+#define CASE(NA) case NA: if (NA <= NWD) nw = band_dword<(NA <= NWD ? NA : NWD), NWD>(tw, w * 16, c1, track, E0, E1, E2, E3, Pv, Mv, e, flag, tr, sh, lastRows); break;
+            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+        }
+    }
+    if (live) {
+        a.segBest[item] = tr.best;
+        a.segCnt[item] = tr.cnt;
+    }
+    if (a.wordSteps && lane == 0) atomicAdd(a.wordSteps, (unsigned long long)bandWork * 16ull * 64ull);
+}
+
+hipError_t launch_scan_reads_banded(int nwords, const ReadScanArgs& a, hipStream_t stream)
+{
+    if (a.nlanes == 0) return hipSuccess;
+    const int nrblk = (a.nlanes + 63) / 64;
+    dim3 grid((nrblk + 3) / 4, a.numSegments), block(256);
+    switch (nwords) {
+#define CASE(N) case N: hipLaunchKernelGGL((scan_reads_banded_kernel<N>), grid, block, 0, stream, a); break;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- the merge
 
 // Joins the per-segment records of a slot: global best, number of columns
@@ -335,13 +546,15 @@ hipError_t launch_scan_reads(int nwords, int mode, const ReadScanArgs& a, hipStr
 // the exact second pass for that slot.
 __global__ void __launch_bounds__(256)
 merge_segments_kernel(const int* __restrict__ segBest, const int* __restrict__ segCnt,
-                      const int* __restrict__ segPos, int S, int cap, int nslots, int capFinal,
+                      const int* __restrict__ segPos, int S, int cap, int nlanes,
+                      const int* __restrict__ slotmap, int capFinal,
                       int* __restrict__ best, int* __restrict__ total, int* __restrict__ pos,
                       int* __restrict__ flags)
 {
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= nslots) return;
-    const size_t base = (size_t)slot * S;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // lane index of the scan launch
+    if (idx >= nlanes) return;
+    const int slot = slotmap ? slotmap[idx] : idx;
+    const size_t base = (size_t)idx * S;
     int b = 0x7fffffff;
     for (int s = 0; s < S; ++s)
         if (segCnt[base + s] > 0 && segBest[base + s] < b) b = segBest[base + s];
@@ -364,12 +577,12 @@ merge_segments_kernel(const int* __restrict__ segBest, const int* __restrict__ s
 }
 
 hipError_t launch_merge_segments(const int* segBest, const int* segCnt, const int* segPos, int S,
-                                 int cap, int nslots, int capFinal, int* best, int* total, int* pos,
-                                 int* flags, hipStream_t stream)
+                                 int cap, int nlanes, const int* slotmap, int capFinal, int* best,
+                                 int* total, int* pos, int* flags, hipStream_t stream)
 {
-    if (nslots == 0) return hipSuccess;
-    hipLaunchKernelGGL(merge_segments_kernel, dim3((nslots + 255) / 256), dim3(256), 0, stream,
-                       segBest, segCnt, segPos, S, cap, nslots, capFinal, best, total, pos, flags);
+    if (nlanes == 0) return hipSuccess;
+    hipLaunchKernelGGL(merge_segments_kernel, dim3((nlanes + 255) / 256), dim3(256), 0, stream,
+                       segBest, segCnt, segPos, S, cap, nlanes, slotmap, capFinal, best, total, pos, flags);
     return hipGetLastError();
 }
 

@@ -27,10 +27,16 @@ struct ReadScanArgs {
     int cap;                  // positions kept per (lane, segment) when posOff == nullptr
     const long long* posOff;  // optional [lanes][numSegments] offset into segPos (exact pass)
     const int* posCap;        // optional [lanes][numSegments] capacity (exact pass)
+    int kcap;                 // banded HW kernel: effective threshold = min(kinit[slot], kcap)
+    int* trash;               // banded HW kernel: one int that absorbs the stores of non-hit lanes
+    unsigned long long* wordSteps;   // banded HW kernel: += 32-row word-columns actually computed (may be null)
 };
 
 // mode: 0 NW, 1 SHW, 2 HW (values of EdlibAlignMode).  Returns hipSuccess or the launch error.
 hipError_t launch_scan_reads(int nwords, int mode, const ReadScanArgs& a, hipStream_t stream);
+
+// HW only: Ukkonen-banded variant with k-doubling (see reads_kernels.hip); same Peq layout.
+hipError_t launch_scan_reads_banded(int nwords, const ReadScanArgs& a, hipStream_t stream);
 
 hipError_t launch_pack_target_2bit(const uint8_t* raw, const uint8_t* lut, int targetLength,
                                    uint32_t* tpk, hipStream_t stream);
@@ -44,7 +50,7 @@ hipError_t launch_build_peq_reads(int nwords, const uint8_t* reads, const long l
                                   hipStream_t stream);
 
 hipError_t launch_merge_segments(const int* segBest, const int* segCnt, const int* segPos,
-                                 int numSegments, int cap, int nslots, int capFinal,
+                                 int numSegments, int cap, int nlanes, const int* slotmap, int capFinal,
                                  int* best, int* total, int* pos, int* flags, hipStream_t stream);
 
 }  // namespace edlib_amd
