@@ -36,7 +36,7 @@ TARGET_LEN = 5_000_000
 READ_LEN = 150
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz (MI355X_MICROARCH.md)
-VALU_OPS_PER_WORD_STEP = 10.8  # (50 DP + 3 score + 1 compare) / 5 words, counted from gfx950 ISA
+VALU_OPS_PER_WORD_STEP = 10.0  # DP ops per 32-row word-column (7 logic + add + 2 shift), counted from gfx950 ISA
 
 
 def cpu_baseline(reads, target, gpu_results, seconds_budget=20.0):
@@ -160,7 +160,7 @@ def main():
                                    % (args.reads, READ_LEN, TARGET_LEN),
                        "reads_per_gpu": args.reads, "read_len": READ_LEN, "target_len": TARGET_LEN,
                        "parallelism": "reads sharded over %d GPU(s), target replicated, no collective" % world},
-            "roofline": {"bound": "hbm", "kernel": "scan_reads_kernel<5,HW>",
+            "roofline": {"bound": "hbm", "kernel": "scan_reads_banded_kernel<5>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_step": algo_bytes,

@@ -320,7 +320,7 @@ static void plan_segments(int nlanes, int T, int mode, int warmFull, long long w
     warm = warmFull;
 }
 
-int Batch::runReads(std::vector<UnitResult>& res)
+int Batch::runReads()
 {
     if (groups_.empty()) return 0;
     const int T = tlen(0);
@@ -377,63 +377,78 @@ int Batch::runReads(std::vector<UnitResult>& res)
         hipLaunchKernelGGL(count_flags_kernel, dim3((g.nslots + 255) / 256), dim3(256), 0, stream_,
                            g.d_flags.p, g.nslots, counter);
     }
-    // collect
+    // exact second pass for the (rare) slots with more end locations than the first pass keeps.
+    // Their best score b is already exact, so "score <= b" selects exactly the end locations:
+    // (a) a counting scan over fine segments gives the number of hits of every (slot, segment),
+    // (b) after a prefix sum the same scan writes them to their final place.  Fine segments keep
+    // the pass parallel (a handful of slots still fills the chip).
     for (auto& gp : groups_) {
         ReadGroup& g = *gp;
         const size_t ns = (size_t)g.nslots;
-        std::vector<int> best(ns), total(ns), extra(ns), pos(ns * 16);
+        g.ovfSlots.clear(); g.ovfOff.assign(1, 0);
         int novf = 0;
+        EDLIB_AMD_HIP(hipMemcpyAsync(&novf, g.d_flags.p + g.nslots, sizeof(int), hipMemcpyDeviceToHost, stream_));
+        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+        if (novf <= 0 || mode == EDLIB_MODE_NW) continue;
+        std::vector<int> flags(ns), total(ns);
+        EDLIB_AMD_HIP(hipMemcpyAsync(flags.data(), g.d_flags.p, ns * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+        for (size_t s = 0; s < ns; ++s)
+            if (flags[s] && g.perm[s] >= 0) g.ovfSlots.push_back((int)s);
+        const size_t no = g.ovfSlots.size();
+        if (!no) continue;
+        int S2, segLen2, warm2;
+        plan_segments((int)no, T, mode, g.warm, 16384, S2, segLen2, warm2);
+        const size_t items = no * (size_t)S2;
+        DevBuf<int> d_map, d_caps, d_sb, d_sc; DevBuf<long long> d_off;
+        EDLIB_AMD_HIP(d_map.alloc(no)); EDLIB_AMD_HIP(d_sb.alloc(items)); EDLIB_AMD_HIP(d_sc.alloc(items));
+        EDLIB_AMD_HIP(hipMemcpyAsync(d_map.p, g.ovfSlots.data(), no * sizeof(int), hipMemcpyHostToDevice, stream_));
+        // (a) count; threshold = the exact best (d_best), so the band is as narrow as it gets
+        if (scanGroup(g, mode, d_map.p, (int)no, kNoCap, g.d_best.p, S2, segLen2, warm2,
+                      d_sb.p, d_sc.p, d_sb.p /*unused*/, 0, nullptr, nullptr)) return 1;
+        std::vector<int> cnts(items);
+        EDLIB_AMD_HIP(hipMemcpyAsync(cnts.data(), d_sc.p, items * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+        std::vector<long long> offs(items);
+        long long acc = 0;
+        g.ovfOff.assign(no + 1, 0);
+        for (size_t i = 0; i < no; ++i) {
+            for (int sg = 0; sg < S2; ++sg) { offs[i * S2 + sg] = acc; acc += cnts[i * S2 + sg]; }
+            g.ovfOff[i + 1] = acc;
+        }
+        EDLIB_AMD_HIP(d_caps.alloc(items)); EDLIB_AMD_HIP(d_off.alloc(items)); EDLIB_AMD_HIP(g.d_ovfPool.ensure((size_t)acc));
+        EDLIB_AMD_HIP(hipMemcpyAsync(d_caps.p, cnts.data(), items * sizeof(int), hipMemcpyHostToDevice, stream_));
+        EDLIB_AMD_HIP(hipMemcpyAsync(d_off.p, offs.data(), items * sizeof(long long), hipMemcpyHostToDevice, stream_));
+        // (b) write
+        if (scanGroup(g, mode, d_map.p, (int)no, kNoCap, g.d_best.p, S2, segLen2, warm2,
+                      d_sb.p, d_sc.p, g.d_ovfPool.p, 0, d_off.p, d_caps.p)) return 1;
+        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));                    // temporaries die here
+        stats.overflow_units += (int)no;
+    }
+    if (banded) {
+        unsigned long long ws = 0;
+        EDLIB_AMD_HIP(hipMemcpy(&ws, d_wordSteps_.p, sizeof ws, hipMemcpyDeviceToHost));
+        stats.word_steps += (long long)ws;
+    }
+    return 0;
+}
+
+int Batch::collectReads(std::vector<UnitResult>& res)
+{
+    if (groups_.empty()) return 0;
+    const int T = tlen(0);
+    const int mode = (cfg_.mode == EDLIB_MODE_HW || cfg_.mode == EDLIB_MODE_SHW) ? (int)cfg_.mode : (int)EDLIB_MODE_NW;
+    for (auto& gp : groups_) {
+        ReadGroup& g = *gp;
+        const size_t ns = (size_t)g.nslots;
+        std::vector<int> best(ns), total(ns), extra(ns), pos(ns * 16), ovfPos((size_t)g.ovfOff.back());
         EDLIB_AMD_HIP(hipMemcpyAsync(best.data(), g.d_best.p, ns * sizeof(int), hipMemcpyDeviceToHost, stream_));
         EDLIB_AMD_HIP(hipMemcpyAsync(total.data(), g.d_total.p, ns * sizeof(int), hipMemcpyDeviceToHost, stream_));
         EDLIB_AMD_HIP(hipMemcpyAsync(extra.data(), g.d_alphaExtra.p, ns * sizeof(int), hipMemcpyDeviceToHost, stream_));
         EDLIB_AMD_HIP(hipMemcpyAsync(pos.data(), g.d_pos.p, ns * 16 * sizeof(int), hipMemcpyDeviceToHost, stream_));
-        EDLIB_AMD_HIP(hipMemcpyAsync(&novf, g.d_flags.p + g.nslots, sizeof(int), hipMemcpyDeviceToHost, stream_));
+        if (!ovfPos.empty())
+            EDLIB_AMD_HIP(hipMemcpyAsync(ovfPos.data(), g.d_ovfPool.p, ovfPos.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
         EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-
-        // Exact second pass for the (rare) slots with more end locations than the first pass
-        // keeps.  Their best score b is already exact, so "score <= b" selects exactly the end
-        // locations: (a) a counting scan over fine segments gives the number of hits of every
-        // (slot, segment), (b) after a prefix sum the same scan writes them to their final place.
-        // Fine segments keep the pass parallel (a handful of slots still fills the chip).
-        std::vector<int> ovfSlots; std::vector<long long> ovfOff; std::vector<int> ovfPos;
-        if (novf > 0 && mode != EDLIB_MODE_NW) {
-            std::vector<int> flags(ns);
-            EDLIB_AMD_HIP(hipMemcpy(flags.data(), g.d_flags.p, ns * sizeof(int), hipMemcpyDeviceToHost));
-            for (size_t s = 0; s < ns; ++s)
-                if (flags[s] && g.perm[s] >= 0) ovfSlots.push_back((int)s);
-            const size_t no = ovfSlots.size();
-            if (no) {
-                int S2, segLen2, warm2;
-                plan_segments((int)no, T, mode, g.warm, 16384, S2, segLen2, warm2);
-                const size_t items = no * (size_t)S2;
-                DevBuf<int> d_map, d_caps, d_pool, d_sb, d_sc; DevBuf<long long> d_off;
-                EDLIB_AMD_HIP(d_map.alloc(no)); EDLIB_AMD_HIP(d_sb.alloc(items)); EDLIB_AMD_HIP(d_sc.alloc(items));
-                EDLIB_AMD_HIP(hipMemcpy(d_map.p, ovfSlots.data(), no * sizeof(int), hipMemcpyHostToDevice));
-                // (a) count; threshold = the exact best (d_best), so the band is as narrow as it gets
-                if (scanGroup(g, mode, d_map.p, (int)no, kNoCap, g.d_best.p, S2, segLen2, warm2,
-                              d_sb.p, d_sc.p, d_sb.p /*unused*/, 0, nullptr, nullptr)) return 1;
-                std::vector<int> cnts(items);
-                EDLIB_AMD_HIP(hipMemcpyAsync(cnts.data(), d_sc.p, items * sizeof(int), hipMemcpyDeviceToHost, stream_));
-                EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-                std::vector<long long> offs(items);
-                long long acc = 0;
-                ovfOff.assign(no + 1, 0);
-                for (size_t i = 0; i < no; ++i) {
-                    for (int sg = 0; sg < S2; ++sg) { offs[i * S2 + sg] = acc; acc += cnts[i * S2 + sg]; }
-                    ovfOff[i + 1] = acc;
-                }
-                EDLIB_AMD_HIP(d_caps.alloc(items)); EDLIB_AMD_HIP(d_off.alloc(items)); EDLIB_AMD_HIP(d_pool.alloc((size_t)acc));
-                EDLIB_AMD_HIP(hipMemcpyAsync(d_caps.p, cnts.data(), items * sizeof(int), hipMemcpyHostToDevice, stream_));
-                EDLIB_AMD_HIP(hipMemcpyAsync(d_off.p, offs.data(), items * sizeof(long long), hipMemcpyHostToDevice, stream_));
-                // (b) write
-                if (scanGroup(g, mode, d_map.p, (int)no, kNoCap, g.d_best.p, S2, segLen2, warm2,
-                              d_sb.p, d_sc.p, d_pool.p, 0, d_off.p, d_caps.p)) return 1;
-                ovfPos.resize((size_t)acc);
-                EDLIB_AMD_HIP(hipMemcpyAsync(ovfPos.data(), d_pool.p, (size_t)acc * sizeof(int), hipMemcpyDeviceToHost, stream_));
-                EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-                stats.overflow_units += (int)no;
-            }
-        }
         size_t oi = 0;
         for (size_t s = 0; s < ns; ++s) {
             const int u = g.perm[s];
@@ -442,8 +457,8 @@ int Batch::runReads(std::vector<UnitResult>& res)
             r.alphabetLength = tab_.sigmaT + extra[s];
             const int m = qlen(u);
             if (mode == EDLIB_MODE_HW || mode == EDLIB_MODE_SHW) {
-                if (oi < ovfSlots.size() && ovfSlots[oi] == (int)s) {
-                    finalize_semiglobal(r, cfg_.k, m, best[s], ovfPos.data() + ovfOff[oi], ovfOff[oi + 1] - ovfOff[oi]);
+                if (oi < g.ovfSlots.size() && g.ovfSlots[oi] == (int)s) {
+                    finalize_semiglobal(r, cfg_.k, m, best[s], ovfPos.data() + g.ovfOff[oi], g.ovfOff[oi + 1] - g.ovfOff[oi]);
                     ++oi;
                 } else {
                     finalize_semiglobal(r, cfg_.k, m, best[s], pos.data() + s * 16, best[s] < 0 ? 0 : total[s]);
@@ -453,11 +468,7 @@ int Batch::runReads(std::vector<UnitResult>& res)
             }
         }
     }
-    if (banded) {
-        unsigned long long ws = 0;
-        EDLIB_AMD_HIP(hipMemcpy(&ws, d_wordSteps_.p, sizeof ws, hipMemcpyDeviceToHost));
-        stats.word_steps += (long long)ws;
-    }
+    readsCollected_ = true;
     return 0;
 }
 
@@ -654,7 +665,10 @@ int Batch::run()
         else r.status = EDLIB_STATUS_ERROR;
     }
     // ---- phase 1: distance + end locations
-    if (runReads(res)) return 1;
+    if (runReads()) return 1;
+    readsCollected_ = groups_.empty();
+    // TASK_DISTANCE leaves the reads-path results in HBM until results(); LOC/PATH need them now
+    if (!readsCollected_ && cfg_.task != EDLIB_TASK_DISTANCE && collectReads(res)) return 1;
     if (!pairUnits_.empty()) {
         std::vector<UnitSpec> units(pairUnits_.size());
         for (size_t i = 0; i < units.size(); ++i) {
@@ -753,8 +767,11 @@ int Batch::run()
     stats.algo_bytes = 0;
     for (int u = 0; u < n_; ++u) {
         const long long m = qlen(u);
-        stats.algo_bytes += tlen(u) + m + 8LL * (res[u].alphabetLength + 1) * ((m + 63) / 64) + 16
-                            + 4LL * (long long)res[u].ends.size();
+        // (sigma+1) Peq rows; units still resident on the device are priced with sigma = |target alphabet|
+        // and one end location
+        const long long sigma = res[u].alphabetLength ? res[u].alphabetLength : tab_.sigmaT;
+        stats.algo_bytes += tlen(u) + m + 8LL * (sigma + 1) * ((m + 63) / 64) + 16
+                            + 4LL * std::max<long long>(1, (long long)res[u].ends.size());
     }
     results_.swap(res);
     haveResults_ = true;
@@ -772,6 +789,10 @@ static int* malloc_ints(const std::vector<int>& v) {
 int Batch::results(EdlibAlignResult* out)
 {
     if (!haveResults_) { set_error("results() before a successful run()"); return 1; }
+    if (!readsCollected_) {
+        EDLIB_AMD_HIP(hipSetDevice(device_));
+        if (collectReads(results_)) return 1;
+    }
     for (int u = 0; u < n_; ++u) {
         const UnitResult& r = results_[u];
         EdlibAlignResult& o = out[u];

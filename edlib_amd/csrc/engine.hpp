@@ -88,13 +88,17 @@ private:
         DevBuf<int> d_perm, d_qlen, d_kinit, d_alphaExtra, d_segBest, d_segCnt, d_segPos;
         DevBuf<int> d_best, d_total, d_pos, d_flags;
         DevBuf<uint32_t> d_peq;
+        // exact second pass of the last run: overflowing slots, their offsets into d_ovfPool
+        std::vector<int> ovfSlots; std::vector<long long> ovfOff; DevBuf<int> d_ovfPool;
     };
     std::vector<std::unique_ptr<ReadGroup>> groups_;
     DevBuf<uint32_t> d_tpk_;
     DevBuf<int> d_trash_;
     DevBuf<unsigned long long> d_wordSteps_;
     bool banded_ = false;        // HW groups use the Ukkonen-banded kernel with k-doubling
-    int runReads(std::vector<UnitResult>& res);
+    int runReads();                                   // device work only; results stay in HBM
+    int collectReads(std::vector<UnitResult>& res);   // D2H + result semantics (lazy for TASK_DISTANCE)
+    bool readsCollected_ = true;
     int scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, int kcap, const int* d_kinit,
                   int numSegments, int segLen, int warm, int* segBest, int* segCnt, int* segPos, int cap,
                   const long long* posOff, const int* posCap);

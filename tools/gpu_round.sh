@@ -9,7 +9,7 @@ python bench.py ${BENCH_ARGS:-} 2> gpurun_out/bench.err | tee gpurun_out/bench.j
 tail -5 gpurun_out/bench.err
 if [ -n "$PROFILE" ]; then
   rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
-  ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o r01 -- python $OLDPWD/bench.py --reads 262144 --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/gpurun_out/prof_bench.json 2> $OLDPWD/gpurun_out/prof.err )
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof -o r01 -- python $OLDPWD/bench.py --reads 262144 --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/gpurun_out/prof_bench.json 2> $OLDPWD/gpurun_out/prof.err )
   tail -3 gpurun_out/prof.err; cat gpurun_out/prof_bench.json
   find gpurun_out/prof -name "*stats*" | head; 
   for f in $(find gpurun_out/prof -name "*kernel_stats.csv"); do head -12 $f; done
