@@ -521,6 +521,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         d.storeOff = storeEntries; if (wantPath) storeEntries += pair_store_entries(s.qlen, s.tlen);
         d.posCap = wantPositions ? kPosCap : 0;
         d.posOff = (long long)i * kPosCap;
+        d.colOff = -1;
         opsOff[i + 1] = opsOff[i] + (wantPath ? (long long)s.qlen + s.tlen : 0);
         stats.word_steps += 2 * nb * (long long)s.tlen;
     }
@@ -544,6 +545,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     a.tlut = d_tlut_.p; a.sigmaT = tab_.sigmaT; a.peq = d_peq64_.p; a.aux = d_aux_.p;
     a.storeP = d_storeP_.p; a.storeM = d_storeM_.p; a.storeS = d_storeS_.p;
     a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p; a.posPool = d_posPool_.p;
+    a.colP = nullptr; a.colM = nullptr; a.colS = nullptr;
     scanTimerStart();
     EDLIB_AMD_HIP(launch_scan_pairs(mode, wantPath, a, stream_));
     scanTimerStop();
@@ -641,6 +643,134 @@ int Batch::alphabetLengths(const std::vector<int>& units, std::vector<UnitResult
     return 0;
 }
 
+// ------------------------------------------------------------- Hirschberg
+
+static bool needs_hirschberg(int m, int T) {
+    const long long nb = (m + 63) / 64;
+    return (2LL * 8 + 4) * nb * T + 8LL * T >= 1024 * 1024;              // edlib.cpp:1188-1190
+}
+
+// One level of the divide step for a set of pieces: forward scan of (query, left half) and reverse
+// scan of (reversed query, reversed right half), both NW and dumped at their last column
+// (edlib.cpp:1246-1260), then the split search on the device (edlib.cpp:1314-1353).
+int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& splitRow,
+                           std::vector<int>& leftScore, std::vector<int>& rightScore)
+{
+    const size_t np = big.size();
+    std::vector<PairDesc> descs(2 * np);
+    std::vector<int> best(np);
+    long long peqWords = 0, auxInts = 0, colBlocks = 0;
+    for (size_t p = 0; p < np; ++p) {
+        const Piece& pc = big[p];
+        const int lw = pc.T / 2, rw = pc.T - lw;                         // :1247-1248
+        const long long nb = (pc.m + 63) / 64;
+        best[p] = pc.score;
+        for (int side = 0; side < 2; ++side) {
+            PairDesc& d = descs[2 * p + side];
+            d.qlen = pc.m; d.kinit = 0; d.posCap = 0; d.posOff = 0; d.storeOff = 0;
+            if (side == 0) { d.qoff = pc.qoff; d.qstep = 1; d.toff = pc.toff; d.tstep = 1; d.tlen = lw; }
+            else { d.qoff = pc.qoff + pc.m - 1; d.qstep = -1; d.toff = pc.toff + pc.T - 1; d.tstep = -1; d.tlen = rw; }
+            d.peqOff = peqWords; peqWords += nb * tab_.sigmaT;
+            d.auxOff = auxInts; if (nb > 64) auxInts += d.tlen;
+            d.colOff = colBlocks; colBlocks += nb;
+            stats.word_steps += 2 * nb * (long long)d.tlen;
+        }
+    }
+    const size_t n = descs.size();
+    DevBuf<unsigned long long> colP, colM; DevBuf<int> colS, d_best, d_out;
+    EDLIB_AMD_HIP(colP.alloc((size_t)colBlocks)); EDLIB_AMD_HIP(colM.alloc((size_t)colBlocks)); EDLIB_AMD_HIP(colS.alloc((size_t)colBlocks));
+    EDLIB_AMD_HIP(d_best.alloc(np)); EDLIB_AMD_HIP(d_out.alloc(3 * np));
+    EDLIB_AMD_HIP(d_descs_.ensure(n)); EDLIB_AMD_HIP(d_peq64_.ensure((size_t)peqWords)); EDLIB_AMD_HIP(d_aux_.ensure((size_t)auxInts));
+    EDLIB_AMD_HIP(d_outScore_.ensure(n)); EDLIB_AMD_HIP(d_outCount_.ensure(n)); EDLIB_AMD_HIP(d_outLast_.ensure(n));
+    EDLIB_AMD_HIP(d_posPool_.ensure(1));
+    EDLIB_AMD_HIP(hipMemcpyAsync(d_descs_.p, descs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
+    EDLIB_AMD_HIP(hipMemcpyAsync(d_best.p, best.data(), np * sizeof(int), hipMemcpyHostToDevice, stream_));
+    EDLIB_AMD_HIP(launch_build_peq_pairs(d_descs_.p, (int)n, d_qpool_.p, d_eq8_.p, d_idToByte_.p, tab_.sigmaT,
+                                         d_peq64_.p, stream_));
+    PairScanArgs a{};
+    a.descs = d_descs_.p; a.numUnits = (int)n; a.qpool = d_qpool_.p; a.tpool = d_tpool_.p;
+    a.tlut = d_tlut_.p; a.sigmaT = tab_.sigmaT; a.peq = d_peq64_.p; a.aux = d_aux_.p;
+    a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p; a.posPool = d_posPool_.p;
+    a.colP = colP.p; a.colM = colM.p; a.colS = colS.p;
+    scanTimerStart();
+    EDLIB_AMD_HIP(launch_scan_pairs(EDLIB_MODE_NW, false, a, stream_));
+    scanTimerStop();
+    SplitArgs sa{};
+    sa.descs = d_descs_.p; sa.numPieces = (int)np; sa.best = d_best.p;
+    sa.colP = colP.p; sa.colM = colM.p; sa.colS = colS.p; sa.out = d_out.p;
+    EDLIB_AMD_HIP(launch_hirschberg_split(sa, stream_));
+    std::vector<int> out(3 * np);
+    EDLIB_AMD_HIP(hipMemcpyAsync(out.data(), d_out.p, out.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+    splitRow.resize(np); leftScore.resize(np); rightScore.resize(np);
+    for (size_t p = 0; p < np; ++p) { splitRow[p] = out[3 * p]; leftScore[p] = out[3 * p + 1]; rightScore[p] = out[3 * p + 2]; }
+    return 0;
+}
+
+// Alignment paths of NW jobs of any size (reference obtainAlignment, edlib.cpp:1161-1213): pieces at
+// or above the 1 MiB column-store estimate are halved Hirschberg-style, level by level across the
+// whole batch, until every piece fits the traceback branch; the pieces' op strings concatenate.
+int Batch::solvePaths(const std::vector<Piece>& jobs, std::vector<std::vector<uint8_t>>& opsOut, std::vector<int>& status)
+{
+    const size_t nj = jobs.size();
+    opsOut.assign(nj, {}); status.assign(nj, EDLIB_STATUS_OK);
+    std::vector<std::vector<Piece>> pieces(nj);
+    for (size_t j = 0; j < nj; ++j) pieces[j].push_back(jobs[j]);
+    for (int level = 0; level < 64; ++level) {
+        std::vector<Piece> big; std::vector<std::pair<size_t, size_t>> where;
+        for (size_t j = 0; j < nj; ++j) {
+            if (status[j] != EDLIB_STATUS_OK) continue;
+            for (size_t i = 0; i < pieces[j].size(); ++i) {
+                const Piece& pc = pieces[j][i];
+                if (pc.m > 0 && pc.T > 0 && needs_hirschberg(pc.m, pc.T)) {
+                    if (pc.T < 2) { status[j] = EDLIB_STATUS_ERROR; break; }   // the reference has no answer here either
+                    big.push_back(pc); where.push_back({j, i});
+                }
+            }
+        }
+        if (big.empty()) break;
+        std::vector<int> row, ls, rs;
+        if (hirschbergLevel(big, row, ls, rs)) return 1;
+        // replace pieces back to front so the recorded indices stay valid
+        for (size_t b = big.size(); b-- > 0;) {
+            const size_t j = where[b].first, i = where[b].second;
+            if (status[j] != EDLIB_STATUS_OK) continue;
+            if (row[b] == -2) { status[j] = EDLIB_STATUS_ERROR; continue; }          // edlib.cpp:1358-1362
+            const Piece pc = pieces[j][i];
+            const int lw = pc.T / 2, ulH = row[b] + 1;                                // :1367-1370
+            const Piece ul{pc.qoff, ulH, pc.toff, lw, ls[b]};
+            const Piece lr{pc.qoff + ulH, pc.m - ulH, pc.toff + lw, pc.T - lw, rs[b]};
+            pieces[j][i] = ul;
+            pieces[j].insert(pieces[j].begin() + i + 1, lr);
+        }
+    }
+    // leaves: trivial pieces on the host (edlib.cpp:1168-1175), the rest through store + traceback
+    std::vector<UnitSpec> units; std::vector<std::pair<size_t, size_t>> where;
+    for (size_t j = 0; j < nj; ++j) {
+        if (status[j] != EDLIB_STATUS_OK) continue;
+        for (size_t i = 0; i < pieces[j].size(); ++i) {
+            const Piece& pc = pieces[j][i];
+            if (pc.m > 0 && pc.T > 0) { units.push_back(UnitSpec{pc.qoff, pc.m, 1, pc.toff, pc.T, 1, 0}); where.push_back({j, i}); }
+        }
+    }
+    SolveOut so;
+    if (solve(EDLIB_MODE_NW, false, true, units, so)) return 1;
+    std::vector<std::vector<std::vector<uint8_t>>> leafOps(nj);
+    for (size_t j = 0; j < nj; ++j) leafOps[j].resize(pieces[j].size());
+    for (size_t u = 0; u < units.size(); ++u)
+        leafOps[where[u].first][where[u].second].assign(so.ops.begin() + so.opsStart[u], so.ops.begin() + so.opsStart[u + 1]);
+    for (size_t j = 0; j < nj; ++j) {
+        if (status[j] != EDLIB_STATUS_OK) continue;
+        for (size_t i = 0; i < pieces[j].size(); ++i) {
+            const Piece& pc = pieces[j][i];
+            if (pc.m == 0) opsOut[j].insert(opsOut[j].end(), (size_t)pc.T, (uint8_t)EDLIB_EDOP_DELETE);
+            else if (pc.T == 0) opsOut[j].insert(opsOut[j].end(), (size_t)pc.m, (uint8_t)EDLIB_EDOP_INSERT);
+            else opsOut[j].insert(opsOut[j].end(), leafOps[j][i].begin(), leafOps[j][i].end());
+        }
+    }
+    return 0;
+}
+
 // --------------------------------------------------------------------- run
 
 int Batch::run()
@@ -725,7 +855,7 @@ int Batch::run()
     }
     // ---- phase 3: alignment path of the first location (edlib.cpp:276-289, 1161-1213)
     if (cfg_.task == EDLIB_TASK_PATH) {
-        std::vector<UnitSpec> units; std::vector<int> where;
+        std::vector<Piece> jobs; std::vector<int> where;
         for (int u : live) {
             UnitResult& r = res[u];
             if (r.ends.empty()) continue;
@@ -733,22 +863,16 @@ int Batch::run()
             const int s = r.starts[0], e = r.ends[0];
             const int len = e - s + 1;
             if (len <= 0) { r.ops.assign(m, EDLIB_EDOP_INSERT); r.hasAlignment = true; continue; }   // :1168-1175
-            const long long nb = (m + 63) / 64;
-            const long long bytes = (2LL * 8 + 4) * nb * len + 8LL * len;                             // :1188-1189
-            if (bytes >= 1024 * 1024) {
-                r.status = EDLIB_STATUS_ERROR;     // Hirschberg regime: not implemented
-                set_error("TASK_PATH for a %d x %d window needs the Hirschberg branch (not implemented)", m, len);
-                continue;
-            }
-            units.push_back(UnitSpec{qoff_[u], m, 1, tbase(u) + s, len, 1, 0});
+            jobs.push_back(Piece{qoff_[u], m, tbase(u) + s, len, r.editDistance});
             where.push_back(u);
         }
-        if (!units.empty()) {
-            SolveOut so;
-            if (solve(EDLIB_MODE_NW, false, true, units, so)) return 1;
-            for (size_t i = 0; i < units.size(); ++i) {
+        if (!jobs.empty()) {
+            std::vector<std::vector<uint8_t>> ops; std::vector<int> st;
+            if (solvePaths(jobs, ops, st)) return 1;
+            for (size_t i = 0; i < jobs.size(); ++i) {
                 UnitResult& r = res[where[i]];
-                r.ops.assign(so.ops.begin() + so.opsStart[i], so.ops.begin() + so.opsStart[i + 1]);
+                if (st[i] != EDLIB_STATUS_OK) { r.status = EDLIB_STATUS_ERROR; continue; }
+                r.ops.swap(ops[i]);
                 r.hasAlignment = true;
             }
         }

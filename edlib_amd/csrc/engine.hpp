@@ -113,6 +113,11 @@ private:
     int solveChunk(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units,
                    size_t a, size_t b, SolveOut& out);
     int alphabetLengths(const std::vector<int>& units, std::vector<UnitResult>& res);
+    // linear-space paths (reference obtainAlignmentHirschberg, edlib.cpp:1231-1396)
+    struct Piece { long long qoff; int m; long long toff; int T; int score; };
+    int hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& splitRow,
+                        std::vector<int>& leftScore, std::vector<int>& rightScore);
+    int solvePaths(const std::vector<Piece>& jobs, std::vector<std::vector<uint8_t>>& opsOut, std::vector<int>& status);
 
     int qlen(int u) const { return (int)(qoff_[u + 1] - qoff_[u]); }
     long long tbase(int u) const { return shared_ ? toff_[0] : toff_[u]; }

@@ -181,6 +181,9 @@ scan_pairs_kernel(const PairScanArgs a)
                     a.storeP[si] = Pv; a.storeM[si] = Mv; a.storeS[si] = bscore;
                 }
                 if (!lastStrip && lane == 63) a.aux[d.auxOff + col] = hout + 1;
+                if (a.colP && d.colOff >= 0 && col == T - 1) {              // last column (Hirschberg)
+                    a.colP[d.colOff + b] = Pv; a.colM[d.colOff + b] = Mv; a.colS[d.colOff + b] = bscore;
+                }
                 if (tracker) {
                     sc += (int)((ph >> sh) & 1ull) - (int)((mh >> sh) & 1ull);
                     if (MODE != 0 && sc <= best) {                   // edlib.cpp:658-673
@@ -225,6 +228,58 @@ hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStr
         case 5: return launch_scan_pairs_t<2, true>(a, stream);
     }
     return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------- Hirschberg split
+
+// value of the cell at row r of a dumped column (same decoding as the traceback's left neighbour)
+__device__ __forceinline__ int column_cell(const u64* P, const u64* M, const int* S, long long off, int r)
+{
+    const int b = r >> 6, bit = r & 63;
+    const u64 above = (bit == 63) ? 0ull : (~0ull << (bit + 1));
+    return S[off + b] - __popcll(P[off + b] & above) + __popcll(M[off + b] & above);
+}
+
+// reference edlib.cpp:1314-1353 ("find the best move").  One workgroup per piece.
+__global__ void __launch_bounds__(256)
+hirschberg_split_kernel(const SplitArgs a)
+{
+    __shared__ int s_first;
+    const int p = blockIdx.x;
+    const PairDesc f = a.descs[2 * p], r = a.descs[2 * p + 1];
+    const int m = f.qlen, best = a.best[p];
+    const int lw = f.tlen, rw = r.tlen;
+    if (threadIdx.x == 0) s_first = 0x7fffffff;
+    __syncthreads();
+    // L[i]   = D(query[0..i], left half)            = forward column cell i
+    // R[i+1] = D(query[i+1..m-1], right half)       = reverse column cell (m-1) - (i+1)
+    for (int i = threadIdx.x; i <= m - 2; i += blockDim.x) {
+        const int L = column_cell(a.colP, a.colM, a.colS, f.colOff, i);
+        const int R = column_cell(a.colP, a.colM, a.colS, r.colOff, m - 2 - i);
+        if (L + R == best) atomicMin(&s_first, i);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int i = s_first, ls = -1, rs = -1;
+        if (i != 0x7fffffff) {
+            ls = column_cell(a.colP, a.colM, a.colS, f.colOff, i);
+            rs = column_cell(a.colP, a.colM, a.colS, r.colOff, m - 2 - i);
+        } else {
+            const int R0 = column_cell(a.colP, a.colM, a.colS, r.colOff, m - 1);     // whole query vs right half
+            const int Lm = column_cell(a.colP, a.colM, a.colS, f.colOff, m - 1);     // whole query vs left half
+            if (lw + R0 == best) { i = -1; ls = lw; rs = R0; }                       // :1337-1344
+            else if (Lm + rw == best) { i = m - 1; ls = Lm; rs = rw; }               // :1345-1353
+            else i = -2;
+        }
+        a.out[3 * p] = i; a.out[3 * p + 1] = ls; a.out[3 * p + 2] = rs;
+    }
+}
+
+hipError_t launch_hirschberg_split(const SplitArgs& a, hipStream_t stream)
+{
+    if (a.numPieces == 0) return hipSuccess;
+    hipLaunchKernelGGL(hirschberg_split_kernel, dim3(a.numPieces), dim3(256), 0, stream, a);
+    return hipGetLastError();
 }
 
 // --------------------------------------------------------------- traceback

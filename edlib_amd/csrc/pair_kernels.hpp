@@ -24,6 +24,7 @@ struct PairDesc {
     int kinit;           // SHW/HW: columns scoring <= kinit are end-location candidates
     int posCap;          // capacity of this unit's end-position list
     long long posOff;    // first int of that list in the positions pool
+    long long colOff;    // first block of this unit's last-column dump (Hirschberg), or -1
 };
 
 struct PairScanArgs {
@@ -44,6 +45,10 @@ struct PairScanArgs {
     int* outCount;              // [units] SHW/HW: number of columns attaining it
     int* outLast;               // [units] SHW/HW: last (largest) such column, -1 if none
     int* posPool;               // end positions
+    // last-column dump (may be null): (Pv, Mv, block score) of every block at column tlen-1
+    unsigned long long* colP;
+    unsigned long long* colM;
+    int* colS;
 };
 
 // mode: 0 NW, 1 SHW, 2 HW.  store: also write the column store.
@@ -71,5 +76,21 @@ hipError_t launch_traceback(const TracebackArgs& a, hipStream_t stream);
 
 // number of block-steps the column store of a unit needs
 long long pair_store_entries(int qlen, int tlen);
+
+// Hirschberg split (reference obtainAlignmentHirschberg, edlib.cpp:1314-1353).  For piece p the
+// forward unit 2p holds the last column of (query vs left half), the reverse unit 2p+1 the last column
+// of (reversed query vs reversed right half).  Finds the first query row i in [0, m-2] with
+// L[i] + R[i+1] == best, else the boundary cases i = -1 / i = m-1; out[3p..3p+2] = {i, leftScore,
+// rightScore} (i = -2 if nothing adds up: internal error).
+struct SplitArgs {
+    const PairDesc* descs;      // 2 per piece (forward, reverse)
+    int numPieces;
+    const int* best;            // [pieces] distance of the piece
+    const unsigned long long* colP;
+    const unsigned long long* colM;
+    const int* colS;
+    int* out;                   // [pieces][3]
+};
+hipError_t launch_hirschberg_split(const SplitArgs& a, hipStream_t stream);
 
 }  // namespace edlib_amd

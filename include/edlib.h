@@ -14,13 +14,10 @@
  *   result arrays are libc malloc() memory owned by the caller
  *   (edlibFreeAlignResult() or plain free()).
  *
- * Behaviour that differs from the reference, all of it additive:
+ * Behaviour that differs from the reference:
  *   - when no MI355X-class device / HIP runtime is usable, edlibAlign() does
  *     NOT fall back to a CPU path: it returns status == EDLIB_STATUS_ERROR
- *     and prints one line to stderr;
- *   - TASK_PATH on a (query, target-window) pair whose column store would be
- *     >= 1 MiB (where the reference switches to Hirschberg,
- *     edlib.cpp:1188-1211) is not implemented yet: status == EDLIB_STATUS_ERROR.
+ *     and prints one line to stderr.
  */
 #ifndef EDLIB_H
 #define EDLIB_H

@@ -194,6 +194,28 @@ def synth_cases():
         cases.append({"name": "c5.pair%d" % i,
                       "input": {"kind": "mut", "seed": 12350 + i, "tn": 1000, "sub": 0.03, "ins": 0.01, "del": 0.01},
                       "mode": "NW", "task": "path", "k": -1, "eq": None})
+    # PATH in the Hirschberg regime (column store >= 1 MiB, edlib.cpp:1188-1211): 10 kb pairs (config 4
+    # with task=path), 3 kb pairs, tie-rich small alphabets, a long read in HW / SHW mode
+    for i in range(3):
+        cases.append({"name": "hirsch.c4.pair%d" % i,
+                      "input": {"kind": "mut", "seed": 22000 + i, "tn": 10000,
+                                "sub": [0.04, 0.01, 0.002][i], "ins": [0.04, 0.01, 0.002][i], "del": [0.04, 0.01, 0.002][i]},
+                      "mode": "NW", "task": "path", "k": -1, "eq": None})
+    for i in range(6):
+        cases.append({"name": "hirsch.3kb.pair%d" % i,
+                      "input": {"kind": "mut", "seed": 22100 + i, "tn": 3000 + 37 * i, "sub": 0.05, "ins": 0.02, "del": 0.02},
+                      "mode": "NW", "task": "path", "k": -1, "eq": None})
+    for i, sigma in enumerate((1, 2, 2, 3, 4)):
+        cases.append({"name": "hirsch.ties.sigma%d.%d" % (sigma, i),
+                      "input": {"kind": "rand", "seed": 22200 + i, "m": 2300 + 100 * i, "tn": 2500 + 64 * i, "sigma": sigma},
+                      "mode": ["NW", "NW", "HW", "SHW", "NW"][i], "task": "path", "k": -1, "eq": None})
+    for i, mode in enumerate(("HW", "SHW", "HW")):
+        cases.append({"name": "hirsch.longread.%s.%d" % (mode, i),
+                      "input": {"kind": "read", "seed": 22300 + i, "tseed": 22301, "tn": 60000, "m": 2400, "index": i, "n": 4},
+                      "mode": mode, "task": "path", "k": -1, "eq": None})
+    cases.append({"name": "hirsch.c1.pair",
+                  "input": {"kind": "mut", "seed": 9100, "tn": 94481, "sub": 0.003, "ins": 0.001, "del": 0.001},
+                  "mode": "NW", "task": "path", "k": -1, "eq": None})
     # config-1 shape: a 94 kb pair at three divergences (the Phage files cannot travel)
     for i, rate in enumerate((0.003, 0.03, 0.1)):
         cases.append({"name": "c1.pair%d" % i,

@@ -83,11 +83,12 @@ def _group(cases, key):
 def test_golden_batches_shared_target(engine):
     """The c2.* fixtures again, but as ONE batch per target through the reads-per-lane kernel."""
     cases = [c for c in load_golden("synth_ref.json") if c["input"]["kind"] == "read"]
-    groups = _group(cases, lambda c: (c["input"]["tseed"], c["input"]["tn"], c["input"]["m"], c["input"]["seed"], c["task"]))
+    groups = _group(cases, lambda c: (c["input"]["tseed"], c["input"]["tn"], c["input"]["m"], c["input"]["seed"],
+                                      c["task"], c["mode"]))
     for key, cs in groups.items():
         qs = [gc.materialise(c)[0] for c in cs]
         t = gc.materialise(cs[0])[1]
-        got = engine.align_batch(qs, t, mode="HW", task=cs[0]["task"], k=-1, raw=True)
+        got = engine.align_batch(qs, t, mode=cs[0]["mode"], task=cs[0]["task"], k=-1, raw=True)
         for c, g in zip(cs, got):
             check(g, gc.expected(c), c["name"] + " (batched)")
 
