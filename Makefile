@@ -12,7 +12,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Iin
 SRCS := $(CSRC)/reads_kernels.hip $(CSRC)/pair_kernels.hip $(CSRC)/engine.hip $(CSRC)/api.hip
 OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 
-all: edlib_amd/libedlib.so
+all: edlib_amd/libedlib.so build/edlib-aligner-batch
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hpp) include/edlib.h include/edlib_amd.h
 	@mkdir -p $(OBJDIR)
@@ -20,6 +20,11 @@ $(OBJDIR)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hpp) include/edlib.h include/e
 
 edlib_amd/libedlib.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+# batch-aware CLI with the reference CLI's flags and output
+build/edlib-aligner-batch: apps/aligner_batch.cpp edlib_amd/libedlib.so include/edlib.h include/edlib_amd.h
+	@mkdir -p build
+	g++ -O2 -std=c++14 -Iinclude apps/aligner_batch.cpp -Ledlib_amd -l:libedlib.so -Wl,-rpath,'$$ORIGIN/../edlib_amd' -o $@
 
 oracle:
 	$(MAKE) -C oracle all

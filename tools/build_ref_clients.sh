@@ -12,6 +12,8 @@ LINK="-L$ROOT/edlib_amd -l:libedlib.so -Wl,-rpath,\$ORIGIN/../../edlib_amd"
 g++ -O2 -std=c++14 -I"$REF/edlib/include" -I"$REF/test" "$REF/test/runTests.cpp" $LINK -o "$ROOT/oracle/_ref/runTests_amd"
 g++ -O2 -std=c++14 -I"$REF/edlib/include" "$REF/apps/aligner/aligner.cpp" $LINK -o "$ROOT/oracle/_ref/aligner_amd"
 gcc -O2 -I"$REF/edlib/include" "$REF/apps/hello-world/helloWorld.c" $LINK -o "$ROOT/oracle/_ref/hello_amd"
+# the pure reference CLI (reference library underneath): expected output for the CLI tests
+g++ -O2 -std=c++14 -I"$REF/edlib/include" "$REF/apps/aligner/aligner.cpp" "$REF/edlib/src/edlib.cpp" -o "$ROOT/oracle/_ref/aligner_ref"
 install -m 644 "$REF/apps/aligner/test_data/query.fasta" "$ROOT/oracle/_ref/aligner_query.fasta"
 install -m 644 "$REF/apps/aligner/test_data/target.fasta" "$ROOT/oracle/_ref/aligner_target.fasta"
 echo "built oracle/_ref/{runTests_amd,aligner_amd,hello_amd}"
