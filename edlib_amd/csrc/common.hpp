@@ -23,6 +23,13 @@ void set_error(const char* fmt, ...);
         }                                                                              \
     } while (0)
 
+// Process-wide cache of device allocations (power-of-two size classes, per device).  edlibAlign()
+// is a batch of one: without the cache every call pays ~30 hipMalloc/hipFree round trips.
+hipError_t pool_alloc(void** p, size_t bytes, size_t* granted);
+void pool_free(void* p, size_t granted);
+hipError_t pool_stream(hipStream_t* s);
+void pool_stream_release(hipStream_t s);
+
 // Device allocation that frees itself.  Never holds host-visible result memory:
 // everything handed to the caller is libc malloc() (reference ownership rules,
 // edlib.h:177-205).
@@ -30,16 +37,17 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    size_t granted = 0;      // bytes of the underlying pool block
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    void release() { if (p) { pool_free(p, granted); p = nullptr; n = 0; granted = 0; } }
     hipError_t alloc(size_t count) {
         release();
         if (count == 0) count = 1;
         n = count;
-        return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+        return pool_alloc(reinterpret_cast<void**>(&p), count * sizeof(T), &granted);
     }
     // grow-only
     hipError_t ensure(size_t count) { return (count <= n && p) ? hipSuccess : alloc(count); }

@@ -29,6 +29,78 @@ void set_error(const char* fmt, ...) {
     last_error() = buf;
 }
 
+// ------------------------------------------------------------ device pool
+
+namespace {
+struct Pool {
+    std::mutex mu;
+    static const int kMaxDev = 16;
+    std::vector<void*> blocks[kMaxDev][48];     // [device][log2 size class]
+    std::vector<hipStream_t> streams[kMaxDev];
+    size_t cachedBytes = 0;
+};
+Pool& pool() { static Pool* p = new Pool; return *p; }     // leaked on purpose: no teardown-order hazards
+const size_t kPoolMaxBlock = 64u << 20;                     // larger blocks go straight back to the driver
+const size_t kPoolMaxCached = 1024u << 20;
+int size_class(size_t bytes, size_t* rounded) {
+    int c = 8;                                              // 256 B minimum
+    while (((size_t)1 << c) < bytes) ++c;
+    *rounded = (size_t)1 << c;
+    return c;
+}
+}  // namespace
+
+hipError_t pool_alloc(void** p, size_t bytes, size_t* granted) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (bytes <= kPoolMaxBlock && dev < Pool::kMaxDev) {
+        size_t r; const int c = size_class(bytes, &r);
+        {
+            std::lock_guard<std::mutex> g(pool().mu);
+            auto& v = pool().blocks[dev][c];
+            if (!v.empty()) { *p = v.back(); v.pop_back(); pool().cachedBytes -= r; *granted = r; return hipSuccess; }
+        }
+        *granted = r;
+        return hipMalloc(p, r);
+    }
+    *granted = bytes;
+    return hipMalloc(p, bytes);
+}
+
+void pool_free(void* p, size_t granted) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device; else (void)hipGetLastError();
+    if (granted <= kPoolMaxBlock && dev < Pool::kMaxDev && (granted & (granted - 1)) == 0) {
+        size_t r; const int c = size_class(granted, &r);
+        std::lock_guard<std::mutex> g(pool().mu);
+        if (pool().cachedBytes + r <= kPoolMaxCached) { pool().blocks[dev][c].push_back(p); pool().cachedBytes += r; return; }
+    }
+    (void)hipFree(p);
+}
+
+hipError_t pool_stream(hipStream_t* s) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < Pool::kMaxDev) {
+        std::lock_guard<std::mutex> g(pool().mu);
+        auto& v = pool().streams[dev];
+        if (!v.empty()) { *s = v.back(); v.pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
+void pool_stream_release(hipStream_t s) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < Pool::kMaxDev) {
+        std::lock_guard<std::mutex> g(pool().mu);
+        if (pool().streams[dev].size() < 16) { pool().streams[dev].push_back(s); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
+
 int device_count() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
@@ -118,7 +190,7 @@ count_flags_kernel(const int* __restrict__ flags, int n, int* __restrict__ count
 Batch::~Batch() {
     (void)hipSetDevice(device_);
     for (auto& p : scanEvents_) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    if (stream_) (void)hipStreamDestroy(stream_);
+    if (stream_) { (void)hipStreamSynchronize(stream_); pool_stream_release(stream_); }
 }
 
 static int roundup(int x, int q) { return (x + q - 1) / q * q; }
@@ -151,7 +223,7 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
                  eqs_.data(), (int)eqs_.size());
 
     EDLIB_AMD_HIP(hipSetDevice(device_));
-    EDLIB_AMD_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    EDLIB_AMD_HIP(pool_stream(&stream_));
     EDLIB_AMD_HIP(evRun0_.create()); EDLIB_AMD_HIP(evRun1_.create());
 
     // resident inputs (pools are rebased to offset 0)

@@ -342,14 +342,41 @@ hipError_t launch_scan_reads(int nwords, int mode, const ReadScanArgs& a, hipStr
 //   * the bottom query row (bit (m-1)%32 of the last word) is only in the band while nw == NWD, so
 //     its score is only followed then; e = score - best - 1 is tracked instead of score, its sign bit is
 //     OR-ed into `flag`, and once per 4 columns a WAVE-UNIFORM test (ballot) enters the rare path,
-//     which is branch-free per lane (selects + a store that non-hit lanes aim at a trash word).
-//     The loop therefore contains only wave-uniform branches.
+//     which updates best/count with selects and stores the position under an exec mask.
 // Op selection follows tools/valu_ubench.hip: x+x instead of v_lshlrev (half rate on gfx950),
 // v_lshrrev + v_and instead of v_bfe, no SGPR operands in the hot VALU ops.
+// Two active words are one 64-bit value: v_lshl_add_u64 and v_lshlrev_b64 take 4 cycles for 64 bits
+// (tools/valu_ubench.hip) where the 32-bit carry chain and v_alignbit pairs take 8 and 6.
+// v_bitop3_b32 truth tables: bit i of the immediate is f(a,b,c) with i = a*4 + b*2 + c
+#define BITOP3_XOR_OR(a, b, c)   __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xde)   /* (a ^ c) | b   */
+#define BITOP3_OR_NOR(a, b, c)   __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xf1)   /* a | ~(b | c)  */
+
+template <int NWD>
+__device__ __forceinline__ void column_step_hw2(const u32 (&Eq)[NWD], u32 (&Pv)[NWD], u32 (&Mv)[NWD])
+{
+    typedef unsigned long long u64;
+    // booleans stay 32-bit, one v_bitop3_b32 per 3-input function; only the add and the two shifts
+    // see the 64-bit register pair
+    const u32 t0 = Eq[0] & Pv[0], t1 = Eq[1] & Pv[1];
+    const u64 t = ((u64)t1 << 32) | t0, pv = ((u64)Pv[1] << 32) | Pv[0];
+    u64 s;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(s) : "v"(t), "v"(pv));
+    const u32 Xh0 = BITOP3_XOR_OR((u32)s, Eq[0], Pv[0]), Xh1 = BITOP3_XOR_OR((u32)(s >> 32), Eq[1], Pv[1]);
+    const u32 Ph0 = BITOP3_OR_NOR(Mv[0], Xh0, Pv[0]), Ph1 = BITOP3_OR_NOR(Mv[1], Xh1, Pv[1]);
+    const u32 Mh0 = Pv[0] & Xh0, Mh1 = Pv[1] & Xh1;
+    u64 ph, mh;
+    asm("v_lshlrev_b64 %0, 1, %1" : "=v"(ph) : "v"(((u64)Ph1 << 32) | Ph0));
+    asm("v_lshlrev_b64 %0, 1, %1" : "=v"(mh) : "v"(((u64)Mh1 << 32) | Mh0));
+    const u32 Xv0 = Eq[0] | Mv[0], Xv1 = Eq[1] | Mv[1];
+    Pv[0] = BITOP3_OR_NOR((u32)mh, Xv0, (u32)ph);  Pv[1] = BITOP3_OR_NOR((u32)(mh >> 32), Xv1, (u32)(ph >> 32));
+    Mv[0] = (u32)ph & Xv0;                          Mv[1] = (u32)(ph >> 32) & Xv1;
+}
+
 template <int NA, int NWD>
 __device__ __forceinline__ void column_step_hw(const u32 (&Eq)[NWD], u32 (&Pv)[NWD], u32 (&Mv)[NWD],
                                                int& e, int& flag, const u32 sh)
 {
+    if (NA == 2 && NWD > 2) { column_step_hw2<NWD>(Eq, Pv, Mv); return; }
     u32 Ph[NA], Mh[NA];
     u32 carry = 0;
 #pragma unroll
@@ -424,8 +451,7 @@ __device__ __forceinline__ int band_dword(const u32 tw, const int colBase, const
                     const bool better = hit && (sc < tr.best);
                     tr.cnt = better ? 0 : tr.cnt;
                     tr.best = better ? sc : tr.best;
-                    int* p = (hit && tr.cnt < tr.cap) ? (tr.pos + tr.cnt) : tr.trash;
-                    *p = col;
+                    if (hit && tr.cnt < tr.cap) tr.pos[tr.cnt] = col;
                     tr.cnt += hit ? 1 : 0;
                 }
                 e = eh[3] + bestIn - tr.best;                               // rebase e on the new best

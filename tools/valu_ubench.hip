@@ -53,6 +53,30 @@ __global__ void __launch_bounds__(256) k_op(u32* out, int iters, u32 seed)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// 64-bit forms: does one u64 op beat two u32 ops?
+template <int KIND>
+__global__ void __launch_bounds__(256) k_op64(u32* out, int iters, u32 seed)
+{
+    unsigned long long r[8];
+    for (int i = 0; i < 8; ++i) r[i] = (unsigned long long)seed * (threadIdx.x + 1) + i * 77;
+    unsigned long long a = seed ^ threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#define OP(i)                                                                                           \
+            if (KIND == 0) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(r[i]) : "v"(a));           \
+            if (KIND == 1) asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(r[i]));                         \
+            if (KIND == 2) asm volatile("v_lshl_add_u64 %0, %0, 1, %1" : "+v"(r[i]) : "v"(a));           \
+            if (KIND == 3) asm volatile("v_lshrrev_b64 %0, 31, %0" : "+v"(r[i]));
+            REP8(OP)
+#undef OP
+        }
+    }
+    unsigned long long s = 0;
+    for (int i = 0; i < 8; ++i) s ^= r[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (u32)s ^ (u32)(s >> 32);
+}
+
 // carry chain: v_add_co + 4 x v_addc_co (the multi-word add of the column step)
 __global__ void __launch_bounds__(256) k_addc(u32* out, int iters, u32 seed)
 {
@@ -149,7 +173,7 @@ int main()
                              "v_lshlrev_b32", "v_lshrrev_b32", "v_add_u32", "v_min_i32", "v_bcnt_u32_b32", "v_bfi_b32", "v_and_or_b32", "v_or3_b32",
                              "v_lshl_or_b32", "v_add_co_u32", "v_cmp_le_i32", "v_ashrrev_i32", "v_mov_b32_dpp", "v_and_b32(sgpr)", "v_bitop3(sgpr)"};
     printf("# ops/clk/CU assume 2.4 GHz; peak model = 4 SIMD x 32 lanes = 128 lane-ops/clk/CU\n");
-    for (int wps : {4, 8}) {
+    for (int wps : {8}) {
         const int blocks = 256 * wps;          // 256-thread blocks: 4 waves = 1 per SIMD
         const int iters = 20000;
         const double laneops = (double)blocks * 256 * iters * 64;
@@ -157,6 +181,12 @@ int main()
                  printf("waves/SIMD %d  %-16s %8.3f ms  %7.2f T lane-ops/s  %6.1f lane-ops/clk/CU@2.4GHz\n", wps, names[K], ms, laneops / ms / 1e9, laneops / (ms * 1e-3) / 2.4e9 / 256); }
         RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7)
         if (wps == 8) { RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18) RUN(19) RUN(20) RUN(21) RUN(22) }
+        if (wps == 8) {
+            const char* n64[4] = {"v_lshl_add_u64(+0)", "v_lshlrev_b64", "v_lshl_add_u64(<<1)", "v_lshrrev_b64"};
+#define RUN64(K) { float ms = time_ms([&] { hipLaunchKernelGGL(k_op64<K>, dim3(blocks), dim3(256), 0, 0, out, iters, 7u); }); \
+                 printf("waves/SIMD %d  %-20s %8.3f ms  %7.2f T 64-bit lane-ops/s\n", wps, n64[K], ms, laneops / ms / 1e9); }
+            RUN64(0) RUN64(1) RUN64(2) RUN64(3)
+        }
         { const double lo = (double)blocks * 256 * iters * 8 * 5;
           float ms = time_ms([&] { hipLaunchKernelGGL(k_addc, dim3(blocks), dim3(256), 0, 0, out, iters, 7u); });
           printf("waves/SIMD %d  %-16s %8.3f ms  %7.2f T lane-ops/s  %6.1f lane-ops/clk/CU@2.4GHz\n", wps, "add_co+4addc", ms, lo / ms / 1e9, lo / (ms * 1e-3) / 2.4e9 / 256); }
