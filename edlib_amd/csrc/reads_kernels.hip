@@ -352,25 +352,57 @@ hipError_t launch_scan_reads(int nwords, int mode, const ReadScanArgs& a, hipStr
 #define BITOP3_OR_NOR(a, b, c)   __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xf1)   /* a | ~(b | c)  */
 
 template <int NWD>
-__device__ __forceinline__ void column_step_hw2(const u32 (&Eq)[NWD], u32 (&Pv)[NWD], u32 (&Mv)[NWD])
+__device__ __forceinline__ void column_step_eq2(const u32 eq0, const u32 eq1, u32 (&Pv)[NWD], u32 (&Mv)[NWD])
 {
     typedef unsigned long long u64;
     // booleans stay 32-bit, one v_bitop3_b32 per 3-input function; only the add and the two shifts
     // see the 64-bit register pair
-    const u32 t0 = Eq[0] & Pv[0], t1 = Eq[1] & Pv[1];
+    const u32 t0 = eq0 & Pv[0], t1 = eq1 & Pv[1];
     const u64 t = ((u64)t1 << 32) | t0, pv = ((u64)Pv[1] << 32) | Pv[0];
     u64 s;
     asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(s) : "v"(t), "v"(pv));
-    const u32 Xh0 = BITOP3_XOR_OR((u32)s, Eq[0], Pv[0]), Xh1 = BITOP3_XOR_OR((u32)(s >> 32), Eq[1], Pv[1]);
+    const u32 Xh0 = BITOP3_XOR_OR((u32)s, eq0, Pv[0]), Xh1 = BITOP3_XOR_OR((u32)(s >> 32), eq1, Pv[1]);
     const u32 Ph0 = BITOP3_OR_NOR(Mv[0], Xh0, Pv[0]), Ph1 = BITOP3_OR_NOR(Mv[1], Xh1, Pv[1]);
     const u32 Mh0 = Pv[0] & Xh0, Mh1 = Pv[1] & Xh1;
     u64 ph, mh;
     asm("v_lshlrev_b64 %0, 1, %1" : "=v"(ph) : "v"(((u64)Ph1 << 32) | Ph0));
     asm("v_lshlrev_b64 %0, 1, %1" : "=v"(mh) : "v"(((u64)Mh1 << 32) | Mh0));
-    const u32 Xv0 = Eq[0] | Mv[0], Xv1 = Eq[1] | Mv[1];
+    const u32 Xv0 = eq0 | Mv[0], Xv1 = eq1 | Mv[1];
     Pv[0] = BITOP3_OR_NOR((u32)mh, Xv0, (u32)ph);  Pv[1] = BITOP3_OR_NOR((u32)(mh >> 32), Xv1, (u32)(ph >> 32));
     Mv[0] = (u32)ph & Xv0;                          Mv[1] = (u32)(ph >> 32) & Xv1;
 }
+
+template <int NWD>
+__device__ __forceinline__ void column_step_eq1(const u32 eq0, u32 (&Pv)[NWD], u32 (&Mv)[NWD])
+{
+    const u32 s = (eq0 & Pv[0]) + Pv[0];                       // carry out of the band's top word is not needed
+    const u32 Xh = BITOP3_XOR_OR(s, eq0, Pv[0]);
+    const u32 Ph = BITOP3_OR_NOR(Mv[0], Xh, Pv[0]);
+    const u32 Mh = Pv[0] & Xh;
+    u32 ph, mh;
+    asm("v_add_u32 %0, %1, %1" : "=v"(ph) : "v"(Ph));
+    asm("v_add_u32 %0, %1, %1" : "=v"(mh) : "v"(Mh));
+    const u32 Xv = eq0 | Mv[0];
+    Pv[0] = BITOP3_OR_NOR(mh, Xv, ph);
+    Mv[0] = ph & Xv;
+}
+
+template <int NWD>
+__device__ __forceinline__ void column_step_hw2(const u32 (&Eq)[NWD], u32 (&Pv)[NWD], u32 (&Mv)[NWD])
+{
+    column_step_eq2<NWD>(Eq[0], Eq[1], Pv, Mv);
+}
+
+// Peq rows of the first two words staged in LDS, [wave][symbol][word][lane]: with one or two active
+// words the branchy dispatch would be scalar-issue bound (~12 SALU + 3 taken branches per 17 VALU);
+// here the row is picked by M0 and fetched with ds_read_addtid_b32 (address = M0 + offset + 4*lane: no
+// address VGPR, no VALU), one column ahead of its use.  hipcc does not count asm loads, so the wait is
+// explicit and names the destinations (cdna_hip_programming.md §5.7).
+#define EDLIB_AMD_LDS_LOAD2(sym, N0, N1)                                                                \
+    { const u32 m0v_ = ldsBase + ((sym) << 9);                                                           \
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:256" \
+                   : "=v"(N0), "=v"(N1) : "s"(m0v_) : "memory"); }
+#define EDLIB_AMD_LDS_WAIT2(N0, N1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(N0), "+v"(N1))
 
 template <int NA, int NWD>
 __device__ __forceinline__ void column_step_hw(const u32 (&Eq)[NWD], u32 (&Pv)[NWD], u32 (&Mv)[NWD],
@@ -429,8 +461,24 @@ template <int NA, int NWD>
 __device__ __forceinline__ int band_dword(const u32 tw, const int colBase, const int colEnd, const bool track,
                                           const u32 (&E0)[NWD], const u32 (&E1)[NWD], const u32 (&E2)[NWD],
                                           const u32 (&E3)[NWD], u32 (&Pv)[NWD], u32 (&Mv)[NWD],
-                                          int& e, int& flag, HwTrack& tr, const u32 sh, const int lastRows)
+                                          int& e, int& flag, HwTrack& tr, const u32 sh, const int lastRows,
+                                          const u32 ldsBase)
 {
+  if (NA <= 2 && NWD > 2) {
+    // narrow band: straight-line code, Peq rows from LDS one column ahead (nothing is tracked: the
+    // bottom row is outside the band)
+    // (a two-column-deep prefetch with lgkmcnt(2) measured 2 % slower: with 7 waves per SIMD the LDS
+    // latency is already covered)
+    u32 n0, n1;
+    EDLIB_AMD_LDS_LOAD2(tw & 3u, n0, n1)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        EDLIB_AMD_LDS_WAIT2(n0, n1);
+        const u32 e0 = n0, e1 = n1;
+        if (j < 15) { EDLIB_AMD_LDS_LOAD2((tw >> (2 * (j + 1))) & 3u, n0, n1) }
+        if (NA == 2) column_step_eq2<NWD>(e0, e1, Pv, Mv); else column_step_eq1<NWD>(e0, Pv, Mv);
+    }
+  } else {
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) {
         int eh[4];
@@ -459,6 +507,7 @@ __device__ __forceinline__ int band_dword(const u32 tw, const int colBase, const
             }
         }
     }
+  }
     // ---- band checkpoint: scores of the bottom rows of the last two active words (computed values:
     // exact when <= k, otherwise upper bounds that still exceed k, which is all the rules below use)
     int Sprev = 0;
@@ -512,6 +561,20 @@ scan_reads_banded_kernel(const ReadScanArgs a)
             Mv[d] = 0u;
         }
     }
+    // first two words of the four Peq rows -> LDS (narrow-band path)
+    __shared__ u32 s_eq[4][4][2][64];
+    const int wv = threadIdx.x >> 6;
+    {
+        const u32* e[4] = {E0, E1, E2, E3};
+#pragma unroll
+        for (int sy = 0; sy < 4; ++sy) {
+            s_eq[wv][sy][0][lane] = e[sy][0];
+            s_eq[wv][sy][1][lane] = (NWD > 1) ? e[sy][NWD > 1 ? 1 : 0] : 0u;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    const u32 ldsBase = __builtin_amdgcn_readfirstlane(
+        (u32)(size_t)(__attribute__((address_space(3))) u32*)&s_eq[wv][0][0][0]);
     const long long item = (long long)idx * a.numSegments + seg;
     HwTrack tr;
     {
@@ -537,7 +600,7 @@ scan_reads_banded_kernel(const ReadScanArgs a)
         const bool track = w >= wmain;                                // warm-up columns record nothing
         bandWork += (unsigned int)nw;
         switch (nw) {
-#define CASE(NA) case NA: if (NA <= NWD) nw = band_dword<(NA <= NWD ? NA : NWD), NWD>(tw, w * 16, c1, track, E0, E1, E2, E3, Pv, Mv, e, flag, tr, sh, lastRows); break;
+#define CASE(NA) case NA: if (NA <= NWD) nw = band_dword<(NA <= NWD ? NA : NWD), NWD>(tw, w * 16, c1, track, E0, E1, E2, E3, Pv, Mv, e, flag, tr, sh, lastRows, ldsBase); break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
         }
