@@ -94,28 +94,47 @@ hipError_t launch_build_peq_pairs(const PairDesc* descs, int numUnits, const uin
 
 // ------------------------------------------------------------------- the scan
 
-// reference calculateBlock (edlib.cpp:412-447) on one 64-row block.  ph/mh return
-// the un-shifted horizontal delta vectors (bit r = row r of the block).
-__device__ __forceinline__ int advance_block64(u64& Pv, u64& Mv, u64 Eq, const int hin,
-                                               u64& phOut, u64& mhOut)
+// v_bitop3_b32 truth tables: bit i of the immediate is f(a,b,c) with i = a*4 + b*2 + c
+#define BITOP3_XOR_OR(a, b, c)   __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xde)   /* (a ^ c) | b   */
+#define BITOP3_OR_NOR(a, b, c)   __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xf1)   /* a | ~(b | c)  */
+
+// reference calculateBlock (edlib.cpp:412-447) on one 64-row block held as two 32-bit halves.
+// hpos / hneg are the two bits of hin (+1 / -1).  The booleans are written per half so that each
+// 3-input function is one v_bitop3_b32; the add and the two shifts use the 64-bit pair
+// (v_lshl_add_u64 / v_lshlrev_b64: 4 cycles per 64 bits, tools/valu_ubench.hip).  ph/mh return the
+// un-shifted horizontal delta vectors (bit r = row r of the block).
+struct Block64 { u32 p0, p1, m0, m1; };
+__device__ __forceinline__ void advance_block64(Block64& B, const u32 e0, const u32 e1,
+                                                const u32 hpos, const u32 hneg,
+                                                u32& ph0, u32& ph1, u32& mh0, u32& mh1)
 {
-    const u64 hneg = (u64)(hin < 0), hpos = (u64)(hin > 0);
-    const u64 Xv = Eq | Mv;
-    Eq |= hneg;
-    const u64 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-    u64 Ph = Mv | ~(Xh | Pv);
-    u64 Mh = Pv & Xh;
-    phOut = Ph; mhOut = Mh;
-    const int hout = (int)(Ph >> 63) - (int)(Mh >> 63);
-    Ph = (Ph << 1) | hpos;
-    Mh = (Mh << 1) | hneg;
-    Pv = Mh | ~(Xv | Ph);
-    Mv = Ph & Xv;
-    return hout;
+    const u32 xv0 = e0 | B.m0, xv1 = e1 | B.m1;                 // Xv = Eq | Mv        (:421)
+    const u32 q0 = e0 | hneg;                                   // Eq |= hinIsNeg      (:423)
+    const u32 t0 = q0 & B.p0, t1 = e1 & B.p1;
+    u64 s;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(s) : "v"(((u64)t1 << 32) | t0), "v"(((u64)B.p1 << 32) | B.p0));
+    const u32 xh0 = BITOP3_XOR_OR((u32)s, q0, B.p0), xh1 = BITOP3_XOR_OR((u32)(s >> 32), e1, B.p1);   // (:424)
+    ph0 = BITOP3_OR_NOR(B.m0, xh0, B.p0); ph1 = BITOP3_OR_NOR(B.m1, xh1, B.p1);                        // (:426)
+    mh0 = B.p0 & xh0; mh1 = B.p1 & xh1;                                                                // (:427)
+    u64 phs, mhs;
+    asm("v_lshlrev_b64 %0, 1, %1" : "=v"(phs) : "v"(((u64)ph1 << 32) | ph0));
+    asm("v_lshlrev_b64 %0, 1, %1" : "=v"(mhs) : "v"(((u64)mh1 << 32) | mh0));
+    const u32 a0 = (u32)phs | hpos, b0 = (u32)mhs | hneg;       // (:435-441)
+    B.p0 = BITOP3_OR_NOR(b0, xv0, a0);
+    B.p1 = BITOP3_OR_NOR((u32)(mhs >> 32), xv1, (u32)(phs >> 32));
+    B.m0 = a0 & xv0;
+    B.m1 = (u32)(phs >> 32) & xv1;
 }
 
 // MODE 0 NW, 1 SHW, 2 HW.  STORE: keep the column store.  LDSPEQ: Peq slice in LDS
 // (sigmaT <= 32), else gathered from the HBM pool.
+//
+// Pipeline of one strip.  At step t lane l updates column t-l.  The packed word that travels one
+// lane down per step (one v_mov_b32_dpp wave_shr:1) carries {hout of the sender's column, the
+// sender's NEXT symbol}: the symbol stream runs one step ahead of the DP, so every lane knows the
+// symbol of its next column one step early and fetches that Peq word (LDS or HBM) while it computes
+// the current column.  Lane 0 is fed {row -1 delta of column t, target[t+1]} through the DPP `old`
+// operand.  The loop starts at t = -1 (symbols only).
 template <int MODE, bool STORE, bool LDSPEQ>
 __global__ void __launch_bounds__(64)
 scan_pairs_kernel(const PairScanArgs a)
@@ -128,11 +147,12 @@ scan_pairs_kernel(const PairScanArgs a)
     const int nb = num_blocks(m);
     const int nstrips = (nb + 63) >> 6;
     const u32 sh = (u32)(m - 1) & 63u;                               // row m-1 inside the last block
-    const int topCode = (MODE == 2) ? 1 : 2;                         // hin+1 at row -1: HW 0, SHW/NW +1
+    const int topCode = (MODE == 2) ? 0 : 1;                         // {hneg,hpos} bits at row -1: HW 0, SHW/NW +1
 
     int sc = m;                                                      // D[m][-1] (edlib.cpp:575-579)
     int best = d.kinit, cnt = 0, lastCol = -1;
     int* pos = a.posPool + d.posOff;
+    const bool dumpCol = a.colP != nullptr && d.colOff >= 0;
 
     for (int strip = 0; strip < nstrips; ++strip) {
         const int nbS = (nb - strip * 64) < 64 ? (nb - strip * 64) : 64;
@@ -143,57 +163,70 @@ scan_pairs_kernel(const PairScanArgs a)
 
         if (LDSPEQ) {
             __syncthreads();                                         // previous strip done with s_peq
-            for (int s = 0; s < a.sigmaT; ++s)
-                s_peq[s * 64 + lane] = laneOn ? a.peq[d.peqOff + (long long)s * nb + b] : 0ull;
+            for (int sy = 0; sy < a.sigmaT; ++sy)
+                s_peq[sy * 64 + lane] = laneOn ? a.peq[d.peqOff + (long long)sy * nb + b] : 0ull;
             __syncthreads();
         }
-        u64 Pv = ~0ull, Mv = 0ull;                                   // column -1
+        Block64 B{~0u, ~0u, 0u, 0u};                                 // column -1
         int bscore = (b + 1) * 64;                                   // block bottom score (edlib.cpp:576)
         int carry = 0;
         int tchunk = 0, hchunk = topCode;
         const long long sbase = STORE ? d.storeOff + strip_base(strip, T) : 0;
         const int nsteps = T + nbS - 1;
+        const unsigned long long* peqRow = a.peq + d.peqOff + b;     // HBM Peq of this lane's block
 
-        for (int t = 0; t < nsteps; ++t) {
-            if ((t & 63) == 0) {                                     // refill 64 columns of input
-                const int c = t + lane;
+        auto step = [&](const int t, const u64 eqCur, u64& eqNxt) {
+            const int tc = t + 1;                                    // column injected at lane 0 now
+            if ((tc & 63) == 0) {                                    // refill 64 columns of symbols
+                const int c = tc + lane;
                 tchunk = (c < T) ? a.tlut[a.tpool[d.toff + (long long)c * d.tstep]] : 0;
-                if (strip > 0)
-                    hchunk = (c < T) ? __hip_atomic_load(&a.aux[d.auxOff + c], __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT) : 1;
             }
-            // lane 0 <- {next target symbol, row -1 delta}; lane l <- lane l-1's {symbol, hout}
-            const int in0 = __builtin_amdgcn_readlane(tchunk, t & 63)
-                          | (__builtin_amdgcn_readlane(hchunk, t & 63) << 8);
+            if (strip > 0 && t >= 0 && (t & 63) == 0) {              // and of the previous strip's bottom deltas
+                const int c = t + lane;
+                hchunk = (c < T) ? __hip_atomic_load(&a.aux[d.auxOff + c], __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT) : 0;
+            }
+            const int in0 = (__builtin_amdgcn_readlane(tchunk, tc & 63) << 2)
+                          | __builtin_amdgcn_readlane(hchunk, t & 63);
             const int x = __builtin_amdgcn_update_dpp(in0, carry, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+            const u32 symN = (u32)x >> 2;
+            eqNxt = LDSPEQ ? s_peq[symN * 64 + lane] : peqRow[(long long)symN * nb];
             const int col = t - lane;
+            u32 hp = 0, hn = 0;
             if (laneOn && col >= 0 && col < T) {
-                const int sym = x & 0xff;
-                const int hin = ((x >> 8) & 3) - 1;
-                const u64 eq = LDSPEQ ? s_peq[sym * 64 + lane]
-                                      : a.peq[d.peqOff + (long long)sym * nb + b];
-                u64 ph, mh;
-                const int hout = advance_block64(Pv, Mv, eq, hin, ph, mh);
-                bscore += hout;
-                carry = sym | ((hout + 1) << 8);
+                u32 ph0, ph1, mh0, mh1;
+                advance_block64(B, (u32)eqCur, (u32)(eqCur >> 32), (u32)x & 1u, ((u32)x >> 1) & 1u, ph0, ph1, mh0, mh1);
+                hp = ph1 >> 31; hn = mh1 >> 31;
+                bscore += (int)hp - (int)hn;
                 if (STORE) {
                     const long long si = sbase + (long long)t * nbS + lane;
-                    a.storeP[si] = Pv; a.storeM[si] = Mv; a.storeS[si] = bscore;
+                    a.storeP[si] = ((u64)B.p1 << 32) | B.p0; a.storeM[si] = ((u64)B.m1 << 32) | B.m0; a.storeS[si] = bscore;
                 }
-                if (!lastStrip && lane == 63) a.aux[d.auxOff + col] = hout + 1;
-                if (a.colP && d.colOff >= 0 && col == T - 1) {              // last column (Hirschberg)
-                    a.colP[d.colOff + b] = Pv; a.colM[d.colOff + b] = Mv; a.colS[d.colOff + b] = bscore;
-                }
-                if (tracker) {
-                    sc += (int)((ph >> sh) & 1ull) - (int)((mh >> sh) & 1ull);
-                    if (MODE != 0 && sc <= best) {                   // edlib.cpp:658-673
-                        if (sc < best) { best = sc; cnt = 0; }
-                        if (cnt < d.posCap) pos[cnt] = col;
-                        ++cnt;
-                        lastCol = col;
+                if (!lastStrip) {
+                    if (lane == 63) a.aux[d.auxOff + col] = (int)(hp | (hn << 1));
+                } else {
+                    if (tracker) {
+                        const u64 ph = ((u64)ph1 << 32) | ph0, mh = ((u64)mh1 << 32) | mh0;
+                        sc += (int)((ph >> sh) & 1ull) - (int)((mh >> sh) & 1ull);
+                        if (MODE != 0 && sc <= best) {                   // edlib.cpp:658-673
+                            if (sc < best) { best = sc; cnt = 0; }
+                            if (cnt < d.posCap) pos[cnt] = col;
+                            ++cnt;
+                            lastCol = col;
+                        }
                     }
                 }
+                if (dumpCol && col == T - 1) {                           // last column (Hirschberg)
+                    a.colP[d.colOff + b] = ((u64)B.p1 << 32) | B.p0; a.colM[d.colOff + b] = ((u64)B.m1 << 32) | B.m0;
+                    a.colS[d.colOff + b] = bscore;
+                }
             }
+            carry = (int)((symN << 2) | hp | (hn << 1));             // every lane forwards the symbol stream
+        };
+        u64 eqA = 0, eqB = 0;
+        for (int t = -1; t < nsteps; t += 2) {                       // two steps per trip: Peq registers ping-pong
+            step(t, eqA, eqB);
+            if (t + 1 < nsteps) step(t + 1, eqB, eqA);
         }
         if (tracker) {
             a.outScore[unit] = (MODE == 0) ? sc : (cnt > 0 ? best : -1);
