@@ -296,7 +296,6 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
     if (!groups_.empty()) {
         EDLIB_AMD_HIP(d_tpk_.alloc((size_t)(T + 15) / 16 + 4));
         EDLIB_AMD_HIP(hipMemset(d_tpk_.p, 0, d_tpk_.bytes()));       // the banded kernel reads whole dwords
-        EDLIB_AMD_HIP(d_trash_.alloc(64));
         EDLIB_AMD_HIP(d_wordSteps_.alloc(1));
     }
     {
@@ -366,7 +365,7 @@ int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, i
     a.numSegments = numSegments; a.segLen = segLen; a.warm = warm;
     a.segBest = segBest; a.segCnt = segCnt; a.segPos = segPos; a.cap = cap;
     a.posOff = posOff; a.posCap = posCap;
-    a.kcap = kcap; a.trash = d_trash_.p; a.wordSteps = d_wordSteps_.p;
+    a.kcap = kcap; a.wordSteps = d_wordSteps_.p;
     scanTimerStart();
     if (banded_ && mode == EDLIB_MODE_HW) EDLIB_AMD_HIP(launch_scan_reads_banded(g.nwords, a, stream_));
     else {
@@ -410,7 +409,34 @@ int Batch::runReads()
                                              d_eqtbl4_.p, d_presence_.p, cfg_.k, g.d_peq.p, g.d_qlen.p,
                                              g.d_kinit.p, g.d_alphaExtra.p, stream_));
         // ---- pass 1: all slots; banded: threshold min(k, kFirst)
-        const bool twoPass = banded && (cfg_.k < 0 || cfg_.k > kFirst) && 32 * g.nwords > kFirst;
+        bool twoPass = banded && (cfg_.k < 0 || cfg_.k > kFirst) && 32 * g.nwords > kFirst;
+        if (twoPass && g.nslots >= 16384) {
+            // k-doubling only pays when most units resolve at the small threshold (pass 1 costs ~2/NWD of a
+            // full scan, unresolved units then pay the full scan on top).  Probe 2048 evenly strided slots
+            // first (0.2 % of the work at 1M reads) and fall back to one full-threshold pass if fewer than
+            // 30 % of them resolve (e.g. noisy long-read chemistry, unrelated sequences).
+            const int np = 2048;
+            std::vector<int> probe(np);
+            for (int i = 0; i < np; ++i) probe[i] = (int)((long long)i * g.nslots / np);
+            int S2, segLen2, warm2;
+            plan_segments(np, T, mode, g.warm, 16384, S2, segLen2, warm2);
+            const size_t items = (size_t)np * S2;
+            DevBuf<int> d_map, d_sb, d_sc, d_sp;
+            EDLIB_AMD_HIP(d_map.alloc(np)); EDLIB_AMD_HIP(d_sb.alloc(items)); EDLIB_AMD_HIP(d_sc.alloc(items));
+            EDLIB_AMD_HIP(hipMemcpyAsync(d_map.p, probe.data(), np * sizeof(int), hipMemcpyHostToDevice, stream_));
+            if (scanGroup(g, mode, d_map.p, np, kFirst, g.d_kinit.p, S2, segLen2, warm2,
+                          d_sb.p, d_sc.p, d_sb.p /*unused*/, 0, nullptr, nullptr)) return 1;
+            std::vector<int> cnts(items);
+            EDLIB_AMD_HIP(hipMemcpyAsync(cnts.data(), d_sc.p, items * sizeof(int), hipMemcpyDeviceToHost, stream_));
+            EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+            int resolved = 0, real = 0;
+            for (int i = 0; i < np; ++i) {
+                if (g.perm[probe[i]] < 0) continue;
+                ++real;
+                for (int sg = 0; sg < S2; ++sg) if (cnts[(size_t)i * S2 + sg] > 0) { ++resolved; break; }
+            }
+            if (real > 0 && resolved * 10 < real * 3) twoPass = false;
+        }
         if (scanGroup(g, mode, nullptr, g.nslots, twoPass ? kFirst : kNoCap, g.d_kinit.p, g.numSegments, g.segLen,
                       g.warm, g.d_segBest.p, g.d_segCnt.p, g.d_segPos.p, 8, nullptr, nullptr)) return 1;
         EDLIB_AMD_HIP(launch_merge_segments(g.d_segBest.p, g.d_segCnt.p, g.d_segPos.p, g.numSegments, 8,

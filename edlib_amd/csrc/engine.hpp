@@ -93,7 +93,6 @@ private:
     };
     std::vector<std::unique_ptr<ReadGroup>> groups_;
     DevBuf<uint32_t> d_tpk_;
-    DevBuf<int> d_trash_;
     DevBuf<unsigned long long> d_wordSteps_;
     bool banded_ = false;        // HW groups use the Ukkonen-banded kernel with k-doubling
     int runReads();                                   // device work only; results stay in HBM

@@ -453,7 +453,6 @@ __device__ __forceinline__ void column_step_hw(const u32 (&Eq)[NWD], u32 (&Pv)[N
 struct HwTrack {            // per-lane tracking state of the banded kernel
     int best, cnt, cap;
     int* pos;
-    int* trash;
 };
 
 // 16 columns (one packed dword) with NA active words, then the band checkpoint.  Returns the new nw.
@@ -584,7 +583,6 @@ scan_reads_banded_kernel(const ReadScanArgs a)
     tr.cnt = 0;
     tr.cap = live ? (a.posCap ? a.posCap[item] : a.cap) : 0;
     tr.pos = a.segPos + (a.posOff ? a.posOff[item] : item * a.cap);
-    tr.trash = a.trash;
     int e = m - tr.best - 1;                                          // score at column -1 is m
     int flag = 0;
 

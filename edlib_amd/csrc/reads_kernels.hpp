@@ -28,7 +28,6 @@ struct ReadScanArgs {
     const long long* posOff;  // optional [lanes][numSegments] offset into segPos (exact pass)
     const int* posCap;        // optional [lanes][numSegments] capacity (exact pass)
     int kcap;                 // banded HW kernel: effective threshold = min(kinit[slot], kcap)
-    int* trash;               // banded HW kernel: one int that absorbs the stores of non-hit lanes
     unsigned long long* wordSteps;   // banded HW kernel: += 32-row word-columns actually computed (may be null)
 };
 

@@ -1,0 +1,86 @@
+"""-m gpu: shapes the fixtures do not reach -- concurrent callers, mixed query lengths in one batch
+(every word-count group of the reads kernel + the pair-kernel fallback + empty queries), noisy
+batches that make the k-doubling probe fall back to a single full pass, wider alphabets."""
+import threading
+
+import numpy as np
+import pytest
+
+from edlib_amd import synth
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("status", "editDistance", "endLocations", "startLocations", "numLocations",
+          "alignment", "alignmentLength", "alphabetLength")
+
+
+def same(got, want):
+    return all(got[f] == want[f] for f in FIELDS)
+
+
+def test_concurrent_callers(engine, oracle):
+    """edlibAlign is re-entrant in the reference (bindings/python/edlib.pyx:128 calls it nogil)."""
+    target = synth.random_dna(41, 6000).tobytes()
+    reads = synth.illumina_reads(np.frombuffer(target, dtype=np.uint8), 64, m=120, seed=42)["reads"]
+    want = [oracle.align(r.tobytes(), target, "HW", "path", -1) for r in reads]
+    bad = []
+
+    def work(tid):
+        for i in range(tid, len(reads), 8):
+            got = engine.align_raw(reads[i].tobytes(), target, "HW", "path", -1)
+            if not same(got, want[i]):
+                bad.append(i)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("mode,task", [("HW", "distance"), ("HW", "path"), ("SHW", "locations"), ("NW", "distance")])
+def test_mixed_lengths_in_one_batch(engine, oracle, mode, task):
+    target = synth.random_dna(43, 3000)
+    qs = [b""]
+    for i, m in enumerate([1, 2, 31, 32, 33, 63, 64, 65, 96, 97, 128, 150, 160, 161, 200, 255, 256, 257, 300, 420]):
+        a = (i * 131) % (len(target) - m)
+        q, _ = synth.mutate(target[a:a + m], 44 + i, 0.04, 0.01, 0.01)
+        qs.append(q.tobytes() or b"A")
+    got = engine.align_batch(qs, target.tobytes(), mode=mode, task=task, raw=True)
+    for q, g in zip(qs, got):
+        want = oracle.align(q, target.tobytes(), mode, task, -1)
+        assert same(g, want), (mode, task, len(q), g, want)
+
+
+def test_noisy_batch_takes_the_full_threshold_pass(engine, oracle):
+    """>= 16384 reads with ~12 % errors: almost nothing resolves at the first threshold of the
+    k-doubling, so the probe must switch to one full pass -- same answers either way."""
+    target = synth.random_dna(45, 120000)
+    r = synth.illumina_reads(target, 16500, m=100, seed=46, sub=0.08, ins=0.02, dele=0.02, frac_random=0.2)
+    got = engine.align_batch(r["reads"], target.tobytes(), mode="HW", task="distance", raw=True)
+    tb = target.tobytes()
+    for i in range(0, len(got), 97):
+        want = oracle.align(r["reads"][i].tobytes(), tb, "HW", "distance", -1)
+        assert same(got[i], want), i
+
+
+def test_fixed_k_shared_batch(engine, oracle):
+    target = synth.random_dna(47, 40000)
+    r = synth.illumina_reads(target, 300, m=150, seed=48)
+    for k in (0, 2, 7, 8, 9, 40, 200):
+        got = engine.align_batch(r["reads"], target.tobytes(), mode="HW", task="locations", k=k, raw=True)
+        for i in range(0, 300, 7):
+            want = oracle.align(r["reads"][i].tobytes(), target.tobytes(), "HW", "locations", k)
+            assert same(got[i], want), (k, i)
+
+
+def test_wider_alphabets_go_through_the_pair_kernel(engine, oracle):
+    for sigma in (5, 20, 33, 90):
+        t = synth.random_symbols(50 + sigma, 2500, sigma, base=33)
+        qs = []
+        for i in range(12):
+            a = 100 * i
+            q = t[a:a + 180].copy()
+            q[::17] = 33 + (q[::17] - 33 + 1) % sigma
+            qs.append(q.tobytes())
+        got = engine.align_batch(qs, t.tobytes(), mode="HW", task="path", raw=True)
+        for q, g in zip(qs, got):
+            assert same(g, oracle.align(q, t.tobytes(), "HW", "path", -1)), sigma
