@@ -295,7 +295,8 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
     }
     if (!groups_.empty()) {
         EDLIB_AMD_HIP(d_tpk_.alloc((size_t)(T + 15) / 16 + 4));
-        EDLIB_AMD_HIP(hipMemset(d_tpk_.p, 0, d_tpk_.bytes()));       // the banded kernel reads whole dwords
+        // the banded kernel reads whole dwords; on OUR stream: the null stream does not order with it
+        EDLIB_AMD_HIP(hipMemsetAsync(d_tpk_.p, 0, d_tpk_.bytes(), stream_));
         EDLIB_AMD_HIP(d_wordSteps_.alloc(1));
     }
     {
