@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a dry run)")
+    ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses device 0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,10 +102,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    if args.share_gpu:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     import edlib_amd
     from edlib_amd import synth
 
@@ -132,7 +139,8 @@ def main():
     dt = time.perf_counter() - t0
     from edlib_amd.parallel import aggregate_throughput
     # whole-job cells (SUM over ranks) and the slowest rank's time (MAX over ranks)
-    cells_all, dt = aggregate_throughput(st["cells"] * args.steps, dt, dist, "cuda" if dist is not None else None)
+    cells_all, dt = aggregate_throughput(st["cells"] * args.steps, dt, dist,
+                                         ("cuda" if args.backend == "nccl" else "cpu") if dist is not None else None)
     value = cells_all / dt / 1e9
     out = None
     if rank == 0:

@@ -387,12 +387,6 @@ __device__ __forceinline__ void column_step_eq1(const u32 eq0, u32 (&Pv)[NWD], u
     Mv[0] = ph & Xv;
 }
 
-template <int NWD>
-__device__ __forceinline__ void column_step_hw2(const u32 (&Eq)[NWD], u32 (&Pv)[NWD], u32 (&Mv)[NWD])
-{
-    column_step_eq2<NWD>(Eq[0], Eq[1], Pv, Mv);
-}
-
 // Peq rows of the first two words staged in LDS, [wave][symbol][word][lane]: with one or two active
 // words the branchy dispatch would be scalar-issue bound (~12 SALU + 3 taken branches per 17 VALU);
 // here the row is picked by M0 and fetched with ds_read_addtid_b32 (address = M0 + offset + 4*lane: no
@@ -408,7 +402,6 @@ template <int NA, int NWD>
 __device__ __forceinline__ void column_step_hw(const u32 (&Eq)[NWD], u32 (&Pv)[NWD], u32 (&Mv)[NWD],
                                                int& e, int& flag, const u32 sh)
 {
-    if (NA == 2 && NWD > 2) { column_step_hw2<NWD>(Eq, Pv, Mv); return; }
     u32 Ph[NA], Mh[NA];
     u32 carry = 0;
 #pragma unroll
