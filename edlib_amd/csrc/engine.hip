@@ -50,10 +50,15 @@ int size_class(size_t bytes, size_t* rounded) {
 }
 }  // namespace
 
+static bool pool_enabled() {
+    static const bool on = !(getenv("EDLIB_AMD_NOPOOL") && getenv("EDLIB_AMD_NOPOOL")[0] == '1');
+    return on;
+}
+
 hipError_t pool_alloc(void** p, size_t bytes, size_t* granted) {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (bytes <= kPoolMaxBlock && dev < Pool::kMaxDev) {
+    if (pool_enabled() && bytes <= kPoolMaxBlock && dev < Pool::kMaxDev) {
         size_t r; const int c = size_class(bytes, &r);
         {
             std::lock_guard<std::mutex> g(pool().mu);
@@ -72,7 +77,7 @@ void pool_free(void* p, size_t granted) {
     (void)hipGetDevice(&dev);
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device; else (void)hipGetLastError();
-    if (granted <= kPoolMaxBlock && dev < Pool::kMaxDev && (granted & (granted - 1)) == 0) {
+    if (pool_enabled() && granted <= kPoolMaxBlock && dev < Pool::kMaxDev && (granted & (granted - 1)) == 0) {
         size_t r; const int c = size_class(granted, &r);
         std::lock_guard<std::mutex> g(pool().mu);
         if (pool().cachedBytes + r <= kPoolMaxCached) { pool().blocks[dev][c].push_back(p); pool().cachedBytes += r; return; }
@@ -367,6 +372,12 @@ int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, i
     a.segBest = segBest; a.segCnt = segCnt; a.segPos = segPos; a.cap = cap;
     a.posOff = posOff; a.posCap = posCap;
     a.kcap = kcap; a.wordSteps = d_wordSteps_.p;
+    static const bool dbg = getenv("EDLIB_AMD_DEBUG") != nullptr;
+    if (dbg) {
+        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+        fprintf(stderr, "[edlib_amd] scanGroup nwords=%d mode=%d nlanes=%d S=%d segLen=%d warm=%d cap=%d kcap=%d slotmap=%p posOff=%p\n",
+                g.nwords, mode, nlanes, numSegments, segLen, warm, cap, kcap, (const void*)d_slotmap, (const void*)posOff);
+    }
     scanTimerStart();
     if (banded_ && mode == EDLIB_MODE_HW) EDLIB_AMD_HIP(launch_scan_reads_banded(g.nwords, a, stream_));
     else {
@@ -375,6 +386,10 @@ int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, i
                             ((long long)a.targetLength + (long long)(numSegments - 1) * warm);
     }
     scanTimerStop();
+    if (dbg) {
+        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+        fprintf(stderr, "[edlib_amd] scanGroup done\n");
+    }
     return 0;
 }
 

@@ -253,9 +253,9 @@ scan_reads_kernel(const ReadScanArgs a)
     int best = a.kinit[slot];
     int cnt = 0;
     const long long item = (long long)idx * a.numSegments + seg;   // (lane, segment) record
-    int cap = a.posCap ? a.posCap[item] : a.cap;
-    int* pos = a.segPos + (a.posOff ? a.posOff[item] : item * a.cap);
-    if (!live) cap = 0;
+    // lanes past nlanes (the tail of the last wave) own no record: they must not even read the tables
+    const int cap = !live ? 0 : (a.posCap ? a.posCap[item] : a.cap);
+    int* pos = a.segPos + (!live ? 0 : (a.posOff ? a.posOff[item] : item * a.cap));
 
     const int T = a.targetLength;
     const int c0 = seg * a.segLen;                                 // multiple of 16
@@ -574,8 +574,9 @@ scan_reads_banded_kernel(const ReadScanArgs a)
         tr.best = k0 < a.kcap ? k0 : a.kcap;
     }
     tr.cnt = 0;
+    // lanes past nlanes (the tail of the last wave) own no record: they must not even read the tables
     tr.cap = live ? (a.posCap ? a.posCap[item] : a.cap) : 0;
-    tr.pos = a.segPos + (a.posOff ? a.posOff[item] : item * a.cap);
+    tr.pos = a.segPos + (!live ? 0 : (a.posOff ? a.posOff[item] : item * a.cap));
     int e = m - tr.best - 1;                                          // score at column -1 is m
     int flag = 0;
 

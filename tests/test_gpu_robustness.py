@@ -84,3 +84,23 @@ def test_wider_alphabets_go_through_the_pair_kernel(engine, oracle):
         got = engine.align_batch(qs, t.tobytes(), mode="HW", task="path", raw=True)
         for q, g in zip(qs, got):
             assert same(g, oracle.align(q, t.tobytes(), "HW", "path", -1)), sigma
+
+
+def test_exact_pass_at_full_target_length(engine, ref, oracle):
+    """4096 reads vs the 5 Mb target: a handful of reads have more end locations than the first pass
+    keeps; their lists come from the exact pass, whose launch has a ragged last wave (this once read its
+    offset tables out of bounds).  Every overflowing read and a sample of the rest must match."""
+    impl = ref or oracle
+    target = synth.random_dna(12345, 5_000_000)
+    r = synth.illumina_reads(target, 4096, m=150, seed=77)
+    b = engine.SharedBatch(r["reads"], target, mode="HW", task="distance")
+    st = b.run()
+    got = b.results(raw=True)
+    b.close()
+    assert st["overflow_units"] > 0
+    many = [i for i, g in enumerate(got) if g["numLocations"] > 16]
+    assert len(many) == st["overflow_units"]
+    tb = target.tobytes()
+    for i in many + list(range(0, 4096, 512)):
+        want = impl.align(r["reads"][i].tobytes(), tb, "HW", "distance", -1)
+        assert same(got[i], want), i
