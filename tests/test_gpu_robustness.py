@@ -98,8 +98,9 @@ def test_exact_pass_at_full_target_length(engine, ref, oracle):
     got = b.results(raw=True)
     b.close()
     assert st["overflow_units"] > 0
-    many = [i for i, g in enumerate(got) if g["numLocations"] > 16]
-    assert len(many) == st["overflow_units"]
+    # a unit overflows when one target segment holds > 8 of its end locations or the whole list > 16
+    many = [i for i, g in enumerate(got) if g["numLocations"] > 8]
+    assert len(many) >= st["overflow_units"] >= sum(1 for g in got if g["numLocations"] > 16)
     tb = target.tobytes()
     for i in many + list(range(0, 4096, 512)):
         want = impl.align(r["reads"][i].tobytes(), tb, "HW", "distance", -1)
