@@ -190,7 +190,7 @@ scan_pairs_kernel(const PairScanArgs a)
                           | __builtin_amdgcn_readlane(hchunk, t & 63);
             const int x = __builtin_amdgcn_update_dpp(in0, carry, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
             const u32 symN = (u32)x >> 2;
-            eqNxt = LDSPEQ ? s_peq[symN * 64 + lane] : peqRow[(long long)symN * nb];
+            eqNxt = LDSPEQ ? s_peq[symN * 64 + lane] : (laneOn ? peqRow[(long long)symN * nb] : 0ull);
             const int col = t - lane;
             u32 hp = 0, hn = 0;
             if (laneOn && col >= 0 && col < T) {
