@@ -590,7 +590,8 @@ int Batch::collectReads(std::vector<UnitResult>& res)
 
 static const int kPosCap = 16;
 
-int Batch::solve(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units, SolveOut& out)
+int Batch::solve(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units, SolveOut& out,
+                 bool nwBand)
 {
     const size_t n = units.size();
     out.score.assign(n, -1); out.count.assign(n, 0); out.last.assign(n, -1);
@@ -611,14 +612,14 @@ int Batch::solve(int mode, bool wantPositions, bool wantPath, const std::vector<
             if (b > a && (peqBytes + pb > peqBudget || storeBytes + sb > storeBudget)) break;
             peqBytes += pb; storeBytes += sb; ++b;
         }
-        if (solveChunk(mode, wantPositions, wantPath, units, a, b, out)) return 1;
+        if (solveChunk(mode, wantPositions, wantPath, units, a, b, out, nwBand)) return 1;
         a = b;
     }
     return 0;
 }
 
 int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units,
-                      size_t ua, size_t ub, SolveOut& out)
+                      size_t ua, size_t ub, SolveOut& out, bool nwBand)
 {
     const size_t n = ub - ua;
     std::vector<PairDesc> descs(n);
@@ -637,7 +638,8 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         d.posOff = (long long)i * kPosCap;
         d.colOff = -1;
         opsOff[i + 1] = opsOff[i] + (wantPath ? (long long)s.qlen + s.tlen : 0);
-        stats.word_steps += 2 * nb * (long long)s.tlen;
+        // executed work: whole matrix, or one 64-block wave per column inside the band
+        stats.word_steps += nwBand ? 2LL * 64 * ((long long)s.tlen + nb - 1) : 2 * nb * (long long)s.tlen;
     }
     EDLIB_AMD_HIP(d_descs_.ensure(n));
     EDLIB_AMD_HIP(d_peq64_.ensure((size_t)peqWords));
@@ -661,7 +663,8 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p; a.posPool = d_posPool_.p;
     a.colP = nullptr; a.colM = nullptr; a.colS = nullptr;
     scanTimerStart();
-    EDLIB_AMD_HIP(launch_scan_pairs(mode, wantPath, a, stream_));
+    if (nwBand) EDLIB_AMD_HIP(launch_scan_pairs_nwband(a, stream_));
+    else EDLIB_AMD_HIP(launch_scan_pairs(mode, wantPath, a, stream_));
     scanTimerStop();
     if (wantPath) {
         TracebackArgs tb{};
@@ -921,12 +924,42 @@ int Batch::run()
                                 (cfg_.k < 0 || cfg_.k > m) ? m : cfg_.k};
         }
         SolveOut so;
-        if (solve(scanMode, true, false, units, so)) return 1;
-        for (size_t i = 0; i < units.size(); ++i) {
-            UnitResult& r = res[pairUnits_[i]];
-            if (scanMode == EDLIB_MODE_NW) finalize_global(r, cfg_.k, mode, units[i].tlen, so.score[i]);
-            else finalize_semiglobal(r, cfg_.k, units[i].qlen, so.score[i], so.posFlat.data() + so.posStart[i],
-                                     so.posStart[i + 1] - so.posStart[i]);
+        if (scanMode == EDLIB_MODE_NW) {
+            // Queries of more than 64 blocks: one banded pass (threshold min(k, kMaxBandK): the band fits one
+            // wave whatever the length, edlib.cpp:744-830), then the exact unbanded strips only for the units
+            // whose distance exceeds that threshold.  Shorter queries are a single strip anyway.
+            const bool bandOff = getenv("EDLIB_AMD_NWBAND") && getenv("EDLIB_AMD_NWBAND")[0] == '0';
+            std::vector<UnitSpec> banded, plain; std::vector<size_t> bi, pi;
+            for (size_t i = 0; i < units.size(); ++i) {
+                const bool longq = units[i].qlen > 64 * 64 && !bandOff;
+                if (longq) {
+                    UnitSpec u = units[i];
+                    u.kinit = (cfg_.k >= 0 && cfg_.k < kMaxBandK) ? cfg_.k : kMaxBandK;
+                    banded.push_back(u); bi.push_back(i);
+                } else { plain.push_back(units[i]); pi.push_back(i); }
+            }
+            std::vector<int> score(units.size(), -1);
+            if (!banded.empty()) {
+                SolveOut sb;
+                if (solve(EDLIB_MODE_NW, false, false, banded, sb, true)) return 1;
+                for (size_t j = 0; j < banded.size(); ++j) {
+                    if (sb.score[j] <= banded[j].kinit) score[bi[j]] = sb.score[j];           // exact
+                    else if (cfg_.k >= 0 && cfg_.k <= banded[j].kinit) score[bi[j]] = 0x3fffffff;   // > k: final
+                    else { plain.push_back(units[bi[j]]); pi.push_back(bi[j]); }              // needs the full scan
+                }
+            }
+            if (!plain.empty()) {
+                SolveOut sp;
+                if (solve(EDLIB_MODE_NW, false, false, plain, sp)) return 1;
+                for (size_t j = 0; j < plain.size(); ++j) score[pi[j]] = sp.score[j];
+            }
+            for (size_t i = 0; i < units.size(); ++i)
+                finalize_global(res[pairUnits_[i]], cfg_.k, mode, units[i].tlen, score[i]);
+        } else {
+            if (solve(scanMode, true, false, units, so)) return 1;
+            for (size_t i = 0; i < units.size(); ++i)
+                finalize_semiglobal(res[pairUnits_[i]], cfg_.k, units[i].qlen, so.score[i],
+                                    so.posFlat.data() + so.posStart[i], so.posStart[i + 1] - so.posStart[i]);
         }
     }
     {   // alphabetLength for everything the reads path did not cover

@@ -108,9 +108,11 @@ private:
     DevBuf<int> d_storeS_, d_aux_, d_outScore_, d_outCount_, d_outLast_, d_posPool_, d_opsLen_, d_alpha_;
     DevBuf<uint8_t> d_ops_;
     DevBuf<long long> d_opsOff_;
-    int solve(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units, SolveOut& out);
+    // nwBand: NW distance inside Ukkonen's band for threshold UnitSpec::kinit (exact iff score <= kinit)
+    int solve(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units, SolveOut& out,
+              bool nwBand = false);
     int solveChunk(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units,
-                   size_t a, size_t b, SolveOut& out);
+                   size_t a, size_t b, SolveOut& out, bool nwBand);
     int alphabetLengths(const std::vector<int>& units, std::vector<UnitResult>& res);
     // linear-space paths (reference obtainAlignmentHirschberg, edlib.cpp:1231-1396)
     struct Piece { long long qoff; int m; long long toff; int T; int score; };

@@ -263,6 +263,133 @@ hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStr
     return hipErrorInvalidValue;
 }
 
+// ------------------------------------------------------- banded NW scan
+
+// NW distance inside Ukkonen's diagonal band for a fixed threshold K = desc.kinit (what the reference's
+// first/lastBlock bookkeeping converges to, edlib.cpp:744-830): a path of cost <= K only visits
+// diagonals d = j - i in [dmin, dmax] = [min(0,D) - p, max(0,D) + p], D = T - m, p = (K - |D|) / 2.
+// Block b therefore lives for columns [64b + dmin, 64b + 63 + dmax]; at most 64 consecutive blocks are
+// alive at a time (K <= kMaxBandK), so ONE wave covers a query of any length:
+//   * blocks are mapped to lanes as a ring (block b -> lane b % 64).  When a lane's block leaves the band
+//     it re-arms for block b + 64: state "+1 per row" below the upstream block's bottom score, exactly the
+//     reference's new block (edlib.cpp:803-808); cells outside the band only ever enter as such upper
+//     bounds, so values <= K stay exact (Ukkonen);
+//   * same anti-diagonal schedule as scan_pairs_kernel (block b updates column t - b at step t), the
+//     carry moves by v_mov_b32_dpp wave_ror:1 (lane 63 feeds lane 0); a block whose upstream is outside
+//     the band (or block 0) takes hin = +1 (edlib.cpp:779);
+//   * target symbols are staged in a 256-entry LDS ring filled 64 columns per coalesced load; each lane
+//     reads the symbol of its next-but-one column and the Peq word of its next column while it computes
+//     the current one;
+//   * steps: T + numBlocks - 1 instead of (T + 63) per 64-block strip.
+template <bool LDSPEQ>
+__global__ void __launch_bounds__(64)
+scan_pairs_nwband_kernel(const PairScanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 s_dyn[];      // [sigmaT][64] Peq columns, then the target ring
+    u64* s_peq = s_dyn;
+    unsigned char* s_tgt = reinterpret_cast<unsigned char*>(s_dyn + (LDSPEQ ? a.sigmaT * 64 : 0));
+    const int lane = threadIdx.x;
+    const int unit = blockIdx.x;
+    const PairDesc d = a.descs[unit];
+    const int m = d.qlen, T = d.tlen, K = d.kinit;
+    const int nb = num_blocks(m);
+    const int D = T - m, absD = D < 0 ? -D : D;
+    if (K < absD) { if (lane == 0) { a.outScore[unit] = 0x3fffffff; a.outCount[unit] = 0; a.outLast[unit] = -1; } return; }
+    const int p = (K - absD) >> 1;
+    const int dmin = (D < 0 ? D : 0) - p, dmax = (D > 0 ? D : 0) + p;
+    const u32 sh = (u32)(m - 1) & 63u;
+    const int lastRows = m - 64 * (nb - 1);                           // query rows in the last block
+
+    // ---- target ring: columns [0, loaded) are in s_tgt[col & 255]
+    int loaded = 0;
+    auto refill = [&]() {                                             // 64 more columns, coalesced
+        const int c = loaded + lane;
+        s_tgt[c & 255] = (c < T) ? a.tlut[a.tpool[d.toff + (long long)c * d.tstep]] : 0;
+        loaded += 64;
+    };
+    for (int i = lane; i < 256; i += 64) s_tgt[i] = 0;                // never index Peq with an unwritten slot
+    refill(); refill(); refill();                                     // 192 columns ahead of column 0
+
+    // ---- per-lane block bookkeeping
+    int b = lane;                                                     // current (or next) block of this lane
+    auto first_col = [&](int blk) { const int c = 64 * blk + dmin; return c < 0 ? 0 : c; };
+    auto last_col = [&](int blk) { const int c = 64 * blk + 63 + dmax; return c > T - 1 ? T - 1 : c; };
+    int tstart = (b < nb && first_col(b) <= last_col(b)) ? first_col(b) + b : 0x7fffffff;
+    int tend = (b < nb) ? last_col(b) + b : -1;
+    int upLast = (b > 0) ? last_col(b - 1) : -1;                      // last column the upstream block delivers
+
+    Block64 B{~0u, ~0u, 0u, 0u};
+    int bscore = 0, sc = 0, carry = 0, symNxt = 0;
+    u64 eqCur = 0;
+    const int nsteps = T + nb - 1;
+
+    for (int t = 0; t < nsteps; ++t) {
+        if ((t & 63) == 0) {                                          // pace the ring by the largest column in use
+            int bt = t - 63 - dmax; bt = bt <= 0 ? 0 : (bt + 64) / 65;
+            if (t - T + 1 > bt) bt = t - T + 1;
+            const int jmax = t - bt;
+            while (loaded < T && loaded < jmax + 64 + 67) refill();
+        }
+        const int x = __builtin_amdgcn_update_dpp(0, carry, 0x13C /*wave_ror:1*/, 0xf, 0xf, false);
+        // upstream's bottom score travels only when some lane starts a block at this step
+        const bool starting = (t == tstart);
+        int upScore = 0;
+        if (__builtin_amdgcn_ballot_w64(starting) != 0ull)
+            upScore = __builtin_amdgcn_update_dpp(0, bscore, 0x13C, 0xf, 0xf, false);
+        const int col = t - b;
+        if (starting) {
+            // (re)arm: Peq column of the new block, fresh "+1 per row" state (edlib.cpp:759-763, 803-808)
+            if (LDSPEQ)
+                for (int sy = 0; sy < a.sigmaT; ++sy) s_peq[sy * 64 + lane] = a.peq[d.peqOff + (long long)sy * nb + b];
+            B = Block64{~0u, ~0u, 0u, 0u};
+            const int hp0 = x & 1, hn0 = (x >> 1) & 1;                // upstream's delta at column `col`
+            const int above = (col == 0) ? 64 * b : (upScore - (hp0 - hn0));   // bottom of the block above, column col-1
+            bscore = above + 64;
+            if (b == nb - 1) sc = above + lastRows;
+            const int s0 = s_tgt[col & 255];
+            eqCur = LDSPEQ ? s_peq[s0 * 64 + lane] : a.peq[d.peqOff + (long long)s0 * nb + b];
+            symNxt = s_tgt[(col + 1) & 255];
+        }
+        u32 hp = 0, hn = 0;
+        if (t >= tstart && t <= tend) {
+            const u64 eqNxt = LDSPEQ ? s_peq[symNxt * 64 + lane] : a.peq[d.peqOff + (long long)symNxt * nb + b];
+            const int symNN = s_tgt[(col + 2) & 255];
+            const bool fromUp = (b > 0) && (col <= upLast);
+            const u32 hpos = fromUp ? ((u32)x & 1u) : 1u, hneg = fromUp ? (((u32)x >> 1) & 1u) : 0u;
+            u32 ph0, ph1, mh0, mh1;
+            advance_block64(B, (u32)eqCur, (u32)(eqCur >> 32), hpos, hneg, ph0, ph1, mh0, mh1);
+            hp = ph1 >> 31; hn = mh1 >> 31;
+            bscore += (int)hp - (int)hn;
+            if (b == nb - 1) {
+                const u64 ph = ((u64)ph1 << 32) | ph0, mh = ((u64)mh1 << 32) | mh0;
+                sc += (int)((ph >> sh) & 1ull) - (int)((mh >> sh) & 1ull);
+                if (col == T - 1) { a.outScore[unit] = sc; a.outCount[unit] = 1; a.outLast[unit] = T - 1; }
+            }
+            eqCur = eqNxt; symNxt = symNN;
+        }
+        carry = (int)(hp | (hn << 1));
+        if (t >= tend && b < nb) {                                    // block done: re-arm this lane for block b + 64
+            b += 64;
+            const bool ok = b < nb && first_col(b) <= last_col(b);
+            tstart = ok ? first_col(b) + b : 0x7fffffff;
+            tend = (b < nb) ? last_col(b) + b : -1;
+            upLast = last_col(b - 1);
+        }
+    }
+}
+
+hipError_t launch_scan_pairs_nwband(const PairScanArgs& a, hipStream_t stream)
+{
+    if (a.numUnits == 0) return hipSuccess;
+    if (a.sigmaT <= 32) {
+        const size_t lds = (size_t)a.sigmaT * 64 * sizeof(u64) + 256;
+        hipLaunchKernelGGL((scan_pairs_nwband_kernel<true>), dim3(a.numUnits), dim3(64), lds, stream, a);
+    } else {
+        hipLaunchKernelGGL((scan_pairs_nwband_kernel<false>), dim3(a.numUnits), dim3(64), 256, stream, a);
+    }
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------- Hirschberg split
 
 // value of the cell at row r of a dumped column (same decoding as the traceback's left neighbour)

@@ -54,6 +54,13 @@ struct PairScanArgs {
 // mode: 0 NW, 1 SHW, 2 HW.  store: also write the column store.
 hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStream_t stream);
 
+// NW distance with Ukkonen's diagonal band for threshold desc.kinit (reference
+// myersCalcEditDistanceNW with a fixed k, edlib.cpp:730-928): exact whenever the distance is <= kinit,
+// otherwise some value > kinit.  The band must fit 64 blocks (kinit <= kMaxBandK); one wave per unit
+// whatever the query length (no strips).  outScore only.
+constexpr int kMaxBandK = 3968;
+hipError_t launch_scan_pairs_nwband(const PairScanArgs& a, hipStream_t stream);
+
 // reference buildPeq (edlib.cpp:358-384) for every unit: Peq[sym][block] from the
 // query bytes and the 256x256 byte equality matrix eq8 (identity + additionalEqualities).
 hipError_t launch_build_peq_pairs(const PairDesc* descs, int numUnits, const uint8_t* qpool,
