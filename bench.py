@@ -14,7 +14,7 @@ Inputs are resident in HBM before the timed region; results stay on the device.
 
 Rank 0 prints ONE JSON line.  metric = GCUPS = sum(queryLen*targetLen)/s/1e9 over
 all ranks (weak scaling: every rank owns its own 1M reads, no collective on the
-data path).  `roofline` prices the dominant kernel (scan_reads_kernel<5,HW>)
+data path).  `roofline` prices the dominant kernel (scan_reads_banded_kernel<5>, all its launches of a step)
 against HBM with the ALGORITHMIC bytes of SURVEY.md §8d (each pair counted as if it
 streamed its own target); `valu_roofline` is the bound that actually binds this
 integer kernel.  `cpu_baseline` times the unmodified reference
