@@ -636,7 +636,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         d.storeOff = storeEntries; if (wantPath) storeEntries += pair_store_entries(s.qlen, s.tlen);
         d.posCap = wantPositions ? kPosCap : 0;
         d.posOff = (long long)i * kPosCap;
-        d.colOff = -1;
+        d.colOff = -1; d.bandT = 0; d.pad_ = 0;
         opsOff[i + 1] = opsOff[i] + (wantPath ? (long long)s.qlen + s.tlen : 0);
         // executed work: whole matrix, or one 64-block wave per column inside the band
         stats.word_steps += nwBand ? 2LL * 64 * ((long long)s.tlen + nb - 1) : 2 * nb * (long long)s.tlen;
@@ -774,29 +774,44 @@ int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& spli
                            std::vector<int>& leftScore, std::vector<int>& rightScore)
 {
     const size_t np = big.size();
+    // Long queries whose distance fits the band take the banded kernel (one wave per scan, the band of the
+    // WHOLE piece with k = its distance, stopped at the half's last column -- exactly the reference's
+    // two calls, edlib.cpp:1252-1260); the others the unbanded strips.  Both dump their last column.
+    std::vector<size_t> order; order.reserve(np);
+    size_t nBanded = 0;
+    for (size_t p = 0; p < np; ++p)
+        if (big[p].m > 64 * 64 && big[p].score <= kMaxBandK) { order.push_back(p); ++nBanded; }
+    for (size_t p = 0; p < np; ++p)
+        if (!(big[p].m > 64 * 64 && big[p].score <= kMaxBandK)) order.push_back(p);
     std::vector<PairDesc> descs(2 * np);
     std::vector<int> best(np);
     long long peqWords = 0, auxInts = 0, colBlocks = 0;
-    for (size_t p = 0; p < np; ++p) {
-        const Piece& pc = big[p];
+    for (size_t q = 0; q < np; ++q) {
+        const Piece& pc = big[order[q]];
+        const bool banded = q < nBanded;
         const int lw = pc.T / 2, rw = pc.T - lw;                         // :1247-1248
         const long long nb = (pc.m + 63) / 64;
-        best[p] = pc.score;
+        best[q] = pc.score;
         for (int side = 0; side < 2; ++side) {
-            PairDesc& d = descs[2 * p + side];
-            d.qlen = pc.m; d.kinit = 0; d.posCap = 0; d.posOff = 0; d.storeOff = 0;
+            PairDesc& d = descs[2 * q + side];
+            d.qlen = pc.m; d.kinit = banded ? pc.score : 0; d.posCap = 0; d.posOff = 0; d.storeOff = 0;
+            d.bandT = banded ? pc.T : 0; d.pad_ = 0;
             if (side == 0) { d.qoff = pc.qoff; d.qstep = 1; d.toff = pc.toff; d.tstep = 1; d.tlen = lw; }
             else { d.qoff = pc.qoff + pc.m - 1; d.qstep = -1; d.toff = pc.toff + pc.T - 1; d.tstep = -1; d.tlen = rw; }
             d.peqOff = peqWords; peqWords += nb * tab_.sigmaT;
-            d.auxOff = auxInts; if (nb > 64) auxInts += d.tlen;
+            d.auxOff = auxInts; if (nb > 64 && !banded) auxInts += d.tlen;
             d.colOff = colBlocks; colBlocks += nb;
-            stats.word_steps += 2 * nb * (long long)d.tlen;
+            stats.word_steps += banded ? 2LL * 64 * ((long long)d.tlen + nb - 1) : 2 * nb * (long long)d.tlen;
         }
     }
     const size_t n = descs.size();
     DevBuf<unsigned long long> colP, colM; DevBuf<int> colS, d_best, d_out;
     EDLIB_AMD_HIP(colP.alloc((size_t)colBlocks)); EDLIB_AMD_HIP(colM.alloc((size_t)colBlocks)); EDLIB_AMD_HIP(colS.alloc((size_t)colBlocks));
     EDLIB_AMD_HIP(d_best.alloc(np)); EDLIB_AMD_HIP(d_out.alloc(3 * np));
+    // blocks outside the band at the stop column: P = M = 0 and a score no sum can reach
+    EDLIB_AMD_HIP(hipMemsetAsync(colP.p, 0, (size_t)colBlocks * 8, stream_));
+    EDLIB_AMD_HIP(hipMemsetAsync(colM.p, 0, (size_t)colBlocks * 8, stream_));
+    EDLIB_AMD_HIP(hipMemsetAsync(colS.p, 0x3f, (size_t)colBlocks * 4, stream_));
     EDLIB_AMD_HIP(d_descs_.ensure(n)); EDLIB_AMD_HIP(d_peq64_.ensure((size_t)peqWords)); EDLIB_AMD_HIP(d_aux_.ensure((size_t)auxInts));
     EDLIB_AMD_HIP(d_outScore_.ensure(n)); EDLIB_AMD_HIP(d_outCount_.ensure(n)); EDLIB_AMD_HIP(d_outLast_.ensure(n));
     EDLIB_AMD_HIP(d_posPool_.ensure(1));
@@ -805,13 +820,24 @@ int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& spli
     EDLIB_AMD_HIP(launch_build_peq_pairs(d_descs_.p, (int)n, d_qpool_.p, d_eq8_.p, d_idToByte_.p, tab_.sigmaT,
                                          d_peq64_.p, stream_));
     PairScanArgs a{};
-    a.descs = d_descs_.p; a.numUnits = (int)n; a.qpool = d_qpool_.p; a.tpool = d_tpool_.p;
+    a.qpool = d_qpool_.p; a.tpool = d_tpool_.p;
     a.tlut = d_tlut_.p; a.sigmaT = tab_.sigmaT; a.peq = d_peq64_.p; a.aux = d_aux_.p;
-    a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p; a.posPool = d_posPool_.p;
+    a.posPool = d_posPool_.p;
     a.colP = colP.p; a.colM = colM.p; a.colS = colS.p;
-    scanTimerStart();
-    EDLIB_AMD_HIP(launch_scan_pairs(EDLIB_MODE_NW, false, a, stream_));
-    scanTimerStop();
+    if (nBanded) {
+        a.descs = d_descs_.p; a.numUnits = (int)(2 * nBanded);
+        a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p;
+        scanTimerStart();
+        EDLIB_AMD_HIP(launch_scan_pairs_nwband(a, stream_));
+        scanTimerStop();
+    }
+    if (np > nBanded) {
+        a.descs = d_descs_.p + 2 * nBanded; a.numUnits = (int)(2 * (np - nBanded));
+        a.outScore = d_outScore_.p + 2 * nBanded; a.outCount = d_outCount_.p + 2 * nBanded; a.outLast = d_outLast_.p + 2 * nBanded;
+        scanTimerStart();
+        EDLIB_AMD_HIP(launch_scan_pairs(EDLIB_MODE_NW, false, a, stream_));
+        scanTimerStop();
+    }
     SplitArgs sa{};
     sa.descs = d_descs_.p; sa.numPieces = (int)np; sa.best = d_best.p;
     sa.colP = colP.p; sa.colM = colM.p; sa.colS = colS.p; sa.out = d_out.p;
@@ -820,7 +846,10 @@ int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& spli
     EDLIB_AMD_HIP(hipMemcpyAsync(out.data(), d_out.p, out.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
     splitRow.resize(np); leftScore.resize(np); rightScore.resize(np);
-    for (size_t p = 0; p < np; ++p) { splitRow[p] = out[3 * p]; leftScore[p] = out[3 * p + 1]; rightScore[p] = out[3 * p + 2]; }
+    for (size_t q = 0; q < np; ++q) {
+        const size_t p = order[q];
+        splitRow[p] = out[3 * q]; leftScore[p] = out[3 * q + 1]; rightScore[p] = out[3 * q + 2];
+    }
     return 0;
 }
 

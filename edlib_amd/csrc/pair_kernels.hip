@@ -291,9 +291,10 @@ scan_pairs_nwband_kernel(const PairScanArgs a)
     const int lane = threadIdx.x;
     const int unit = blockIdx.x;
     const PairDesc d = a.descs[unit];
-    const int m = d.qlen, T = d.tlen, K = d.kinit;
+    const int m = d.qlen, T = d.tlen, K = d.kinit;      // T: columns to process (the scan stops at column T-1)
     const int nb = num_blocks(m);
-    const int D = T - m, absD = D < 0 ? -D : D;
+    const int D = (d.bandT ? d.bandT : T) - m, absD = D < 0 ? -D : D;   // the band is that of the whole problem
+    const bool dumpCol = a.colP != nullptr && d.colOff >= 0;
     if (K < absD) { if (lane == 0) { a.outScore[unit] = 0x3fffffff; a.outCount[unit] = 0; a.outLast[unit] = -1; } return; }
     const int p = (K - absD) >> 1;
     const int dmin = (D < 0 ? D : 0) - p, dmax = (D > 0 ? D : 0) + p;
@@ -364,6 +365,10 @@ scan_pairs_nwband_kernel(const PairScanArgs a)
                 const u64 ph = ((u64)ph1 << 32) | ph0, mh = ((u64)mh1 << 32) | mh0;
                 sc += (int)((ph >> sh) & 1ull) - (int)((mh >> sh) & 1ull);
                 if (col == T - 1) { a.outScore[unit] = sc; a.outCount[unit] = 1; a.outLast[unit] = T - 1; }
+            }
+            if (dumpCol && col == T - 1) {                            // stop column of a Hirschberg half
+                a.colP[d.colOff + b] = ((u64)B.p1 << 32) | B.p0; a.colM[d.colOff + b] = ((u64)B.m1 << 32) | B.m0;
+                a.colS[d.colOff + b] = bscore;
             }
             eqCur = eqNxt; symNxt = symNN;
         }

@@ -25,6 +25,9 @@ struct PairDesc {
     int posCap;          // capacity of this unit's end-position list
     long long posOff;    // first int of that list in the positions pool
     long long colOff;    // first block of this unit's last-column dump (Hirschberg), or -1
+    int bandT;           // banded NW kernel: target length that defines the band when the scan stops early
+                         // at column tlen-1 (Hirschberg halves, edlib.cpp:1252-1260); 0 = tlen
+    int pad_;
 };
 
 struct PairScanArgs {
@@ -57,7 +60,8 @@ hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStr
 // NW distance with Ukkonen's diagonal band for threshold desc.kinit (reference
 // myersCalcEditDistanceNW with a fixed k, edlib.cpp:730-928): exact whenever the distance is <= kinit,
 // otherwise some value > kinit.  The band must fit 64 blocks (kinit <= kMaxBandK); one wave per unit
-// whatever the query length (no strips).  outScore only.
+// whatever the query length (no strips).  Writes outScore and, when colP is set, the (P, M, score) of the
+// blocks alive at the last processed column (the caller pre-fills the dump with "invalid").
 constexpr int kMaxBandK = 3968;
 hipError_t launch_scan_pairs_nwband(const PairScanArgs& a, hipStream_t stream);
 
