@@ -278,7 +278,7 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
         if (mode == EDLIB_MODE_HW) {
             // enough waves to fill 256 CUs x 4 SIMDs several times over, segments >= 4096 columns
             long long S = (65536 + nrblk - 1) / nrblk;
-            const long long maxS = std::max(1, T / 4096);
+            const long long maxS = std::min(65535, std::max(1, T / 4096));     // gridDim.y limit
             S = std::max(1LL, std::min(S, maxS));
             g->segLen = roundup((int)((T + S - 1) / S), 16);
             g->numSegments = (T + g->segLen - 1) / g->segLen;
@@ -401,7 +401,7 @@ static void plan_segments(int nlanes, int T, int mode, int warmFull, long long w
     if (mode != EDLIB_MODE_HW) return;
     const long long nrblk = ((long long)nlanes + 63) / 64;
     long long want = (wantWaves + nrblk - 1) / nrblk;
-    want = std::max(1LL, std::min<long long>(want, std::max(1, T / 4096)));
+    want = std::max(1LL, std::min<long long>(want, std::min(65535, std::max(1, T / 4096))));   // gridDim.y limit
     segLen = roundup((int)((T + want - 1) / want), 16);
     S = (T + segLen - 1) / segLen;
     warm = warmFull;
