@@ -2,24 +2,20 @@
 //
 // Replaces, for BASELINE.json configs 2/3, the reference's per-query call of
 // myersCalcEditDistanceSemiGlobal (edlib.cpp:550-704) + buildPeq (:358-384) +
-// calculateBlock (:412-447).  Design:
+// calculateBlock (:412-447) and the k-doubling loop around it (:197-217).  Design:
 //
 //   * one wave64 = 64 queries ("slots") x one segment of the target; every
 //     lane owns one query, so the target symbol of a column is WAVE-UNIFORM:
 //     it is fetched with scalar loads from the 2-bit packed target and picks,
-//     by a scalar 4-way branch, which of the lane's four Peq register rows
-//     feeds the column.  No cross-lane traffic, no LDS, no divergence in the
-//     DP itself.
+//     by a scalar 4-way branch (or, in the narrow band, by M0 for an LDS read),
+//     which of the lane's four Peq rows feeds the column.  No cross-lane traffic
+//     and no divergence in the DP itself.
 //   * the query column lives in VGPRs as NWD 32-bit words (Pv, Mv) instead of
 //     the reference's 64-bit blocks: 150 rows need 5 words (160 rows) rather
 //     than 3 blocks (192 rows).  The 64-bit add of calculateBlock becomes a
 //     v_add_co/v_addc_co carry chain, the <<1 a v_alignbit chain, and every
 //     3-input boolean a single v_bitop3_b32 (gfx950).  10 VALU ops per word
 //     per column.
-//   * no Ukkonen band: every output of the reference is a pure function of the
-//     full DP matrix, so the kernel computes all rows of every
-//     column (the reference itself touches 68 % of them on this workload) and
-//     never branches on data.
 //   * the score of the bottom query row is followed directly at bit (m-1) of
 //     the last word, so no wildcard padding (the reference's W) is needed and
 //     end positions are produced un-shifted.
@@ -27,6 +23,12 @@
 //     fresh state reproduces the exact bottom-row scores of its own columns,
 //     so the target is cut into segments for load balance and for small
 //     batches; merge_segments() joins them.
+//
+// Two scan kernels:
+//   scan_reads_kernel<NWD, MODE>        every row of every column (SHW, NW; HW with EDLIB_AMD_BAND=0).
+//                                       All outputs are functions of the full DP matrix, so no band is
+//                                       needed for correctness and the kernel never branches on data.
+//   scan_reads_banded_kernel<NWD>       HW: Ukkonen band per wave + k-doubling (the bench kernel, §3b).
 #include "reads_kernels.hpp"
 
 namespace edlib_amd {
