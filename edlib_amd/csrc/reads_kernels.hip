@@ -458,7 +458,7 @@ __device__ __forceinline__ int band_dword(const u32 tw, const int colBase, const
                                           int& e, int& flag, HwTrack& tr, const u32 sh, const int lastRows,
                                           const u32 ldsBase)
 {
-  if (NA <= 2 && NWD > 2) {
+  if constexpr (NA <= 2 && NWD > 2) {
     // narrow band: straight-line code, Peq rows from LDS one column ahead (nothing is tracked: the
     // bottom row is outside the band)
     // (a two-column-deep prefetch with lgkmcnt(2) measured 2 % slower: with 7 waves per SIMD the LDS
@@ -470,7 +470,7 @@ __device__ __forceinline__ int band_dword(const u32 tw, const int colBase, const
         EDLIB_AMD_LDS_WAIT2(n0, n1);
         const u32 e0 = n0, e1 = n1;
         if (j < 15) { EDLIB_AMD_LDS_LOAD2((tw >> (2 * (j + 1))) & 3u, n0, n1) }
-        if (NA == 2) column_step_eq2<NWD>(e0, e1, Pv, Mv); else column_step_eq1<NWD>(e0, Pv, Mv);
+        if constexpr (NA == 2) column_step_eq2<NWD>(e0, e1, Pv, Mv); else column_step_eq1<NWD>(e0, Pv, Mv);
     }
   } else {
 #pragma unroll
