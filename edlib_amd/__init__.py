@@ -82,6 +82,10 @@ def lib():
         L.edlibAmdBatchStats.argtypes = [C.c_void_p, C.POINTER(BatchStats)]
         L.edlibAmdBatchDestroy.argtypes = [C.c_void_p]
         L.edlibAmdBatchDestroy.restype = None
+        L.edlibAlignBatchSharedTarget.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_int,
+                                                  AlignConfig, C.POINTER(AlignResult)]
+        L.edlibAlignBatchPairs.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_char_p),
+                                           C.POINTER(C.c_int), C.c_int, AlignConfig, C.POINTER(AlignResult)]
         L.libc = C.CDLL(None)
         L.libc.free.argtypes = [C.c_void_p]
         _lib = L
@@ -381,6 +385,32 @@ def align_batch(queries, target, mode="HW", task="distance", k=-1, additionalEqu
         return b.results(raw=raw)
     finally:
         b.close()
+
+
+def align_batch_oneshot(queries, target, targets=None, mode="HW", task="distance", k=-1, additionalEqualities=None):
+    """The one-shot C entry points edlibAlignBatchSharedTarget / edlibAlignBatchPairs (pointer arrays in,
+    EdlibAlignResult[] out; shards over EDLIB_AMD_DEVICES).  Returns raw result dicts."""
+    L = lib()
+    n = len(queries)
+    cfg, keep = _make_config(mode, task, k, additionalEqualities)
+    qs = [bytes(q) for q in queries]
+    qarr = (C.c_char_p * max(n, 1))(*qs)
+    qlen = (C.c_int * max(n, 1))(*[len(q) for q in qs])
+    res = (AlignResult * max(n, 1))()
+    if targets is None:
+        rc = L.edlibAlignBatchSharedTarget(qarr, qlen, n, bytes(target), len(target), cfg, res)
+    else:
+        ts = [bytes(t) for t in targets]
+        tarr = (C.c_char_p * max(n, 1))(*ts)
+        tlen = (C.c_int * max(n, 1))(*[len(t) for t in ts])
+        rc = L.edlibAlignBatchPairs(qarr, qlen, tarr, tlen, n, cfg, res)
+    if rc != 0:
+        raise RuntimeError("edlib_amd: one-shot batch failed: " + last_error())
+    out = []
+    for i in range(n):
+        out.append(_raw_result(res[i]))
+        L.edlibFreeAlignResult(res[i])
+    return out
 
 
 def align_pairs(queries, targets, mode="NW", task="distance", k=-1, additionalEqualities=None, raw=False):

@@ -4,9 +4,11 @@
 #define EDLIB_BUILD
 #include "engine.hpp"
 
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace edlib_amd;
@@ -136,22 +138,6 @@ EDLIB_API int edlibAmdBatchStats(EdlibAmdBatch* b, EdlibAmdBatchStats* out) {
 
 EDLIB_API void edlibAmdBatchDestroy(EdlibAmdBatch* b) { delete b; }
 
-static int run_oneshot(EdlibAmdBatch* b, int n, EdlibAlignResult* results, const char* where) {
-    if (!b) {
-        fail_loudly(where);
-        for (int i = 0; i < n; ++i) results[i] = blank_result(EDLIB_STATUS_ERROR);
-        return EDLIB_STATUS_ERROR;
-    }
-    int rc = edlibAmdBatchRun(b);
-    if (rc == EDLIB_STATUS_OK) rc = edlibAmdBatchResults(b, results);
-    if (rc != EDLIB_STATUS_OK) {
-        fail_loudly(where);
-        for (int i = 0; i < n; ++i) results[i] = blank_result(EDLIB_STATUS_ERROR);
-    }
-    edlibAmdBatchDestroy(b);
-    return rc;
-}
-
 static void pack(const char* const* seqs, const int* lens, int n, std::vector<char>& bytes,
                  std::vector<long long>& off) {
     off.assign(n + 1, 0);
@@ -161,23 +147,89 @@ static void pack(const char* const* seqs, const int* lens, int n, std::vector<ch
         if (lens[i] > 0) memcpy(bytes.data() + off[i], seqs[i], (size_t)lens[i]);
 }
 
+// Devices the one-shot batch entry points shard over (contiguous slices of the units,
+// target replicated, one host thread + one stream per device, no collective).  Default: device 0.
+// EDLIB_AMD_DEVICES=all | "0,1,2,..." (a device may be listed twice: used by the tests on a 1-GPU box).
+static std::vector<int> oneshot_devices() {
+    std::vector<int> devs;
+    const char* env = getenv("EDLIB_AMD_DEVICES");
+    const int ndev = device_count();
+    if (env && !strcmp(env, "all")) { for (int d = 0; d < ndev; ++d) devs.push_back(d); }
+    else if (env && *env) {
+        for (const char* p = env; *p;) {
+            char* e; const long d = strtol(p, &e, 10);
+            if (e == p) break;
+            if (d >= 0 && d < ndev) devs.push_back((int)d);
+            p = (*e == ',') ? e + 1 : e;
+        }
+    }
+    if (devs.empty()) devs.push_back(0);
+    return devs;
+}
+
+// Runs units [lo, hi) of a packed batch on one device.  toff == nullptr: shared target.
+static int run_shard(const char* q, const long long* qoff, const char* t, const long long* toff, int targetLength,
+                     int lo, int hi, EdlibAlignConfig config, int device, EdlibAlignResult* results, std::string* err) {
+    EdlibAmdBatch* b = toff ? edlibAmdBatchCreatePairs(q, qoff + lo, t, toff + lo, hi - lo, config, device)
+                            : edlibAmdBatchCreateShared(q, qoff + lo, hi - lo, t, targetLength, config, device);
+    int rc = b ? edlibAmdBatchRun(b) : EDLIB_STATUS_ERROR;
+    if (rc == EDLIB_STATUS_OK) rc = edlibAmdBatchResults(b, results + lo);
+    if (rc != EDLIB_STATUS_OK) *err = last_error();
+    if (b) edlibAmdBatchDestroy(b);
+    return rc;
+}
+
+static int run_sharded(const char* q, const long long* qoff, const char* t, const long long* toff, int targetLength,
+                       int n, EdlibAlignConfig config, EdlibAlignResult* results, const char* where) {
+    const std::vector<int> devs = oneshot_devices();
+    const int world = (int)std::min<size_t>(devs.size(), (size_t)std::max(1, n));
+    std::vector<int> rc(world, EDLIB_STATUS_OK);
+    std::vector<std::string> err(world);
+    const int per = (n + world - 1) / world;                     // same rule as edlib_amd/parallel.py
+    auto work = [&](int r) {
+        const int lo = std::min(n, r * per), hi = std::min(n, lo + per);
+        if (hi > lo || n == 0) rc[r] = run_shard(q, qoff, t, toff, targetLength, lo, hi, config, devs[r], results, &err[r]);
+    };
+    if (world == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int r = 0; r < world; ++r) th.emplace_back(work, r);
+        for (auto& x : th) x.join();
+    }
+    for (int r = 0; r < world; ++r) {
+        if (rc[r] == EDLIB_STATUS_OK) continue;
+        set_error("%s", err[r].c_str());
+        fail_loudly(where);
+        for (int i = 0; i < n; ++i) {                            // all or nothing: free what other shards produced
+            if (results[i].status == EDLIB_STATUS_OK) edlibFreeAlignResult(results[i]);
+            results[i] = blank_result(EDLIB_STATUS_ERROR);
+        }
+        return EDLIB_STATUS_ERROR;
+    }
+    return EDLIB_STATUS_OK;
+}
+
 EDLIB_API int edlibAlignBatchSharedTarget(const char* const* queries, const int* queryLengths, int numQueries,
                                           const char* target, int targetLength, EdlibAlignConfig config,
                                           EdlibAlignResult* results) {
+    if (numQueries < 0 || targetLength < 0) { set_error("negative size"); return EDLIB_STATUS_ERROR; }
     std::vector<char> qb; std::vector<long long> qo;
     pack(queries, queryLengths, numQueries, qb, qo);
-    return run_oneshot(edlibAmdBatchCreateShared(qb.data(), qo.data(), numQueries, target, targetLength, config, 0),
-                       numQueries, results, "edlibAlignBatchSharedTarget");
+    for (int i = 0; i < numQueries; ++i) results[i] = blank_result(EDLIB_STATUS_ERROR);
+    return run_sharded(qb.data(), qo.data(), target, nullptr, targetLength, numQueries, config, results,
+                       "edlibAlignBatchSharedTarget");
 }
 
 EDLIB_API int edlibAlignBatchPairs(const char* const* queries, const int* queryLengths,
                                    const char* const* targets, const int* targetLengths, int numPairs,
                                    EdlibAlignConfig config, EdlibAlignResult* results) {
+    if (numPairs < 0) { set_error("negative size"); return EDLIB_STATUS_ERROR; }
     std::vector<char> qb, tb; std::vector<long long> qo, to;
     pack(queries, queryLengths, numPairs, qb, qo);
     pack(targets, targetLengths, numPairs, tb, to);
-    return run_oneshot(edlibAmdBatchCreatePairs(qb.data(), qo.data(), tb.data(), to.data(), numPairs, config, 0),
-                       numPairs, results, "edlibAlignBatchPairs");
+    for (int i = 0; i < numPairs; ++i) results[i] = blank_result(EDLIB_STATUS_ERROR);
+    return run_sharded(qb.data(), qo.data(), tb.data(), to.data(), 0, numPairs, config, results,
+                       "edlibAlignBatchPairs");
 }
 
 }  // extern "C"

@@ -36,7 +36,11 @@ EDLIB_API const char* edlibAmdVersion(void);
  * `for q: results[q] = edlibAlign(queries[q], .., target, .., config)`
  * (apps/aligner/aligner.cpp:162-172).  results[] must hold numQueries
  * entries; each is exactly what edlibAlign() would have returned and is
- * released the same way (edlibFreeAlignResult / free). */
+ * released the same way (edlibFreeAlignResult / free).
+ * Environment: EDLIB_AMD_DEVICES = "all" or a comma list of device ordinals
+ * shards the units over several GPUs of the node (contiguous slices, target
+ * replicated, one host thread + stream per device, no collective); default
+ * is device 0.  All-or-nothing: if any shard fails every result is ERROR. */
 EDLIB_API int edlibAlignBatchSharedTarget(
     const char* const* queries, const int* queryLengths, int numQueries,
     const char* target, int targetLength,

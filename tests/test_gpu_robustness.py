@@ -105,3 +105,20 @@ def test_exact_pass_at_full_target_length(engine, ref, oracle):
     for i in many + list(range(0, 4096, 512)):
         want = impl.align(r["reads"][i].tobytes(), tb, "HW", "distance", -1)
         assert same(got[i], want), i
+
+
+def test_oneshot_entry_points_shard_over_devices(engine, oracle, monkeypatch):
+    """edlibAlignBatchSharedTarget / edlibAlignBatchPairs split the units into contiguous shards, one host
+    thread + stream per listed device.  On a 1-GPU box the same device is listed 3 times."""
+    target = synth.random_dna(61, 30000)
+    reads = synth.illumina_reads(target, 50, m=150, seed=62)["reads"]
+    qs = [r.tobytes() for r in reads] + [b""]
+    for devs in ("0", "0,0,0"):
+        monkeypatch.setenv("EDLIB_AMD_DEVICES", devs)
+        got = engine.align_batch_oneshot(qs, target.tobytes(), mode="HW", task="path")
+        for q, g in zip(qs, got):
+            assert same(g, oracle.align(q, target.tobytes(), "HW", "path", -1)), devs
+        ts = [target[i * 100:i * 100 + 170].tobytes() for i in range(len(qs))]
+        got = engine.align_batch_oneshot(qs, None, targets=ts, mode="NW", task="distance")
+        for q, t, g in zip(qs, ts, got):
+            assert same(g, oracle.align(q, t, "NW", "distance", -1)), devs
