@@ -104,7 +104,7 @@ def main():
     dist = None
     if args.share_gpu:
         local_rank = 0
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:        # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":

@@ -221,6 +221,18 @@ def synth_cases():
         cases.append({"name": "c1.pair%d" % i,
                       "input": {"kind": "mut", "seed": 9000 + i, "tn": 94481, "sub": rate, "ins": rate / 3, "del": rate / 3},
                       "mode": "NW", "task": "distance", "k": -1, "eq": None})
+    # the divergence of the reference's mutated_60_perc file (its golden there: 39829), far above the
+    # band limit of the ring kernel, and a PATH whose Hirschberg levels cannot use the banded scans
+    cases.append({"name": "c1.pair3",
+                  "input": {"kind": "mut", "seed": 9003, "tn": 94481, "sub": 0.3, "ins": 0.1, "del": 0.1},
+                  "mode": "NW", "task": "distance", "k": -1, "eq": None})
+    cases.append({"name": "hirsch.c1.div",
+                  "input": {"kind": "mut", "seed": 9101, "tn": 94481, "sub": 0.03, "ins": 0.01, "del": 0.01},
+                  "mode": "NW", "task": "path", "k": -1, "eq": None})
+    for i, (mode, kk) in enumerate((("HW", -1), ("SHW", -1), ("NW", 3000), ("NW", 20000))):
+        cases.append({"name": "c1.modes%d" % i,
+                      "input": {"kind": "mut", "seed": 9200 + i, "tn": 30000, "sub": 0.1, "ins": 0.03, "del": 0.03},
+                      "mode": mode, "task": "locations", "k": kk, "eq": None})
     return cases
 
 
