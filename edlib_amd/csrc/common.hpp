@@ -27,6 +27,10 @@ void set_error(const char* fmt, ...);
 // is a batch of one: without the cache every call pays ~30 hipMalloc/hipFree round trips.
 hipError_t pool_alloc(void** p, size_t bytes, size_t* granted);
 void pool_free(void* p, size_t granted);
+// Pinned host staging blocks (D2H of op strings and result tables at full link rate, no page faults);
+// cached like the device blocks.  Never handed to the caller.
+hipError_t pinned_alloc(void** p, size_t bytes, size_t* granted);
+void pinned_free(void* p, size_t granted);
 hipError_t pool_stream(hipStream_t* s);
 void pool_stream_release(hipStream_t s);
 
@@ -52,6 +56,23 @@ struct DevBuf {
     // grow-only
     hipError_t ensure(size_t count) { return (count <= n && p) ? hipSuccess : alloc(count); }
     size_t bytes() const { return n * sizeof(T); }
+};
+
+// Pinned host block that frees itself (back into the cache).
+struct PinBuf {
+    uint8_t* p = nullptr;
+    size_t n = 0, granted = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+    ~PinBuf() { release(); }
+    void release() { if (p) { pinned_free(p, granted); p = nullptr; n = 0; granted = 0; } }
+    hipError_t alloc(size_t bytes) {
+        release();
+        if (bytes == 0) bytes = 1;
+        n = bytes;
+        return pinned_alloc(reinterpret_cast<void**>(&p), bytes, &granted);
+    }
 };
 
 struct Event {

@@ -14,6 +14,7 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstring>
 #include <mutex>
@@ -38,10 +39,14 @@ struct Pool {
     std::vector<void*> blocks[kMaxDev][48];     // [device][log2 size class]
     std::vector<hipStream_t> streams[kMaxDev];
     size_t cachedBytes = 0;
+    std::vector<void*> pinned[48];              // [log2 size class], host memory: device independent
+    size_t cachedPinned = 0;
 };
 Pool& pool() { static Pool* p = new Pool; return *p; }     // leaked on purpose: no teardown-order hazards
 const size_t kPoolMaxBlock = 64u << 20;                     // larger blocks go straight back to the driver
 const size_t kPoolMaxCached = 1024u << 20;
+const size_t kPinnedMaxBlock = 256u << 20;
+const size_t kPinnedMaxCached = 512u << 20;
 int size_class(size_t bytes, size_t* rounded) {
     int c = 8;                                              // 256 B minimum
     while (((size_t)1 << c) < bytes) ++c;
@@ -83,6 +88,30 @@ void pool_free(void* p, size_t granted) {
         if (pool().cachedBytes + r <= kPoolMaxCached) { pool().blocks[dev][c].push_back(p); pool().cachedBytes += r; return; }
     }
     (void)hipFree(p);
+}
+
+hipError_t pinned_alloc(void** p, size_t bytes, size_t* granted) {
+    if (pool_enabled() && bytes <= kPinnedMaxBlock) {
+        size_t r; const int c = size_class(bytes, &r);
+        {
+            std::lock_guard<std::mutex> g(pool().mu);
+            auto& v = pool().pinned[c];
+            if (!v.empty()) { *p = v.back(); v.pop_back(); pool().cachedPinned -= r; *granted = r; return hipSuccess; }
+        }
+        *granted = r;
+        return hipHostMalloc(p, r, hipHostMallocDefault);
+    }
+    *granted = bytes;
+    return hipHostMalloc(p, bytes, hipHostMallocDefault);
+}
+
+void pinned_free(void* p, size_t granted) {
+    if (pool_enabled() && granted <= kPinnedMaxBlock && (granted & (granted - 1)) == 0) {
+        size_t r; const int c = size_class(granted, &r);
+        std::lock_guard<std::mutex> g(pool().mu);
+        if (pool().cachedPinned + r <= kPinnedMaxCached) { pool().pinned[c].push_back(p); pool().cachedPinned += r; return; }
+    }
+    (void)hipHostFree(p);
 }
 
 hipError_t pool_stream(hipStream_t* s) {
@@ -199,6 +228,18 @@ Batch::~Batch() {
 }
 
 static int roundup(int x, int q) { return (x + q - 1) / q * q; }
+
+// EDLIB_AMD_DEBUG: host wall time between named points of a run (stderr)
+struct Lap {
+    bool on; std::chrono::steady_clock::time_point t;
+    Lap() : on(getenv("EDLIB_AMD_DEBUG") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void operator()(const char* what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[edlib_amd] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
 
 int Batch::init(const char* queries, const long long* qoff, int n, const char* targets,
                 const long long* toff, int numTargets, EdlibAlignConfig cfg, int device)
@@ -596,7 +637,7 @@ int Batch::solve(int mode, bool wantPositions, bool wantPath, const std::vector<
     const size_t n = units.size();
     out.score.assign(n, -1); out.count.assign(n, 0); out.last.assign(n, -1);
     out.posStart.assign(n + 1, 0); out.posFlat.clear();
-    out.opsStart.assign(n + 1, 0); out.ops.clear();
+    out.opsPtr.assign(n, nullptr); out.opsLen.assign(n, 0); out.opsBufs.clear();
     if (n == 0) return 0;
     stats.path |= 2;
     // chunk so that the Peq pool and (for PATH) the column store stay within a budget
@@ -622,6 +663,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
                       size_t ua, size_t ub, SolveOut& out, bool nwBand)
 {
     const size_t n = ub - ua;
+    Lap lap;
     std::vector<PairDesc> descs(n);
     std::vector<long long> opsOff(n + 1, 0);
     long long peqWords = 0, auxInts = 0, storeEntries = 0;
@@ -656,6 +698,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     EDLIB_AMD_HIP(hipMemcpyAsync(d_descs_.p, descs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
     EDLIB_AMD_HIP(launch_build_peq_pairs(d_descs_.p, (int)n, d_qpool_.p, d_eq8_.p, d_idToByte_.p, tab_.sigmaT,
                                          d_peq64_.p, stream_));
+    lap("chunk: descs+alloc");
     PairScanArgs a{};
     a.descs = d_descs_.p; a.numUnits = (int)n; a.qpool = d_qpool_.p; a.tpool = d_tpool_.p;
     a.tlut = d_tlut_.p; a.sigmaT = tab_.sigmaT; a.peq = d_peq64_.p; a.aux = d_aux_.p;
@@ -673,8 +716,9 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         tb.ops = d_ops_.p; tb.opsOff = d_opsOff_.p; tb.opsLen = d_opsLen_.p;
         EDLIB_AMD_HIP(launch_traceback(tb, stream_));
     }
+    if (lap.on) { EDLIB_AMD_HIP(hipStreamSynchronize(stream_)); lap("chunk: kernels"); }
     std::vector<int> score(n), count(n), last(n), pool, opsLen;
-    std::vector<uint8_t> ops;
+    std::shared_ptr<PinBuf> ops;
     EDLIB_AMD_HIP(hipMemcpyAsync(score.data(), d_outScore_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
     EDLIB_AMD_HIP(hipMemcpyAsync(count.data(), d_outCount_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
     EDLIB_AMD_HIP(hipMemcpyAsync(last.data(), d_outLast_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -683,12 +727,19 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         EDLIB_AMD_HIP(hipMemcpyAsync(pool.data(), d_posPool_.p, n * kPosCap * sizeof(int), hipMemcpyDeviceToHost, stream_));
     }
     if (wantPath) {
-        opsLen.resize(n); ops.resize((size_t)opsOff[n]);
+        opsLen.resize(n);
         EDLIB_AMD_HIP(hipMemcpyAsync(opsLen.data(), d_opsLen_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
-        if (!ops.empty())
-            EDLIB_AMD_HIP(hipMemcpyAsync(ops.data(), d_ops_.p, ops.size(), hipMemcpyDeviceToHost, stream_));
+        if (opsOff[n] > 0) {
+            // the op slots (qlen + tlen bytes per unit, filled from the back) land in pinned staging and
+            // are read from there by results(): no intermediate host copies
+            ops = std::make_shared<PinBuf>();
+            EDLIB_AMD_HIP(ops->alloc((size_t)opsOff[n]));
+            EDLIB_AMD_HIP(hipMemcpyAsync(ops->p, d_ops_.p, (size_t)opsOff[n], hipMemcpyDeviceToHost, stream_));
+            out.opsBufs.push_back(ops);
+        }
     }
     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+    lap("chunk: kernels+D2H");
 
     // exact second pass for units with more end locations than kPosCap
     std::vector<int> ovf; std::vector<long long> ovfOff(1, 0); std::vector<int> ovfPos;
@@ -734,12 +785,12 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
             }
         }
         out.posStart[g + 1] = (long long)out.posFlat.size();
-        if (wantPath) {
-            const uint8_t* e = ops.data() + opsOff[i + 1];
-            out.ops.insert(out.ops.end(), e - opsLen[i], e);
+        if (wantPath && ops) {
+            out.opsPtr[g] = ops->p + opsOff[i + 1] - opsLen[i];
+            out.opsLen[g] = opsLen[i];
         }
-        out.opsStart[g + 1] = (long long)out.ops.size();
     }
+    lap("chunk: host gather");
     return 0;
 }
 
@@ -856,10 +907,11 @@ int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& spli
 // Alignment paths of NW jobs of any size (reference obtainAlignment, edlib.cpp:1161-1213): pieces at
 // or above the 1 MiB column-store estimate are halved Hirschberg-style, level by level across the
 // whole batch, until every piece fits the traceback branch; the pieces' op strings concatenate.
-int Batch::solvePaths(const std::vector<Piece>& jobs, std::vector<std::vector<uint8_t>>& opsOut, std::vector<int>& status)
+int Batch::solvePaths(const std::vector<Piece>& jobs, std::vector<OpsOut>& opsOut, std::vector<int>& status)
 {
     const size_t nj = jobs.size();
-    opsOut.assign(nj, {}); status.assign(nj, EDLIB_STATUS_OK);
+    Lap lap;
+    opsOut.clear(); opsOut.resize(nj); status.assign(nj, EDLIB_STATUS_OK);
     std::vector<std::vector<Piece>> pieces(nj);
     for (size_t j = 0; j < nj; ++j) pieces[j].push_back(jobs[j]);
     for (int level = 0; level < 64; ++level) {
@@ -899,21 +951,39 @@ int Batch::solvePaths(const std::vector<Piece>& jobs, std::vector<std::vector<ui
             if (pc.m > 0 && pc.T > 0) { units.push_back(UnitSpec{pc.qoff, pc.m, 1, pc.toff, pc.T, 1, 0}); where.push_back({j, i}); }
         }
     }
+    lap("paths: levels+units");
     SolveOut so;
     if (solve(EDLIB_MODE_NW, false, true, units, so)) return 1;
-    std::vector<std::vector<std::vector<uint8_t>>> leafOps(nj);
-    for (size_t j = 0; j < nj; ++j) leafOps[j].resize(pieces[j].size());
-    for (size_t u = 0; u < units.size(); ++u)
-        leafOps[where[u].first][where[u].second].assign(so.ops.begin() + so.opsStart[u], so.ops.begin() + so.opsStart[u + 1]);
+    lap("paths: solve");
+    opsKeep_.insert(opsKeep_.end(), so.opsBufs.begin(), so.opsBufs.end());
+    // a job that was never split is its single leaf: hand out the view; split jobs concatenate their pieces
+    std::vector<size_t> firstLeaf(nj + 1, 0);                 // leaves are listed job by job, piece by piece
+    {
+        size_t u = 0;
+        for (size_t j = 0; j < nj; ++j) {
+            firstLeaf[j] = u;
+            if (status[j] != EDLIB_STATUS_OK) continue;
+            for (size_t i = 0; i < pieces[j].size(); ++i) if (pieces[j][i].m > 0 && pieces[j][i].T > 0) ++u;
+        }
+        firstLeaf[nj] = u;
+    }
     for (size_t j = 0; j < nj; ++j) {
         if (status[j] != EDLIB_STATUS_OK) continue;
+        OpsOut& o = opsOut[j];
+        size_t u = firstLeaf[j];
+        if (pieces[j].size() == 1 && pieces[j][0].m > 0 && pieces[j][0].T > 0) {
+            o.p = so.opsPtr[u]; o.len = so.opsLen[u];
+            continue;
+        }
         for (size_t i = 0; i < pieces[j].size(); ++i) {
             const Piece& pc = pieces[j][i];
-            if (pc.m == 0) opsOut[j].insert(opsOut[j].end(), (size_t)pc.T, (uint8_t)EDLIB_EDOP_DELETE);
-            else if (pc.T == 0) opsOut[j].insert(opsOut[j].end(), (size_t)pc.m, (uint8_t)EDLIB_EDOP_INSERT);
-            else opsOut[j].insert(opsOut[j].end(), leafOps[j][i].begin(), leafOps[j][i].end());
+            if (pc.m == 0) o.own.insert(o.own.end(), (size_t)pc.T, (uint8_t)EDLIB_EDOP_DELETE);
+            else if (pc.T == 0) o.own.insert(o.own.end(), (size_t)pc.m, (uint8_t)EDLIB_EDOP_INSERT);
+            else { o.own.insert(o.own.end(), so.opsPtr[u], so.opsPtr[u] + so.opsLen[u]); ++u; }
         }
+        o.p = o.own.data(); o.len = (int)o.own.size();
     }
+    lap("paths: assemble");
     return 0;
 }
 
@@ -927,10 +997,13 @@ int Batch::run()
     stats.cells = cells;
     scanEventsUsed_ = 0;
     haveResults_ = false;
+    results_.clear();            // views of the previous run die before their staging blocks
+    opsKeep_.clear();
     std::vector<UnitResult> res(n_);
     const int mode = (int)cfg_.mode;
     const int scanMode = (mode == EDLIB_MODE_HW || mode == EDLIB_MODE_SHW) ? mode : EDLIB_MODE_NW;
     EDLIB_AMD_HIP(hipEventRecord(evRun0_.e, stream_));
+    Lap lap;
 
     // ---- empty sequences: answered without any DP (edlib.cpp:166-184)
     for (int u : emptyUnits_) {
@@ -996,6 +1069,7 @@ int Batch::run()
         rest.insert(rest.end(), pairUnits_.begin(), pairUnits_.end());
         if (alphabetLengths(rest, res)) return 1;
     }
+    lap("run: phase 1 (distance)");
     std::vector<int> live;                     // non-empty units with a solution
     for (int u = 0; u < n_; ++u)
         if (qlen(u) > 0 && tlen(u) > 0 && res[u].editDistance >= 0) live.push_back(u);
@@ -1029,6 +1103,7 @@ int Batch::run()
             }
         }
     }
+    lap("run: phase 2 (starts)");
     // ---- phase 3: alignment path of the first location (edlib.cpp:276-289, 1161-1213)
     if (cfg_.task == EDLIB_TASK_PATH) {
         std::vector<Piece> jobs; std::vector<int> where;
@@ -1043,16 +1118,18 @@ int Batch::run()
             where.push_back(u);
         }
         if (!jobs.empty()) {
-            std::vector<std::vector<uint8_t>> ops; std::vector<int> st;
+            std::vector<OpsOut> ops; std::vector<int> st;
             if (solvePaths(jobs, ops, st)) return 1;
             for (size_t i = 0; i < jobs.size(); ++i) {
                 UnitResult& r = res[where[i]];
                 if (st[i] != EDLIB_STATUS_OK) { r.status = EDLIB_STATUS_ERROR; continue; }
-                r.ops.swap(ops[i]);
+                if (!ops[i].own.empty()) r.ops.swap(ops[i].own);
+                else { r.opsView = ops[i].p; r.opsViewLen = ops[i].len; }
                 r.hasAlignment = true;
             }
         }
     }
+    lap("run: phase 3 (paths)");
     EDLIB_AMD_HIP(hipEventRecord(evRun1_.e, stream_));
     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
     float ms = 0;
@@ -1075,6 +1152,7 @@ int Batch::run()
     }
     results_.swap(res);
     haveResults_ = true;
+    lap("run: stats");
     return 0;
 }
 
@@ -1104,9 +1182,11 @@ int Batch::results(EdlibAlignResult* out)
         if (r.hasEnds) { o.endLocations = malloc_ints(r.ends); o.numLocations = (int)r.ends.size(); }
         if (r.hasStarts) o.startLocations = malloc_ints(r.starts);
         if (r.hasAlignment) {
-            o.alignment = static_cast<unsigned char*>(malloc(std::max<size_t>(r.ops.size(), 1)));
-            if (!r.ops.empty()) memcpy(o.alignment, r.ops.data(), r.ops.size());
-            o.alignmentLength = (int)r.ops.size();
+            const uint8_t* src = r.opsView ? r.opsView : r.ops.data();
+            const size_t len = r.opsView ? (size_t)r.opsViewLen : r.ops.size();
+            o.alignment = static_cast<unsigned char*>(malloc(std::max<size_t>(len, 1)));
+            if (len) memcpy(o.alignment, src, len);
+            o.alignmentLength = (int)len;
         }
     }
     return 0;

@@ -35,8 +35,17 @@ struct SolveOut {
     std::vector<int> score, count, last;
     std::vector<long long> posStart;      // [units+1] into posFlat (exact, complete lists)
     std::vector<int> posFlat;
-    std::vector<long long> opsStart;      // [units+1] into ops
-    std::vector<uint8_t> ops;
+    // op strings stay where the D2H put them (pinned staging, one block per chunk); units point into it
+    std::vector<const uint8_t*> opsPtr;
+    std::vector<int> opsLen;
+    std::vector<std::shared_ptr<PinBuf>> opsBufs;
+};
+
+// Op string of one job: a view into a staging block, or an owned concatenation (Hirschberg pieces).
+struct OpsOut {
+    const uint8_t* p = nullptr;
+    int len = 0;
+    std::vector<uint8_t> own;
 };
 
 // Per-unit result assembled on the host before it is marshalled into
@@ -47,7 +56,9 @@ struct UnitResult {
     int alphabetLength = 0;
     bool hasEnds = false, hasStarts = false, hasAlignment = false;
     std::vector<int> ends, starts;
-    std::vector<uint8_t> ops;
+    std::vector<uint8_t> ops;                 // owned op string, or ...
+    const uint8_t* opsView = nullptr;         // ... a view into a staging block the batch keeps alive
+    int opsViewLen = 0;
 };
 
 class Batch {
@@ -118,7 +129,8 @@ private:
     struct Piece { long long qoff; int m; long long toff; int T; int score; };
     int hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& splitRow,
                         std::vector<int>& leftScore, std::vector<int>& rightScore);
-    int solvePaths(const std::vector<Piece>& jobs, std::vector<std::vector<uint8_t>>& opsOut, std::vector<int>& status);
+    int solvePaths(const std::vector<Piece>& jobs, std::vector<OpsOut>& opsOut, std::vector<int>& status);
+    std::vector<std::shared_ptr<PinBuf>> opsKeep_;      // staging blocks the last run's op views point into
 
     int qlen(int u) const { return (int)(qoff_[u + 1] - qoff_[u]); }
     long long tbase(int u) const { return shared_ ? toff_[0] : toff_[u]; }
