@@ -632,7 +632,7 @@ int Batch::collectReads(std::vector<UnitResult>& res)
 static const int kPosCap = 16;
 
 int Batch::solve(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units, SolveOut& out,
-                 bool nwBand)
+                 int ring)
 {
     const size_t n = units.size();
     out.score.assign(n, -1); out.count.assign(n, 0); out.last.assign(n, -1);
@@ -649,39 +649,42 @@ int Batch::solve(int mode, bool wantPositions, bool wantPath, const std::vector<
         while (b < n) {
             const long long nb = (units[b].qlen + 63) / 64;
             const long long pb = nb * tab_.sigmaT * 8;
-            const long long sb = wantPath ? pair_store_entries(units[b].qlen, units[b].tlen) * 20 : 0;
+            const long long sb = !wantPath ? 0 : 20 * (ring ? ring_store_entries(ring, units[b].qlen, units[b].tlen)
+                                                            : pair_store_entries(units[b].qlen, units[b].tlen));
             if (b > a && (peqBytes + pb > peqBudget || storeBytes + sb > storeBudget)) break;
             peqBytes += pb; storeBytes += sb; ++b;
         }
-        if (solveChunk(mode, wantPositions, wantPath, units, a, b, out, nwBand)) return 1;
+        if (solveChunk(mode, wantPositions, wantPath, units, a, b, out, ring)) return 1;
         a = b;
     }
     return 0;
 }
 
 int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units,
-                      size_t ua, size_t ub, SolveOut& out, bool nwBand)
+                      size_t ua, size_t ub, SolveOut& out, int ring)
 {
     const size_t n = ub - ua;
     Lap lap;
     std::vector<PairDesc> descs(n);
     std::vector<long long> opsOff(n + 1, 0);
-    long long peqWords = 0, auxInts = 0, storeEntries = 0;
+    long long peqWords = 0, auxInts = 0, storeEntries = 0, nbMax = 0;
     for (size_t i = 0; i < n; ++i) {
         const UnitSpec& s = units[ua + i];
         PairDesc& d = descs[i];
         const long long nb = (s.qlen + 63) / 64;
+        nbMax = std::max(nbMax, nb);
         d.qoff = s.qoff; d.toff = s.toff; d.qlen = s.qlen; d.tlen = s.tlen; d.qstep = s.qstep; d.tstep = s.tstep;
         d.kinit = s.kinit;
         d.peqOff = peqWords; peqWords += nb * tab_.sigmaT;
-        d.auxOff = auxInts; if (nb > 64) auxInts += s.tlen;
-        d.storeOff = storeEntries; if (wantPath) storeEntries += pair_store_entries(s.qlen, s.tlen);
+        d.auxOff = auxInts; if (nb > 64 && !ring) auxInts += s.tlen;
+        d.storeOff = storeEntries;
+        if (wantPath) storeEntries += ring ? ring_store_entries(ring, s.qlen, s.tlen) : pair_store_entries(s.qlen, s.tlen);
         d.posCap = wantPositions ? kPosCap : 0;
         d.posOff = (long long)i * kPosCap;
-        d.colOff = -1; d.bandT = 0; d.pad_ = 0;
+        d.colOff = -1; d.bandT = 0; d.ring = ring;
         opsOff[i + 1] = opsOff[i] + (wantPath ? (long long)s.qlen + s.tlen : 0);
         // executed work: whole matrix, or one 64-block wave per column inside the band
-        stats.word_steps += nwBand ? 2LL * 64 * ((long long)s.tlen + nb - 1) : 2 * nb * (long long)s.tlen;
+        stats.word_steps += ring ? 2LL * ring * ((long long)s.tlen + nb - 1) : 2 * nb * (long long)s.tlen;
     }
     EDLIB_AMD_HIP(d_descs_.ensure(n));
     EDLIB_AMD_HIP(d_peq64_.ensure((size_t)peqWords));
@@ -702,11 +705,13 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     PairScanArgs a{};
     a.descs = d_descs_.p; a.numUnits = (int)n; a.qpool = d_qpool_.p; a.tpool = d_tpool_.p;
     a.tlut = d_tlut_.p; a.sigmaT = tab_.sigmaT; a.peq = d_peq64_.p; a.aux = d_aux_.p;
+    a.peqFullStride = (int)std::min<long long>(nbMax * tab_.sigmaT, 1 << 20);
+    if (getenv("EDLIB_AMD_PEQFULL") && getenv("EDLIB_AMD_PEQFULL")[0] == '0') a.peqFullStride = 0;
     a.storeP = d_storeP_.p; a.storeM = d_storeM_.p; a.storeS = d_storeS_.p;
     a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p; a.posPool = d_posPool_.p;
     a.colP = nullptr; a.colM = nullptr; a.colS = nullptr;
     scanTimerStart();
-    if (nwBand) EDLIB_AMD_HIP(launch_scan_pairs_nwband(a, stream_));
+    if (ring) EDLIB_AMD_HIP(launch_scan_pairs_ring(ring, wantPath, a, stream_));
     else EDLIB_AMD_HIP(launch_scan_pairs(mode, wantPath, a, stream_));
     scanTimerStop();
     if (wantPath) {
@@ -846,7 +851,7 @@ int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& spli
         for (int side = 0; side < 2; ++side) {
             PairDesc& d = descs[2 * q + side];
             d.qlen = pc.m; d.kinit = banded ? pc.score : 0; d.posCap = 0; d.posOff = 0; d.storeOff = 0;
-            d.bandT = banded ? pc.T : 0; d.pad_ = 0;
+            d.bandT = banded ? pc.T : 0; d.ring = 0;
             if (side == 0) { d.qoff = pc.qoff; d.qstep = 1; d.toff = pc.toff; d.tstep = 1; d.tlen = lw; }
             else { d.qoff = pc.qoff + pc.m - 1; d.qstep = -1; d.toff = pc.toff + pc.T - 1; d.tstep = -1; d.tlen = rw; }
             d.peqOff = peqWords; peqWords += nb * tab_.sigmaT;
@@ -874,12 +879,17 @@ int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& spli
     a.qpool = d_qpool_.p; a.tpool = d_tpool_.p;
     a.tlut = d_tlut_.p; a.sigmaT = tab_.sigmaT; a.peq = d_peq64_.p; a.aux = d_aux_.p;
     a.posPool = d_posPool_.p;
+    {
+        long long nbMax = 0;
+        for (const Piece& pc : big) nbMax = std::max<long long>(nbMax, (pc.m + 63) / 64);
+        a.peqFullStride = (int)std::min<long long>(nbMax * tab_.sigmaT, 1 << 20);
+    }
     a.colP = colP.p; a.colM = colM.p; a.colS = colS.p;
     if (nBanded) {
         a.descs = d_descs_.p; a.numUnits = (int)(2 * nBanded);
         a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p;
         scanTimerStart();
-        EDLIB_AMD_HIP(launch_scan_pairs_nwband(a, stream_));
+        EDLIB_AMD_HIP(launch_scan_pairs_ring(64, false, a, stream_));
         scanTimerStop();
     }
     if (np > nBanded) {
@@ -948,14 +958,34 @@ int Batch::solvePaths(const std::vector<Piece>& jobs, std::vector<OpsOut>& opsOu
         if (status[j] != EDLIB_STATUS_OK) continue;
         for (size_t i = 0; i < pieces[j].size(); ++i) {
             const Piece& pc = pieces[j][i];
-            if (pc.m > 0 && pc.T > 0) { units.push_back(UnitSpec{pc.qoff, pc.m, 1, pc.toff, pc.T, 1, 0}); where.push_back({j, i}); }
+            // kinit = the piece's distance: the storing scan runs inside exactly that band (the reference's
+            // second call with k = bestScore, edlib.cpp:1196-1199)
+            if (pc.m > 0 && pc.T > 0) { units.push_back(UnitSpec{pc.qoff, pc.m, 1, pc.toff, pc.T, 1, pc.score}); where.push_back({j, i}); }
         }
     }
     lap("paths: levels+units");
-    SolveOut so;
-    if (solve(EDLIB_MODE_NW, false, true, units, so)) return 1;
+    // smallest ring that holds the band (or all blocks) of each leaf; strips when none does
+    std::vector<const uint8_t*> leafPtr(units.size(), nullptr); std::vector<int> leafLen(units.size(), 0);
+    {
+        const bool bandOff = getenv("EDLIB_AMD_NWBAND") && getenv("EDLIB_AMD_NWBAND")[0] == '0';
+        static const int rings[4] = {4, 16, 64, 0};
+        std::vector<int> ringOfUnit(units.size(), 0);
+        for (size_t u = 0; u < units.size(); ++u) {
+            const int nb = (units[u].qlen + 63) / 64;
+            for (int g = 0; g < 3 && !bandOff; ++g)
+                if (nb <= rings[g] || units[u].kinit <= ring_max_k(rings[g])) { ringOfUnit[u] = rings[g]; break; }
+        }
+        for (int g = 0; g < 4; ++g) {
+            std::vector<UnitSpec> sel; std::vector<size_t> who;
+            for (size_t u = 0; u < units.size(); ++u) if (ringOfUnit[u] == rings[g]) { sel.push_back(units[u]); who.push_back(u); }
+            if (sel.empty()) continue;
+            SolveOut so;
+            if (solve(EDLIB_MODE_NW, false, true, sel, so, rings[g])) return 1;
+            for (size_t q = 0; q < sel.size(); ++q) { leafPtr[who[q]] = so.opsPtr[q]; leafLen[who[q]] = so.opsLen[q]; }
+            opsKeep_.insert(opsKeep_.end(), so.opsBufs.begin(), so.opsBufs.end());
+        }
+    }
     lap("paths: solve");
-    opsKeep_.insert(opsKeep_.end(), so.opsBufs.begin(), so.opsBufs.end());
     // a job that was never split is its single leaf: hand out the view; split jobs concatenate their pieces
     std::vector<size_t> firstLeaf(nj + 1, 0);                 // leaves are listed job by job, piece by piece
     {
@@ -972,18 +1002,87 @@ int Batch::solvePaths(const std::vector<Piece>& jobs, std::vector<OpsOut>& opsOu
         OpsOut& o = opsOut[j];
         size_t u = firstLeaf[j];
         if (pieces[j].size() == 1 && pieces[j][0].m > 0 && pieces[j][0].T > 0) {
-            o.p = so.opsPtr[u]; o.len = so.opsLen[u];
+            o.p = leafPtr[u]; o.len = leafLen[u];
             continue;
         }
         for (size_t i = 0; i < pieces[j].size(); ++i) {
             const Piece& pc = pieces[j][i];
             if (pc.m == 0) o.own.insert(o.own.end(), (size_t)pc.T, (uint8_t)EDLIB_EDOP_DELETE);
             else if (pc.T == 0) o.own.insert(o.own.end(), (size_t)pc.m, (uint8_t)EDLIB_EDOP_INSERT);
-            else { o.own.insert(o.own.end(), so.opsPtr[u], so.opsPtr[u] + so.opsLen[u]); ++u; }
+            else { o.own.insert(o.own.end(), leafPtr[u], leafPtr[u] + leafLen[u]); ++u; }
         }
         o.p = o.own.data(); o.len = (int)o.own.size();
     }
     lap("paths: assemble");
+    return 0;
+}
+
+// ------------------------------------------------------ NW distance levels
+
+// The reference finds the NW distance by doubling k from 64 until the banded scan succeeds
+// (edlib.cpp:197-217); any threshold >= the distance gives the same answer, so the levels here are the
+// ring sizes of scan_pairs_ring_kernel: K = 128 on 4-lane rings (16 units per wave), K = 896 on 16-lane
+// rings, K = 3968 on whole waves, then the unbanded strips.  A unit whose blocks all fit a ring is exact on
+// it for any distance (threshold max(m, T)).  A failed level costs 1/16 or 1/4 of the next one, which is
+// pure waste when the whole batch is divergent, so larger batches first measure the divergence of 64
+// strided units on their 1 kb prefixes (one small launch) and every unit starts at the level that holds
+// its extrapolated distance.  The estimate only picks the starting level; results never depend on it.
+int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<int>& score)
+{
+    const size_t n = units.size();
+    score.assign(n, -1);
+    if (n == 0) return 0;
+    const bool bandOff = getenv("EDLIB_AMD_NWBAND") && getenv("EDLIB_AMD_NWBAND")[0] == '0';
+    static const int ringOf[3] = {4, 16, 64};
+    const int kInf = 0x3fffffff;
+    const int kcap = cfg_.k >= 0 ? cfg_.k : kInf;                       // answers above the caller's k are all alike
+    auto blocks = [&](size_t i) { return (units[i].qlen + 63) / 64; };
+
+    double rate = 0.0;                                                  // edits per base, upper quartile of the sample
+    if (n >= 256 && !bandOff && !getenv("EDLIB_AMD_NOPROBE")) {
+        const int np = 64, cut = 1024;
+        std::vector<UnitSpec> probe(np);
+        for (int i = 0; i < np; ++i) {
+            UnitSpec u = units[(size_t)((long long)i * n / np)];
+            u.qlen = std::min(u.qlen, cut); u.tlen = std::min(u.tlen, cut);
+            u.kinit = std::max(u.qlen, u.tlen);                         // 16 blocks at most: exact on a 16-lane ring
+            probe[i] = u;
+        }
+        SolveOut so;
+        if (solve(EDLIB_MODE_NW, false, false, probe, so, 16)) return 1;
+        std::vector<double> r(np);
+        for (int i = 0; i < np; ++i) r[i] = (double)so.score[i] / std::max(1, std::max(probe[i].qlen, probe[i].tlen));
+        std::sort(r.begin(), r.end());
+        rate = r[(np * 3) / 4];
+    }
+    // first level of a unit: the smallest ring that holds all its blocks or its extrapolated distance
+    auto first_level = [&](size_t i) {
+        const UnitSpec& u = units[i];
+        const double est = std::min<double>(kcap, 1.25 * rate * std::max(u.qlen, u.tlen) + std::abs(u.qlen - u.tlen) + 8);
+        for (int l = 0; l < 3; ++l)
+            if (blocks(i) <= ringOf[l] || est <= ring_max_k(ringOf[l])) return l;
+        return est <= 2.0 * ring_max_k(64) ? 2 : 3;                     // far above every band: straight to the strips
+    };
+    std::vector<int> lvl(n);
+    for (size_t i = 0; i < n; ++i) lvl[i] = bandOff ? 3 : first_level(i);
+    for (int l = 0; l <= 3; ++l) {
+        std::vector<UnitSpec> sel; std::vector<size_t> who;
+        for (size_t i = 0; i < n; ++i) {
+            if (lvl[i] != l) continue;
+            UnitSpec u = units[i];
+            if (l < 3) u.kinit = std::min(kcap, blocks(i) <= ringOf[l] ? std::max(u.qlen, u.tlen) : ring_max_k(ringOf[l]));
+            sel.push_back(u); who.push_back(i);
+        }
+        if (sel.empty()) continue;
+        SolveOut so;
+        if (solve(EDLIB_MODE_NW, false, false, sel, so, l < 3 ? ringOf[l] : 0)) return 1;
+        for (size_t q = 0; q < sel.size(); ++q) {
+            const size_t i = who[q];
+            if (l == 3 || so.score[q] <= sel[q].kinit) score[i] = so.score[q];          // exact
+            else if (sel[q].kinit >= kcap) score[i] = kInf;                              // > k: final
+            else lvl[i] = l + 1;                                                         // next level
+        }
+    }
     return 0;
 }
 
@@ -1027,34 +1126,8 @@ int Batch::run()
         }
         SolveOut so;
         if (scanMode == EDLIB_MODE_NW) {
-            // Queries of more than 64 blocks: one banded pass (threshold min(k, kMaxBandK): the band fits one
-            // wave whatever the length, edlib.cpp:744-830), then the exact unbanded strips only for the units
-            // whose distance exceeds that threshold.  Shorter queries are a single strip anyway.
-            const bool bandOff = getenv("EDLIB_AMD_NWBAND") && getenv("EDLIB_AMD_NWBAND")[0] == '0';
-            std::vector<UnitSpec> banded, plain; std::vector<size_t> bi, pi;
-            for (size_t i = 0; i < units.size(); ++i) {
-                const bool longq = units[i].qlen > 64 * 64 && !bandOff;
-                if (longq) {
-                    UnitSpec u = units[i];
-                    u.kinit = (cfg_.k >= 0 && cfg_.k < kMaxBandK) ? cfg_.k : kMaxBandK;
-                    banded.push_back(u); bi.push_back(i);
-                } else { plain.push_back(units[i]); pi.push_back(i); }
-            }
-            std::vector<int> score(units.size(), -1);
-            if (!banded.empty()) {
-                SolveOut sb;
-                if (solve(EDLIB_MODE_NW, false, false, banded, sb, true)) return 1;
-                for (size_t j = 0; j < banded.size(); ++j) {
-                    if (sb.score[j] <= banded[j].kinit) score[bi[j]] = sb.score[j];           // exact
-                    else if (cfg_.k >= 0 && cfg_.k <= banded[j].kinit) score[bi[j]] = 0x3fffffff;   // > k: final
-                    else { plain.push_back(units[bi[j]]); pi.push_back(bi[j]); }              // needs the full scan
-                }
-            }
-            if (!plain.empty()) {
-                SolveOut sp;
-                if (solve(EDLIB_MODE_NW, false, false, plain, sp)) return 1;
-                for (size_t j = 0; j < plain.size(); ++j) score[pi[j]] = sp.score[j];
-            }
+            std::vector<int> score;
+            if (solveGlobalDistances(units, score)) return 1;
             for (size_t i = 0; i < units.size(); ++i)
                 finalize_global(res[pairUnits_[i]], cfg_.k, mode, units[i].tlen, score[i]);
         } else {

@@ -119,11 +119,16 @@ private:
     DevBuf<int> d_storeS_, d_aux_, d_outScore_, d_outCount_, d_outLast_, d_posPool_, d_opsLen_, d_alpha_;
     DevBuf<uint8_t> d_ops_;
     DevBuf<long long> d_opsOff_;
-    // nwBand: NW distance inside Ukkonen's band for threshold UnitSpec::kinit (exact iff score <= kinit)
+    // ring = 0: unbanded strips (any mode).  ring = 4 / 16 / 64: NW inside Ukkonen's band for threshold
+    // UnitSpec::kinit on rings of that many lanes (exact iff score <= kinit); the caller guarantees that
+    // the band fits (kinit <= ring_max_k(ring), or the unit has at most `ring` blocks)
     int solve(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units, SolveOut& out,
-              bool nwBand = false);
+              int ring = 0);
     int solveChunk(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units,
-                   size_t a, size_t b, SolveOut& out, bool nwBand);
+                   size_t a, size_t b, SolveOut& out, int ring);
+    // NW distances by threshold levels on rings of 4, 16, 64 lanes, then unbanded (the reference's
+    // k-doubling, edlib.cpp:197-217, with thresholds chosen for the hardware)
+    int solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<int>& score);
     int alphabetLengths(const std::vector<int>& units, std::vector<UnitResult>& res);
     // linear-space paths (reference obtainAlignmentHirschberg, edlib.cpp:1231-1396)
     struct Piece { long long qoff; int m; long long toff; int T; int score; };

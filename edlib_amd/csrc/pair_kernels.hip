@@ -265,95 +265,164 @@ hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStr
 
 // ------------------------------------------------------- banded NW scan
 
-// NW distance inside Ukkonen's diagonal band for a fixed threshold K = desc.kinit (what the reference's
+// NW inside Ukkonen's diagonal band for a fixed threshold K = desc.kinit (what the reference's
 // first/lastBlock bookkeeping converges to, edlib.cpp:744-830): a path of cost <= K only visits
 // diagonals d = j - i in [dmin, dmax] = [min(0,D) - p, max(0,D) + p], D = T - m, p = (K - |D|) / 2.
-// Block b therefore lives for columns [64b + dmin, 64b + 63 + dmax]; at most 64 consecutive blocks are
-// alive at a time (K <= kMaxBandK), so ONE wave covers a query of any length:
-//   * blocks are mapped to lanes as a ring (block b -> lane b % 64).  When a lane's block leaves the band
-//     it re-arms for block b + 64: state "+1 per row" below the upstream block's bottom score, exactly the
-//     reference's new block (edlib.cpp:803-808); cells outside the band only ever enter as such upper
-//     bounds, so values <= K stay exact (Ukkonen);
-//   * same anti-diagonal schedule as scan_pairs_kernel (block b updates column t - b at step t), the
-//     carry moves by v_mov_b32_dpp wave_ror:1 (lane 63 feeds lane 0); a block whose upstream is outside
-//     the band (or block 0) takes hin = +1 (edlib.cpp:779);
-//   * target symbols are staged in a 256-entry LDS ring filled 64 columns per coalesced load; each lane
-//     reads the symbol of its next-but-one column and the Peq word of its next column while it computes
-//     the current one;
-//   * steps: T + numBlocks - 1 instead of (T + 63) per 64-block strip.
-template <bool LDSPEQ>
-__global__ void __launch_bounds__(64)
-scan_pairs_nwband_kernel(const PairScanArgs a)
+// Block b therefore lives for columns [64b + dmin, 64b + 63 + dmax], and fewer than G consecutive
+// blocks are alive at a time when K <= ring_max_k(G).  A RING of G lanes (G = 4, 16 or 64) therefore
+// covers a query of any length, and a wave carries 64 / G independent units:
+//   * blocks are mapped to the ring's lanes round-robin (block b -> ring lane b % G).  When a lane's
+//     block leaves the band it re-arms for block b + G: state "+1 per row" below the upstream block's
+//     bottom score, exactly the reference's new block (edlib.cpp:803-808); cells outside the band only
+//     ever enter as such upper bounds, so values <= K stay exact (Ukkonen);
+//   * same anti-diagonal schedule as scan_pairs_kernel (block b updates column t - b at step t); the
+//     carry moves one lane up the ring per step in one DPP move (wave_ror:1 / row_ror:1 / quad_perm,
+//     the last ring lane feeds the first); a block whose upstream is outside the band (or block 0)
+//     takes hin = +1 (edlib.cpp:779);
+//   * target symbols are staged in a 256-entry LDS ring per unit, filled 64 columns at a time; each
+//     lane reads the symbol of its next-but-one column and the Peq word of its next column while it
+//     computes the current one;
+//   * steps: T + numBlocks - 1 instead of (T + 63) per 64-block strip;
+//   * STORE: every block-step also writes (Pv, Mv, block score) at [step][ring lane] (G entries per
+//     step, coalesced per ring) for traceback_kernel -- the reference's AlignmentData restricted to
+//     first..lastBlock (edlib.cpp:883-893).
+// A unit whose blocks all fit the ring (numBlocks <= G) may use any K: with K = max(m, T) the band is
+// the whole matrix.
+template <int G> __device__ __forceinline__ int ring_ror(const int v)
 {
-    extern __shared__ __attribute__((aligned(16))) u64 s_dyn[];      // [sigmaT][64] Peq columns, then the target ring
-    u64* s_peq = s_dyn;
-    unsigned char* s_tgt = reinterpret_cast<unsigned char*>(s_dyn + (LDSPEQ ? a.sigmaT * 64 : 0));
+    if constexpr (G == 64) return __builtin_amdgcn_update_dpp(0, v, 0x13C /*wave_ror:1*/, 0xf, 0xf, false);
+    else if constexpr (G == 16) return __builtin_amdgcn_update_dpp(0, v, 0x121 /*row_ror:1*/, 0xf, 0xf, false);
+    else return __builtin_amdgcn_update_dpp(0, v, 0x93 /*quad_perm:[3,0,1,2]*/, 0xf, 0xf, false);
+}
+
+__host__ __device__ static inline long long ring_index(int G, int c, int b) {
+    return (long long)(c + b) * G + (b & (G - 1));
+}
+long long ring_store_entries(int G, int qlen, int tlen) {
+    return ((long long)tlen + num_blocks(qlen) - 1) * G;
+}
+
+// PEQ: where a lane finds the Peq word of (symbol, its block):
+//   0  HBM pool (more than 32 target symbols)
+//   1  LDS slice [symbol][lane], refilled from the pool whenever the lane re-arms for a new block
+//   2  the unit's whole Peq in LDS ([unit in wave][symbol][block], a.peqFullStride words per unit):
+//      no refills, chosen by the launcher when it fits 16 KB per wave
+template <int G, bool STORE, int PEQ>
+__global__ void __launch_bounds__(64)
+scan_pairs_ring_kernel(const PairScanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 s_dyn[];      // Peq words, then the target rings
+    constexpr int U = 64 / G;                                         // units per wave
+    constexpr bool LDSPEQ = PEQ == 1;
     const int lane = threadIdx.x;
-    const int unit = blockIdx.x;
-    const PairDesc d = a.descs[unit];
-    const int m = d.qlen, T = d.tlen, K = d.kinit;      // T: columns to process (the scan stops at column T-1)
+    const int rl = lane & (G - 1), uw = lane / G;                     // lane within the ring, ring within the wave
+    const int peqWords = PEQ == 1 ? a.sigmaT * 64 : (PEQ == 2 ? U * a.peqFullStride : 0);
+    u64* s_peq = s_dyn + (PEQ == 2 ? uw * a.peqFullStride : 0);
+    unsigned char* s_tgt = reinterpret_cast<unsigned char*>(s_dyn + peqWords) + uw * 256;
+    const int unit = blockIdx.x * U + uw;
+    const bool have = unit < a.numUnits;
+    const PairDesc* dp = a.descs + (have ? unit : 0);
+    // a whole-wave ring keeps its descriptor in SGPRs (38 instead of 70 VGPRs: one more wave per SIMD)
+    auto uni = [](int v) { return G == 64 ? __builtin_amdgcn_readfirstlane(v) : v; };
+    auto uni64 = [&](long long v) {
+        return G == 64 ? (long long)(((u64)(u32)uni((int)((u64)v >> 32)) << 32) | (u32)uni((int)(u32)(u64)v)) : v;
+    };
+    const int m = uni(dp->qlen), T = uni(dp->tlen), K = uni(dp->kinit);   // T: columns to process (the scan stops at column T-1)
+    const int bandT = uni(dp->bandT);
+    // rarely used descriptor fields: SGPRs for a whole-wave ring, re-read from the descriptor (L1/L2) by the
+    // packed rings, whose VGPR budget decides the occupancy
+    const int tstepU = G == 64 ? uni(dp->tstep) : 0;
+    const long long toffU = G == 64 ? uni64(dp->toff) : 0, peqOffU = G == 64 ? uni64(dp->peqOff) : 0;
+    const long long colOffU = G == 64 ? uni64(dp->colOff) : 0;
+    auto tstep_ = [&]() { return G == 64 ? tstepU : dp->tstep; };
+    auto toff_ = [&]() { return G == 64 ? toffU : dp->toff; };
+    auto peqOff_ = [&]() { return G == 64 ? peqOffU : dp->peqOff; };
+    const long long storeOff = STORE ? uni64(dp->storeOff) : 0;
     const int nb = num_blocks(m);
-    const int D = (d.bandT ? d.bandT : T) - m, absD = D < 0 ? -D : D;   // the band is that of the whole problem
-    const bool dumpCol = a.colP != nullptr && d.colOff >= 0;
-    if (K < absD) { if (lane == 0) { a.outScore[unit] = 0x3fffffff; a.outCount[unit] = 0; a.outLast[unit] = -1; } return; }
+    const int D = (bandT ? bandT : T) - m, absD = D < 0 ? -D : D;     // the band is that of the whole problem
+    const bool dumpCol = G == 64 && a.colP != nullptr && colOffU >= 0;   // Hirschberg halves run on whole waves
+    const bool active = have && K >= absD;
+    if (have && !active && rl == 0) { a.outScore[unit] = 0x3fffffff; a.outCount[unit] = 0; a.outLast[unit] = -1; }
+    if (__builtin_amdgcn_ballot_w64(active) == 0ull) return;
     const int p = (K - absD) >> 1;
     const int dmin = (D < 0 ? D : 0) - p, dmax = (D > 0 ? D : 0) + p;
     const u32 sh = (u32)(m - 1) & 63u;
     const int lastRows = m - 64 * (nb - 1);                           // query rows in the last block
+    const int nbA = active ? nb : 0;                                  // idle rings own no block
 
     // ---- target ring: columns [0, loaded) are in s_tgt[col & 255]
     int loaded = 0;
-    auto refill = [&]() {                                             // 64 more columns, coalesced
-        const int c = loaded + lane;
-        s_tgt[c & 255] = (c < T) ? a.tlut[a.tpool[d.toff + (long long)c * d.tstep]] : 0;
+    auto refill = [&]() {                                             // 64 more columns per ring
+        const long long toff = toff_(); const int tstep = tstep_();
+        for (int i = rl; i < 64; i += G) {
+            const int c = loaded + i;
+            s_tgt[c & 255] = (c < T) ? a.tlut[a.tpool[toff + (long long)c * tstep]] : 0;
+        }
         loaded += 64;
     };
-    for (int i = lane; i < 256; i += 64) s_tgt[i] = 0;                // never index Peq with an unwritten slot
-    refill(); refill(); refill();                                     // 192 columns ahead of column 0
+    for (int i = rl; i < 256; i += G) s_tgt[i] = 0;                   // never index Peq with an unwritten slot
+    if (active) { refill(); refill(); refill(); }                     // 192 columns ahead of column 0
+    if (PEQ == 2 && active) {
+        const long long peqOff = peqOff_();
+        for (int i = rl; i < a.sigmaT * nb; i += G) s_peq[i] = a.peq[peqOff + i];
+    }
+    auto peq_word = [&](int sym, int blk) -> u64 {
+        if (PEQ == 2) return s_peq[sym * nb + blk];
+        if (PEQ == 1) return s_peq[sym * 64 + lane];
+        return a.peq[peqOff_() + (long long)sym * nb + blk];
+    };
 
     // ---- per-lane block bookkeeping
-    int b = lane;                                                     // current (or next) block of this lane
+    int b = rl;                                                       // current (or next) block of this lane
     auto first_col = [&](int blk) { const int c = 64 * blk + dmin; return c < 0 ? 0 : c; };
     auto last_col = [&](int blk) { const int c = 64 * blk + 63 + dmax; return c > T - 1 ? T - 1 : c; };
-    int tstart = (b < nb && first_col(b) <= last_col(b)) ? first_col(b) + b : 0x7fffffff;
-    int tend = (b < nb) ? last_col(b) + b : -1;
+    int tstart = (b < nbA && first_col(b) <= last_col(b)) ? first_col(b) + b : 0x7fffffff;
+    int tend = (b < nbA) ? last_col(b) + b : -1;
     int upLast = (b > 0) ? last_col(b - 1) : -1;                      // last column the upstream block delivers
 
     Block64 B{~0u, ~0u, 0u, 0u};
     int bscore = 0, sc = 0, carry = 0, symNxt = 0;
     u64 eqCur = 0;
-    const int nsteps = T + nb - 1;
+    int nsteps = active ? T + nb - 1 : 0;
+    if constexpr (G == 64) nsteps = __builtin_amdgcn_readfirstlane(nsteps);
+    else {                                          // the wave runs for its longest unit
+        int w = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int v = __builtin_amdgcn_readlane(nsteps, u * G); w = v > w ? v : w; }
+        nsteps = w;
+    }
 
     for (int t = 0; t < nsteps; ++t) {
         if ((t & 63) == 0) {                                          // pace the ring by the largest column in use
             int bt = t - 63 - dmax; bt = bt <= 0 ? 0 : (bt + 64) / 65;
             if (t - T + 1 > bt) bt = t - T + 1;
             const int jmax = t - bt;
-            while (loaded < T && loaded < jmax + 64 + 67) refill();
+            while (active && loaded < T && loaded < jmax + 64 + 67) refill();
         }
-        const int x = __builtin_amdgcn_update_dpp(0, carry, 0x13C /*wave_ror:1*/, 0xf, 0xf, false);
+        const int x = ring_ror<G>(carry);
         // upstream's bottom score travels only when some lane starts a block at this step
         const bool starting = (t == tstart);
         int upScore = 0;
-        if (__builtin_amdgcn_ballot_w64(starting) != 0ull)
-            upScore = __builtin_amdgcn_update_dpp(0, bscore, 0x13C, 0xf, 0xf, false);
+        if (__builtin_amdgcn_ballot_w64(starting) != 0ull) upScore = ring_ror<G>(bscore);
         const int col = t - b;
         if (starting) {
             // (re)arm: Peq column of the new block, fresh "+1 per row" state (edlib.cpp:759-763, 803-808)
-            if (LDSPEQ)
-                for (int sy = 0; sy < a.sigmaT; ++sy) s_peq[sy * 64 + lane] = a.peq[d.peqOff + (long long)sy * nb + b];
+            if (LDSPEQ) {
+                const long long peqOff = peqOff_();
+                for (int sy = 0; sy < a.sigmaT; ++sy) s_peq[sy * 64 + lane] = a.peq[peqOff + (long long)sy * nb + b];
+            }
             B = Block64{~0u, ~0u, 0u, 0u};
             const int hp0 = x & 1, hn0 = (x >> 1) & 1;                // upstream's delta at column `col`
             const int above = (col == 0) ? 64 * b : (upScore - (hp0 - hn0));   // bottom of the block above, column col-1
             bscore = above + 64;
             if (b == nb - 1) sc = above + lastRows;
             const int s0 = s_tgt[col & 255];
-            eqCur = LDSPEQ ? s_peq[s0 * 64 + lane] : a.peq[d.peqOff + (long long)s0 * nb + b];
+            eqCur = peq_word(s0, b);
             symNxt = s_tgt[(col + 1) & 255];
         }
         u32 hp = 0, hn = 0;
         if (t >= tstart && t <= tend) {
-            const u64 eqNxt = LDSPEQ ? s_peq[symNxt * 64 + lane] : a.peq[d.peqOff + (long long)symNxt * nb + b];
+            const u64 eqNxt = peq_word(symNxt, b);
             const int symNN = s_tgt[(col + 2) & 255];
             const bool fromUp = (b > 0) && (col <= upLast);
             const u32 hpos = fromUp ? ((u32)x & 1u) : 1u, hneg = fromUp ? (((u32)x >> 1) & 1u) : 0u;
@@ -361,38 +430,61 @@ scan_pairs_nwband_kernel(const PairScanArgs a)
             advance_block64(B, (u32)eqCur, (u32)(eqCur >> 32), hpos, hneg, ph0, ph1, mh0, mh1);
             hp = ph1 >> 31; hn = mh1 >> 31;
             bscore += (int)hp - (int)hn;
+            if (STORE) {
+                const long long si = storeOff + (long long)t * G + rl;
+                a.storeP[si] = ((u64)B.p1 << 32) | B.p0; a.storeM[si] = ((u64)B.m1 << 32) | B.m0; a.storeS[si] = bscore;
+            }
             if (b == nb - 1) {
                 const u64 ph = ((u64)ph1 << 32) | ph0, mh = ((u64)mh1 << 32) | mh0;
                 sc += (int)((ph >> sh) & 1ull) - (int)((mh >> sh) & 1ull);
                 if (col == T - 1) { a.outScore[unit] = sc; a.outCount[unit] = 1; a.outLast[unit] = T - 1; }
             }
             if (dumpCol && col == T - 1) {                            // stop column of a Hirschberg half
-                a.colP[d.colOff + b] = ((u64)B.p1 << 32) | B.p0; a.colM[d.colOff + b] = ((u64)B.m1 << 32) | B.m0;
-                a.colS[d.colOff + b] = bscore;
+                a.colP[colOffU + b] = ((u64)B.p1 << 32) | B.p0; a.colM[colOffU + b] = ((u64)B.m1 << 32) | B.m0;
+                a.colS[colOffU + b] = bscore;
             }
             eqCur = eqNxt; symNxt = symNN;
         }
         carry = (int)(hp | (hn << 1));
-        if (t >= tend && b < nb) {                                    // block done: re-arm this lane for block b + 64
-            b += 64;
-            const bool ok = b < nb && first_col(b) <= last_col(b);
+        if (t >= tend && b < nbA) {                                   // block done: re-arm this lane for block b + G
+            b += G;
+            const bool ok = b < nbA && first_col(b) <= last_col(b);
             tstart = ok ? first_col(b) + b : 0x7fffffff;
-            tend = (b < nb) ? last_col(b) + b : -1;
+            tend = (b < nbA) ? last_col(b) + b : -1;
             upLast = last_col(b - 1);
         }
     }
 }
 
-hipError_t launch_scan_pairs_nwband(const PairScanArgs& a, hipStream_t stream)
+template <int G, bool STORE>
+static hipError_t launch_scan_pairs_ring_t(const PairScanArgs& a, hipStream_t stream)
 {
-    if (a.numUnits == 0) return hipSuccess;
-    if (a.sigmaT <= 32) {
-        const size_t lds = (size_t)a.sigmaT * 64 * sizeof(u64) + 256;
-        hipLaunchKernelGGL((scan_pairs_nwband_kernel<true>), dim3(a.numUnits), dim3(64), lds, stream, a);
+    constexpr int U = 64 / G;
+    const dim3 grid((a.numUnits + U - 1) / U);
+    const size_t full = (size_t)U * a.peqFullStride * sizeof(u64);
+    if (G < 64 && a.peqFullStride > 0 && full <= 16384) {     // whole-wave rings: the conflict-free slice is faster
+        hipLaunchKernelGGL((scan_pairs_ring_kernel<G, STORE, 2>), grid, dim3(64), full + 256 * U, stream, a);
+    } else if (a.sigmaT <= 32) {
+        const size_t lds = (size_t)a.sigmaT * 64 * sizeof(u64) + 256 * U;
+        hipLaunchKernelGGL((scan_pairs_ring_kernel<G, STORE, 1>), grid, dim3(64), lds, stream, a);
     } else {
-        hipLaunchKernelGGL((scan_pairs_nwband_kernel<false>), dim3(a.numUnits), dim3(64), 256, stream, a);
+        hipLaunchKernelGGL((scan_pairs_ring_kernel<G, STORE, 0>), grid, dim3(64), 256 * U, stream, a);
     }
     return hipGetLastError();
+}
+
+hipError_t launch_scan_pairs_ring(int G, bool store, const PairScanArgs& a, hipStream_t stream)
+{
+    if (a.numUnits == 0) return hipSuccess;
+    switch (G * 2 + (store ? 1 : 0)) {
+        case 8: return launch_scan_pairs_ring_t<4, false>(a, stream);
+        case 9: return launch_scan_pairs_ring_t<4, true>(a, stream);
+        case 32: return launch_scan_pairs_ring_t<16, false>(a, stream);
+        case 33: return launch_scan_pairs_ring_t<16, true>(a, stream);
+        case 128: return launch_scan_pairs_ring_t<64, false>(a, stream);
+        case 129: return launch_scan_pairs_ring_t<64, true>(a, stream);
+    }
+    return hipErrorInvalidValue;
 }
 
 // ------------------------------------------------------- Hirschberg split
@@ -470,19 +562,33 @@ traceback_kernel(const TracebackArgs a)
     const u64* SP = a.storeP + d.storeOff;
     const u64* SM = a.storeM + d.storeOff;
     const int* SS = a.storeS + d.storeOff;
+    // ring layout (scan_pairs_ring_kernel): only the blocks inside the band of threshold kinit exist.
+    // The walk stays on cells of optimal paths, which are inside the band and exact; a neighbour outside
+    // the band can never be "one less than here", so it is simply not a candidate (the reference's
+    // stored band behaves the same, edlib.cpp:996-1016).
+    const int G = d.ring;
+    int dmin = 0;
+    if (G) {
+        const int D = T - m, absD = D < 0 ? -D : D, p = (d.kinit - absD) >> 1;
+        dmin = (D < 0 ? D : 0) - p;
+    }
+    const int kInf = 0x3fffffff;
     for (;;) {
         const int b = r >> 6, bit = r & 63;
-        const long long ic = store_index(T, nb, c, b);
+        const long long ic = G ? ring_index(G, c, b) : store_index(T, nb, c, b);
         const u64 Pc = SP[ic], Mc = SM[ic];
         const int u = cur - ((int)((Pc >> bit) & 1ull) - (int)((Mc >> bit) & 1ull));
         int l, ul;
         if (c == 0) { l = r + 1; ul = r; }          // column -1 boundary (:976-980)
-        else {
-            const long long il = store_index(T, nb, c - 1, b);
+        else if (!G || c - 1 >= 64 * b + dmin) {    // block b exists in column c-1
+            const long long il = G ? ring_index(G, c - 1, b) : store_index(T, nb, c - 1, b);
             const u64 Pl = SP[il], Ml = SM[il];
             const u64 above = (bit == 63) ? 0ull : (~0ull << (bit + 1));   // rows below r in the block
             l = SS[il] - __popcll(Pl & above) + __popcll(Ml & above);
             ul = l - ((int)((Pl >> bit) & 1ull) - (int)((Ml >> bit) & 1ull));
+        } else {                                     // left edge of the band: only the diagonal neighbour may
+            l = kInf;                                // exist, as the bottom cell of the block above
+            ul = (bit == 0 && b > 0) ? SS[ring_index(G, c - 1, b - 1)] : kInf;
         }
         if (u + 1 == cur) {                          // up: INSERT
             cur = u;

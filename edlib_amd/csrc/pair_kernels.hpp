@@ -27,7 +27,8 @@ struct PairDesc {
     long long colOff;    // first block of this unit's last-column dump (Hirschberg), or -1
     int bandT;           // banded NW kernel: target length that defines the band when the scan stops early
                          // at column tlen-1 (Hirschberg halves, edlib.cpp:1252-1260); 0 = tlen
-    int pad_;
+    int ring;            // layout of this unit's column store: 0 = strips (scan_pairs_kernel), else the ring
+                         // size G of scan_pairs_ring_kernel (band of threshold kinit)
 };
 
 struct PairScanArgs {
@@ -38,6 +39,7 @@ struct PairScanArgs {
     const uint8_t* tlut;        // [256] target byte -> symbol id (row of Peq)
     int sigmaT;                 // number of target symbols (rows of Peq)
     const unsigned long long* peq;   // Peq pool, built by launch_build_peq_pairs
+    int peqFullStride;          // ring kernel: sigmaT * (largest block count of the launch), 0 = unknown
     int* aux;                   // strip hand-off pool (horizontal deltas of a strip's bottom row)
     // column store for the traceback (may be null): anti-diagonal order, see pair_kernels.hip
     unsigned long long* storeP;
@@ -57,13 +59,16 @@ struct PairScanArgs {
 // mode: 0 NW, 1 SHW, 2 HW.  store: also write the column store.
 hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStream_t stream);
 
-// NW distance with Ukkonen's diagonal band for threshold desc.kinit (reference
-// myersCalcEditDistanceNW with a fixed k, edlib.cpp:730-928): exact whenever the distance is <= kinit,
-// otherwise some value > kinit.  The band must fit 64 blocks (kinit <= kMaxBandK); one wave per unit
-// whatever the query length (no strips).  Writes outScore and, when colP is set, the (P, M, score) of the
-// blocks alive at the last processed column (the caller pre-fills the dump with "invalid").
-constexpr int kMaxBandK = 3968;
-hipError_t launch_scan_pairs_nwband(const PairScanArgs& a, hipStream_t stream);
+// NW with Ukkonen's diagonal band for threshold desc.kinit (reference myersCalcEditDistanceNW with a
+// fixed k, edlib.cpp:730-928): exact whenever the distance is <= kinit, otherwise some value > kinit.
+// ringLanes G in {4, 16, 64}: the band must fit the ring (kinit <= ring_max_k(G), or numBlocks <= G and any
+// kinit); a wave carries 64 / G units, whatever the query length (no strips).  Writes outScore and, when
+// colP is set, the (P, M, score) of the blocks alive at the last processed column (the caller pre-fills
+// the dump with "invalid").  store: also the column store in ring layout (ring_store_entries per unit).
+constexpr int ring_max_k(int G) { return 64 * G - 128; }
+constexpr int kMaxBandK = ring_max_k(64);
+hipError_t launch_scan_pairs_ring(int ringLanes, bool store, const PairScanArgs& a, hipStream_t stream);
+long long ring_store_entries(int ringLanes, int qlen, int tlen);
 
 // reference buildPeq (edlib.cpp:358-384) for every unit: Peq[sym][block] from the
 // query bytes and the 256x256 byte equality matrix eq8 (identity + additionalEqualities).
