@@ -1,0 +1,159 @@
+"""-m gpu: the banded lane-ring NW kernels (scan_pairs_ring_kernel, 4 / 16 / 64 lanes per unit) and
+the banded column store + traceback behind EDLIB_TASK_PATH, against the compiled reference (or the
+oracle restatement where it did not travel).
+
+Directed at what the generic fuzz only hits by chance: distances right at the level thresholds
+(128, 896, 3968), block counts right at the ring sizes (4, 16, 64 blocks), mixed batches whose units
+resolve at different levels, batches large enough to take the prefix divergence probe, fixed k, rings
+sharing a wave with idle rings, and paths that run along the edge of the band."""
+import random
+
+import numpy as np
+import pytest
+
+from edlib_amd import synth
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("status", "editDistance", "endLocations", "startLocations", "numLocations",
+          "alignment", "alignmentLength", "alphabetLength")
+
+
+def _impl(ref, oracle):
+    return ref if ref is not None else oracle
+
+
+def _check(engine, impl, qs, ts, mode, task, k, what):
+    got = engine.align_pairs(qs, ts, mode=mode, task=task, k=k, raw=True)
+    bad = []
+    for i, (q, t, g) in enumerate(zip(qs, ts, got)):
+        want = impl.align(q, t, mode, task, k)
+        if want["status"] == 2:                       # oracle restatement: Hirschberg regime unsupported
+            continue
+        if any(g[f] != want[f] for f in FIELDS):
+            bad.append((i, len(q), len(t), {f: (g[f], want[f]) for f in FIELDS if g[f] != want[f] and f != "alignment"}))
+    assert not bad, (what, mode, task, k, bad[:3])
+
+
+def _pair_with_edits(rng, n, edits, indel_frac=0.5):
+    """A random n-base target and a query exactly `edits` scattered edit operations away (the true
+    distance is <= edits and usually equal for sparse edits)."""
+    t = synth.random_dna(rng.randrange(1 << 30), n).tobytes()
+    q = bytearray(t)
+    for _ in range(edits):
+        p = rng.randrange(len(q))
+        x = rng.random()
+        if x < indel_frac / 2 and len(q) > 1:
+            del q[p]
+        elif x < indel_frac:
+            q.insert(p, rng.choice(b"ACGT"))
+        else:
+            q[p] = rng.choice([c for c in b"ACGT" if c != q[p]])
+    return bytes(q), t
+
+
+def test_distances_at_level_thresholds(engine, ref, oracle):
+    """Distances just below / at / above 128, 896 and 3968 (ring_max_k of the three ring sizes)."""
+    rng = random.Random(4101)
+    impl = _impl(ref, oracle)
+    qs, ts = [], []
+    for n, edits in ((6000, 120), (6000, 127), (6000, 128), (6000, 129), (6000, 135),
+                     (9000, 880), (9000, 896), (9000, 900), (9000, 930),
+                     (30000, 3900), (30000, 3968), (30000, 3975), (30000, 4100)):
+        for _ in range(2):
+            q, t = _pair_with_edits(rng, n, edits, indel_frac=0.2)
+            qs.append(q); ts.append(t)
+    _check(engine, impl, qs, ts, "NW", "distance", -1, "thresholds")
+    for k in (127, 128, 129, 896, 3968, 5000):
+        _check(engine, impl, qs[:18], ts[:18], "NW", "distance", k, "thresholds fixed k")
+
+
+def test_block_counts_at_ring_sizes(engine, ref, oracle):
+    """Queries of 1..5, 15..17 and 63..65 blocks, similar and unrelated targets, distance and path."""
+    rng = random.Random(4102)
+    impl = _impl(ref, oracle)
+    for task in ("distance", "path"):
+        qs, ts = [], []
+        for m in (1, 63, 64, 65, 255, 256, 257, 320, 960, 1023, 1024, 1025, 1088, 4032, 4096, 4097, 4160):
+            if task == "path" and m > 1100:
+                continue
+            for rate in (0.0, 0.03, 0.25):
+                t = synth.random_dna(rng.randrange(1 << 30), m + rng.randrange(-m // 8, m // 8 + 1) if m > 8 else m)
+                q, _ = synth.mutate(t, rng.randrange(1 << 30), rate, rate / 3, rate / 3)
+                q = q[:m] if len(q) >= m else np.concatenate([q, synth.random_dna(rng.randrange(1 << 30), m - len(q))])
+                qs.append(q.tobytes()); ts.append(t.tobytes())
+            # unrelated pair: distance close to max(m, T), the band is the whole matrix
+            qs.append(synth.random_dna(rng.randrange(1 << 30), m).tobytes())
+            ts.append(synth.random_dna(rng.randrange(1 << 30), max(1, m // 2)).tobytes())
+        _check(engine, impl, qs, ts, "NW", task, -1, "ring sizes")
+
+
+def test_mixed_levels_and_probe(engine, ref, oracle):
+    """A batch of > 256 units (takes the divergence probe) whose units need different levels; the
+    sample checked against the reference covers every kind."""
+    rng = random.Random(4103)
+    impl = _impl(ref, oracle)
+    qs, ts, kinds = [], [], []
+    for i in range(600):
+        kind = i % 6
+        n = (200, 1000, 1000, 3000, 8000, 300)[kind]
+        rate = (0.02, 0.01, 0.3, 0.05, 0.15, 0.6)[kind]
+        t = synth.random_dna(rng.randrange(1 << 30), n + rng.randrange(0, 50))
+        q, _ = synth.mutate(t, rng.randrange(1 << 30), rate, rate / 4, rate / 4)
+        qs.append(q.tobytes() or b"A"); ts.append(t.tobytes()); kinds.append(kind)
+    got = engine.align_pairs(qs, ts, mode="NW", task="distance", k=-1, raw=True)
+    for i in list(range(0, 600, 7)) + list(range(590, 600)):
+        want = impl.align(qs[i], ts[i], "NW", "distance", -1)
+        assert all(got[i][f] == want[f] for f in FIELDS), (i, kinds[i], got[i], want)
+    # the same batch with paths for the short kinds only (1 kb paths are the traceback branch)
+    sel = [i for i in range(600) if kinds[i] in (0, 1, 2, 5)][:200]
+    _check(engine, impl, [qs[i] for i in sel], [ts[i] for i in sel], "NW", "path", -1, "mixed paths")
+
+
+def test_paths_along_the_band_edge(engine, ref, oracle):
+    """All edits of one kind at one end: the optimal path hugs the lowest / highest diagonal of the
+    band, where a block's left neighbour column is outside the band and the diagonal neighbour is the
+    bottom cell of the block above (traceback_kernel, ring layout)."""
+    rng = random.Random(4104)
+    impl = _impl(ref, oracle)
+    qs, ts = [], []
+    for n in (64, 128, 129, 640, 1000):
+        t = synth.random_dna(rng.randrange(1 << 30), n).tobytes()
+        for d in (1, 2, 63, 64, 65, 100):
+            if d >= n:
+                continue
+            ins = bytes(rng.choice(b"ACGT") for _ in range(d))
+            qs += [ins + t, t + ins, t[d:], t[:-d], t[:n // 2] + ins + t[n // 2:], ins + t[:-d], t[d:] + ins]
+            ts += [t] * 7
+    for mode in ("NW", "HW", "SHW"):
+        _check(engine, impl, qs, ts, mode, "path", -1, "band edge")
+
+
+def test_low_complexity_paths(engine, ref, oracle):
+    """Tie-rich inputs (1-3 letter alphabets): every tie must break as in the reference (up > left > diagonal)."""
+    rng = random.Random(4105)
+    impl = _impl(ref, oracle)
+    qs, ts = [], []
+    for _ in range(120):
+        sigma = rng.choice([1, 2, 2, 3])
+        m, n = rng.randrange(1, 700), rng.randrange(1, 700)
+        qs.append(bytes(rng.choice(b"ACG"[:sigma]) for _ in range(m)))
+        ts.append(bytes(rng.choice(b"ACG"[:sigma]) for _ in range(n)))
+    for mode in ("NW", "HW", "SHW"):
+        _check(engine, impl, qs, ts, mode, "path", -1, "ties")
+    _check(engine, impl, qs, ts, "NW", "path", 150, "ties fixed k")
+
+
+def test_wide_alphabet_rings(engine, ref, oracle):
+    """More than 32 target symbols: the ring kernels gather Peq from the HBM pool."""
+    rng = random.Random(4106)
+    impl = _impl(ref, oracle)
+    qs, ts = [], []
+    for _ in range(40):
+        n = rng.randrange(50, 2500)
+        t = bytes(rng.randrange(33, 120) for _ in range(n))
+        q = bytearray(t)
+        for _ in range(rng.randrange(0, n // 5 + 1)):
+            q[rng.randrange(len(q))] = rng.randrange(33, 120)
+        qs.append(bytes(q)); ts.append(t)
+    _check(engine, impl, qs, ts, "NW", "distance", -1, "wide alphabet")
+    _check(engine, impl, qs[:20], ts[:20], "NW", "path", -1, "wide alphabet")
