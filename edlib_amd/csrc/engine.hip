@@ -649,7 +649,7 @@ int Batch::solve(int mode, bool wantPositions, bool wantPath, const std::vector<
         while (b < n) {
             const long long nb = (units[b].qlen + 63) / 64;
             const long long pb = nb * tab_.sigmaT * 8;
-            const long long sb = !wantPath ? 0 : 20 * (ring ? ring_store_entries(ring, units[b].qlen, units[b].tlen)
+            const long long sb = !wantPath ? 0 : (long long)sizeof(StoreEntry) * (ring ? ring_store_entries(ring, units[b].qlen, units[b].tlen)
                                                             : pair_store_entries(units[b].qlen, units[b].tlen));
             if (b > a && (peqBytes + pb > peqBudget || storeBytes + sb > storeBudget)) break;
             peqBytes += pb; storeBytes += sb; ++b;
@@ -692,8 +692,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     EDLIB_AMD_HIP(d_outScore_.ensure(n)); EDLIB_AMD_HIP(d_outCount_.ensure(n)); EDLIB_AMD_HIP(d_outLast_.ensure(n));
     EDLIB_AMD_HIP(d_posPool_.ensure(n * kPosCap));
     if (wantPath) {
-        EDLIB_AMD_HIP(d_storeP_.ensure((size_t)storeEntries)); EDLIB_AMD_HIP(d_storeM_.ensure((size_t)storeEntries));
-        EDLIB_AMD_HIP(d_storeS_.ensure((size_t)storeEntries));
+        EDLIB_AMD_HIP(d_store_.ensure((size_t)storeEntries));
         EDLIB_AMD_HIP(d_ops_.ensure((size_t)opsOff[n])); EDLIB_AMD_HIP(d_opsOff_.ensure(n + 1));
         EDLIB_AMD_HIP(d_opsLen_.ensure(n));
         EDLIB_AMD_HIP(hipMemcpyAsync(d_opsOff_.p, opsOff.data(), (n + 1) * sizeof(long long), hipMemcpyHostToDevice, stream_));
@@ -707,7 +706,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     a.tlut = d_tlut_.p; a.sigmaT = tab_.sigmaT; a.peq = d_peq64_.p; a.aux = d_aux_.p;
     a.peqFullStride = (int)std::min<long long>(nbMax * tab_.sigmaT, 1 << 20);
     if (getenv("EDLIB_AMD_PEQFULL") && getenv("EDLIB_AMD_PEQFULL")[0] == '0') a.peqFullStride = 0;
-    a.storeP = d_storeP_.p; a.storeM = d_storeM_.p; a.storeS = d_storeS_.p;
+    a.store = d_store_.p;
     a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p; a.posPool = d_posPool_.p;
     a.colP = nullptr; a.colM = nullptr; a.colS = nullptr;
     scanTimerStart();
@@ -717,7 +716,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     if (wantPath) {
         TracebackArgs tb{};
         tb.descs = d_descs_.p; tb.numUnits = (int)n; tb.score = d_outScore_.p;
-        tb.storeP = d_storeP_.p; tb.storeM = d_storeM_.p; tb.storeS = d_storeS_.p;
+        tb.store = d_store_.p;
         tb.ops = d_ops_.p; tb.opsOff = d_opsOff_.p; tb.opsLen = d_opsLen_.p;
         EDLIB_AMD_HIP(launch_traceback(tb, stream_));
     }
@@ -922,11 +921,16 @@ int Batch::solvePaths(const std::vector<Piece>& jobs, std::vector<OpsOut>& opsOu
     const size_t nj = jobs.size();
     Lap lap;
     opsOut.clear(); opsOut.resize(nj); status.assign(nj, EDLIB_STATUS_OK);
+    // only jobs at or above the 1 MiB rule are ever split: the others stay a single implicit piece
     std::vector<std::vector<Piece>> pieces(nj);
-    for (size_t j = 0; j < nj; ++j) pieces[j].push_back(jobs[j]);
-    for (int level = 0; level < 64; ++level) {
+    std::vector<size_t> bigJobs;
+    for (size_t j = 0; j < nj; ++j)
+        if (needs_hirschberg(jobs[j].m, jobs[j].T)) { pieces[j].push_back(jobs[j]); bigJobs.push_back(j); }
+    auto npieces = [&](size_t j) { return pieces[j].empty() ? (size_t)1 : pieces[j].size(); };
+    auto piece = [&](size_t j, size_t i) -> const Piece& { return pieces[j].empty() ? jobs[j] : pieces[j][i]; };
+    for (int level = 0; level < 64 && !bigJobs.empty(); ++level) {
         std::vector<Piece> big; std::vector<std::pair<size_t, size_t>> where;
-        for (size_t j = 0; j < nj; ++j) {
+        for (size_t j : bigJobs) {
             if (status[j] != EDLIB_STATUS_OK) continue;
             for (size_t i = 0; i < pieces[j].size(); ++i) {
                 const Piece& pc = pieces[j][i];
@@ -953,14 +957,15 @@ int Batch::solvePaths(const std::vector<Piece>& jobs, std::vector<OpsOut>& opsOu
         }
     }
     // leaves: trivial pieces on the host (edlib.cpp:1168-1175), the rest through store + traceback
-    std::vector<UnitSpec> units; std::vector<std::pair<size_t, size_t>> where;
+    std::vector<UnitSpec> units;
+    units.reserve(nj);
     for (size_t j = 0; j < nj; ++j) {
         if (status[j] != EDLIB_STATUS_OK) continue;
-        for (size_t i = 0; i < pieces[j].size(); ++i) {
-            const Piece& pc = pieces[j][i];
+        for (size_t i = 0; i < npieces(j); ++i) {
+            const Piece& pc = piece(j, i);
             // kinit = the piece's distance: the storing scan runs inside exactly that band (the reference's
             // second call with k = bestScore, edlib.cpp:1196-1199)
-            if (pc.m > 0 && pc.T > 0) { units.push_back(UnitSpec{pc.qoff, pc.m, 1, pc.toff, pc.T, 1, pc.score}); where.push_back({j, i}); }
+            if (pc.m > 0 && pc.T > 0) units.push_back(UnitSpec{pc.qoff, pc.m, 1, pc.toff, pc.T, 1, pc.score});
         }
     }
     lap("paths: levels+units");
@@ -993,7 +998,7 @@ int Batch::solvePaths(const std::vector<Piece>& jobs, std::vector<OpsOut>& opsOu
         for (size_t j = 0; j < nj; ++j) {
             firstLeaf[j] = u;
             if (status[j] != EDLIB_STATUS_OK) continue;
-            for (size_t i = 0; i < pieces[j].size(); ++i) if (pieces[j][i].m > 0 && pieces[j][i].T > 0) ++u;
+            for (size_t i = 0; i < npieces(j); ++i) if (piece(j, i).m > 0 && piece(j, i).T > 0) ++u;
         }
         firstLeaf[nj] = u;
     }
@@ -1001,12 +1006,12 @@ int Batch::solvePaths(const std::vector<Piece>& jobs, std::vector<OpsOut>& opsOu
         if (status[j] != EDLIB_STATUS_OK) continue;
         OpsOut& o = opsOut[j];
         size_t u = firstLeaf[j];
-        if (pieces[j].size() == 1 && pieces[j][0].m > 0 && pieces[j][0].T > 0) {
+        if (npieces(j) == 1 && piece(j, 0).m > 0 && piece(j, 0).T > 0) {
             o.p = leafPtr[u]; o.len = leafLen[u];
             continue;
         }
-        for (size_t i = 0; i < pieces[j].size(); ++i) {
-            const Piece& pc = pieces[j][i];
+        for (size_t i = 0; i < npieces(j); ++i) {
+            const Piece& pc = piece(j, i);
             if (pc.m == 0) o.own.insert(o.own.end(), (size_t)pc.T, (uint8_t)EDLIB_EDOP_DELETE);
             else if (pc.T == 0) o.own.insert(o.own.end(), (size_t)pc.m, (uint8_t)EDLIB_EDOP_INSERT);
             else { o.own.insert(o.own.end(), leafPtr[u], leafPtr[u] + leafLen[u]); ++u; }

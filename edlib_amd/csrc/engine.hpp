@@ -115,8 +115,9 @@ private:
 
     // ---- block-per-lane path
     DevBuf<PairDesc> d_descs_;
-    DevBuf<unsigned long long> d_peq64_, d_storeP_, d_storeM_;
-    DevBuf<int> d_storeS_, d_aux_, d_outScore_, d_outCount_, d_outLast_, d_posPool_, d_opsLen_, d_alpha_;
+    DevBuf<unsigned long long> d_peq64_;
+    DevBuf<StoreEntry> d_store_;
+    DevBuf<int> d_aux_, d_outScore_, d_outCount_, d_outLast_, d_posPool_, d_opsLen_, d_alpha_;
     DevBuf<uint8_t> d_ops_;
     DevBuf<long long> d_opsOff_;
     // ring = 0: unbanded strips (any mode).  ring = 4 / 16 / 64: NW inside Ukkonen's band for threshold

@@ -200,7 +200,7 @@ scan_pairs_kernel(const PairScanArgs a)
                 bscore += (int)hp - (int)hn;
                 if (STORE) {
                     const long long si = sbase + (long long)t * nbS + lane;
-                    a.storeP[si] = ((u64)B.p1 << 32) | B.p0; a.storeM[si] = ((u64)B.m1 << 32) | B.m0; a.storeS[si] = bscore;
+                    a.store[si] = StoreEntry{((u64)B.p1 << 32) | B.p0, ((u64)B.m1 << 32) | B.m0, bscore, {0, 0, 0}};
                 }
                 if (!lastStrip) {
                     if (lane == 63) a.aux[d.auxOff + col] = (int)(hp | (hn << 1));
@@ -283,9 +283,8 @@ hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStr
 //     lane reads the symbol of its next-but-one column and the Peq word of its next column while it
 //     computes the current one;
 //   * steps: T + numBlocks - 1 instead of (T + 63) per 64-block strip;
-//   * STORE: every block-step also writes (Pv, Mv, block score) at [step][ring lane] (G entries per
-//     step, coalesced per ring) for traceback_kernel -- the reference's AlignmentData restricted to
-//     first..lastBlock (edlib.cpp:883-893).
+//   * STORE: every block-step also writes (Pv, Mv, block score) at [ring lane][column] for
+//     traceback_kernel -- the reference's AlignmentData restricted to first..lastBlock (edlib.cpp:883-893).
 // A unit whose blocks all fit the ring (numBlocks <= G) may use any K: with K = max(m, T) the band is
 // the whole matrix.
 template <int G> __device__ __forceinline__ int ring_ror(const int v)
@@ -295,11 +294,15 @@ template <int G> __device__ __forceinline__ int ring_ror(const int v)
     else return __builtin_amdgcn_update_dpp(0, v, 0x93 /*quad_perm:[3,0,1,2]*/, 0xf, 0xf, false);
 }
 
-__host__ __device__ static inline long long ring_index(int G, int c, int b) {
-    return (long long)(c + b) * G + (b & (G - 1));
+// Ring layout of the column store: one row of T entries per ring lane, block b in row b % G (blocks b and
+// b + G are never alive in the same column).  A lane writes consecutive entries step after step, and the
+// traceback walking left through a block reads them back-to-back (4 columns per 128-byte line).
+__host__ __device__ static inline long long ring_index(int G, int T, int c, int b) {
+    return (long long)(b & (G - 1)) * T + c;
 }
 long long ring_store_entries(int G, int qlen, int tlen) {
-    return ((long long)tlen + num_blocks(qlen) - 1) * G;
+    (void)qlen;
+    return (long long)tlen * G;
 }
 
 // PEQ: where a lane finds the Peq word of (symbol, its block):
@@ -431,8 +434,8 @@ scan_pairs_ring_kernel(const PairScanArgs a)
             hp = ph1 >> 31; hn = mh1 >> 31;
             bscore += (int)hp - (int)hn;
             if (STORE) {
-                const long long si = storeOff + (long long)t * G + rl;
-                a.storeP[si] = ((u64)B.p1 << 32) | B.p0; a.storeM[si] = ((u64)B.m1 << 32) | B.m0; a.storeS[si] = bscore;
+                a.store[storeOff + (long long)rl * T + col] =
+                    StoreEntry{((u64)B.p1 << 32) | B.p0, ((u64)B.m1 << 32) | B.m0, bscore, {0, 0, 0}};
             }
             if (b == nb - 1) {
                 const u64 ph = ((u64)ph1 << 32) | ph0, mh = ((u64)mh1 << 32) | mh0;
@@ -559,9 +562,7 @@ traceback_kernel(const TracebackArgs a)
     uint8_t* ops = a.ops + a.opsOff[unit];
     int w = m + T;                                  // next write index is --w
     int r = m - 1, c = T - 1, cur = a.score[unit];
-    const u64* SP = a.storeP + d.storeOff;
-    const u64* SM = a.storeM + d.storeOff;
-    const int* SS = a.storeS + d.storeOff;
+    const StoreEntry* S = a.store + d.storeOff;
     // ring layout (scan_pairs_ring_kernel): only the blocks inside the band of threshold kinit exist.
     // The walk stays on cells of optimal paths, which are inside the band and exact; a neighbour outside
     // the band can never be "one less than here", so it is simply not a candidate (the reference's
@@ -573,22 +574,32 @@ traceback_kernel(const TracebackArgs a)
         dmin = (D < 0 ? D : 0) - p;
     }
     const int kInf = 0x3fffffff;
+    auto entry = [&](int col, int blk) -> const StoreEntry& {
+        return S[G ? ring_index(G, T, col, blk) : store_index(T, nb, col, blk)];
+    };
+    // the walk keeps the block of the current column and of the column to its left in registers: a step
+    // to the left or along the diagonal inside a block shifts them and fetches one new entry
+    int hb = -1, hc = -2;                            // block / column the registers describe (hc = current column)
+    u64 Pc = 0, Mc = 0, Pl = 0, Ml = 0; int Sl = 0; bool leftIn = false;
     for (;;) {
         const int b = r >> 6, bit = r & 63;
-        const long long ic = G ? ring_index(G, c, b) : store_index(T, nb, c, b);
-        const u64 Pc = SP[ic], Mc = SM[ic];
+        if (b != hb || c != hc) {
+            if (b == hb && c == hc - 1 && leftIn) { Pc = Pl; Mc = Ml; }
+            else { const StoreEntry e = entry(c, b); Pc = e.p; Mc = e.m; }
+            leftIn = c > 0 && (!G || c - 1 >= 64 * b + dmin);          // block b exists in column c-1
+            if (leftIn) { const StoreEntry e = entry(c - 1, b); Pl = e.p; Ml = e.m; Sl = e.s; }
+            hb = b; hc = c;
+        }
         const int u = cur - ((int)((Pc >> bit) & 1ull) - (int)((Mc >> bit) & 1ull));
         int l, ul;
         if (c == 0) { l = r + 1; ul = r; }          // column -1 boundary (:976-980)
-        else if (!G || c - 1 >= 64 * b + dmin) {    // block b exists in column c-1
-            const long long il = G ? ring_index(G, c - 1, b) : store_index(T, nb, c - 1, b);
-            const u64 Pl = SP[il], Ml = SM[il];
+        else if (leftIn) {
             const u64 above = (bit == 63) ? 0ull : (~0ull << (bit + 1));   // rows below r in the block
-            l = SS[il] - __popcll(Pl & above) + __popcll(Ml & above);
+            l = Sl - __popcll(Pl & above) + __popcll(Ml & above);
             ul = l - ((int)((Pl >> bit) & 1ull) - (int)((Ml >> bit) & 1ull));
         } else {                                     // left edge of the band: only the diagonal neighbour may
             l = kInf;                                // exist, as the bottom cell of the block above
-            ul = (bit == 0 && b > 0) ? SS[ring_index(G, c - 1, b - 1)] : kInf;
+            ul = (bit == 0 && b > 0) ? entry(c - 1, b - 1).s : kInf;
         }
         if (u + 1 == cur) {                          // up: INSERT
             cur = u;

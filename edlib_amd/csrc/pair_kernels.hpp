@@ -31,6 +31,14 @@ struct PairDesc {
                          // size G of scan_pairs_ring_kernel (band of threshold kinit)
 };
 
+// One block-step of the column store (the reference's AlignmentData Ps/Ms/scores, edlib.cpp:22-47): 32 bytes,
+// so that the traceback fetches a cell's block with one sector.
+struct __attribute__((aligned(32))) StoreEntry {
+    unsigned long long p, m;    // vertical delta vectors after the column
+    int s;                      // score of the block's bottom row
+    int pad[3];
+};
+
 struct PairScanArgs {
     const PairDesc* descs;
     int numUnits;
@@ -41,10 +49,8 @@ struct PairScanArgs {
     const unsigned long long* peq;   // Peq pool, built by launch_build_peq_pairs
     int peqFullStride;          // ring kernel: sigmaT * (largest block count of the launch), 0 = unknown
     int* aux;                   // strip hand-off pool (horizontal deltas of a strip's bottom row)
-    // column store for the traceback (may be null): anti-diagonal order, see pair_kernels.hip
-    unsigned long long* storeP;
-    unsigned long long* storeM;
-    int* storeS;
+    // column store for the traceback (may be null), see pair_kernels.hip for the two layouts
+    StoreEntry* store;
     // outputs
     int* outScore;              // [units] NW: D[m][T]; SHW/HW: best bottom-row score (or -1)
     int* outCount;              // [units] SHW/HW: number of columns attaining it
@@ -80,9 +86,7 @@ struct TracebackArgs {
     const PairDesc* descs;
     int numUnits;
     const int* score;           // [units] D[m][T] (start value of the walk)
-    const unsigned long long* storeP;
-    const unsigned long long* storeM;
-    const int* storeS;
+    const StoreEntry* store;
     uint8_t* ops;               // ops pool; unit u owns [opsOff[u], opsOff[u] + qlen + tlen)
     const long long* opsOff;
     int* opsLen;                // [units] number of ops; they occupy the END of the unit's range
