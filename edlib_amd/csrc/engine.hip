@@ -710,7 +710,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p; a.posPool = d_posPool_.p;
     a.colP = nullptr; a.colM = nullptr; a.colS = nullptr;
     scanTimerStart();
-    if (ring) EDLIB_AMD_HIP(launch_scan_pairs_ring(ring, wantPath, a, stream_));
+    if (ring) EDLIB_AMD_HIP(launch_scan_pairs_ring(ring, mode, wantPath, a, stream_));
     else EDLIB_AMD_HIP(launch_scan_pairs(mode, wantPath, a, stream_));
     scanTimerStop();
     if (wantPath) {
@@ -888,7 +888,7 @@ int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& spli
         a.descs = d_descs_.p; a.numUnits = (int)(2 * nBanded);
         a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p;
         scanTimerStart();
-        EDLIB_AMD_HIP(launch_scan_pairs_ring(64, false, a, stream_));
+        EDLIB_AMD_HIP(launch_scan_pairs_ring(64, 0, false, a, stream_));
         scanTimerStop();
     }
     if (np > nBanded) {
@@ -1022,6 +1022,44 @@ int Batch::solvePaths(const std::vector<Piece>& jobs, std::vector<OpsOut>& opsOu
     return 0;
 }
 
+// ------------------------------------------------- semi-global units on rings
+
+// SHW / HW units of at most 4 (16) blocks share a wave 16 (4) at a time on the lane rings; longer ones take
+// the strips.  Same outputs as solve().
+int Batch::solveSemiGlobal(int mode, bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out)
+{
+    const size_t n = units.size();
+    const bool ringsOff = getenv("EDLIB_AMD_NWBAND") && getenv("EDLIB_AMD_NWBAND")[0] == '0';
+    static const int rings[3] = {4, 16, 0};
+    std::vector<int> grp(n, 2);
+    size_t cnt[3] = {0, 0, 0};
+    for (size_t i = 0; i < n; ++i) {
+        const int nb = (units[i].qlen + 63) / 64;
+        if (!ringsOff) grp[i] = nb <= 4 ? 0 : (nb <= 16 ? 1 : 2);
+        ++cnt[grp[i]];
+    }
+    if (cnt[2] == n) return solve(mode, wantPositions, false, units, out, 0);
+    SolveOut part[3];
+    std::vector<size_t> where(n);
+    for (int g = 0; g < 3; ++g) {
+        if (!cnt[g]) continue;
+        std::vector<UnitSpec> sel; sel.reserve(cnt[g]);
+        for (size_t i = 0; i < n; ++i) if (grp[i] == g) { where[i] = sel.size(); sel.push_back(units[i]); }
+        if (solve(mode, wantPositions, false, sel, part[g], rings[g])) return 1;
+    }
+    out.score.resize(n); out.count.resize(n); out.last.resize(n);
+    out.posStart.assign(n + 1, 0); out.posFlat.clear();
+    out.opsPtr.assign(n, nullptr); out.opsLen.assign(n, 0); out.opsBufs.clear();
+    for (size_t i = 0; i < n; ++i) {
+        const SolveOut& p = part[grp[i]];
+        const size_t q = where[i];
+        out.score[i] = p.score[q]; out.count[i] = p.count[q]; out.last[i] = p.last[q];
+        out.posFlat.insert(out.posFlat.end(), p.posFlat.begin() + p.posStart[q], p.posFlat.begin() + p.posStart[q + 1]);
+        out.posStart[i + 1] = (long long)out.posFlat.size();
+    }
+    return 0;
+}
+
 // ------------------------------------------------------ NW distance levels
 
 // The reference finds the NW distance by doubling k from 64 until the banded scan succeeds
@@ -1136,7 +1174,7 @@ int Batch::run()
             for (size_t i = 0; i < units.size(); ++i)
                 finalize_global(res[pairUnits_[i]], cfg_.k, mode, units[i].tlen, score[i]);
         } else {
-            if (solve(scanMode, true, false, units, so)) return 1;
+            if (solveSemiGlobal(scanMode, true, units, so)) return 1;
             for (size_t i = 0; i < units.size(); ++i)
                 finalize_semiglobal(res[pairUnits_[i]], cfg_.k, units[i].qlen, so.score[i],
                                     so.posFlat.data() + so.posStart[i], so.posStart[i + 1] - so.posStart[i]);
@@ -1173,7 +1211,7 @@ int Batch::run()
         }
         if (!units.empty()) {
             SolveOut so;
-            if (solve(EDLIB_MODE_SHW, false, false, units, so)) return 1;
+            if (solveSemiGlobal(EDLIB_MODE_SHW, false, units, so)) return 1;
             for (size_t i = 0; i < units.size(); ++i) {
                 UnitResult& r = res[where[i].first];
                 // last reported position of the reverse scan (:260); -1 when only the empty prefix qualifies

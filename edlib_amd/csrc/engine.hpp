@@ -130,6 +130,8 @@ private:
     // NW distances by threshold levels on rings of 4, 16, 64 lanes, then unbanded (the reference's
     // k-doubling, edlib.cpp:197-217, with thresholds chosen for the hardware)
     int solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<int>& score);
+    // SHW / HW units: short queries packed on 4- and 16-lane rings, the rest on the strips
+    int solveSemiGlobal(int mode, bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out);
     int alphabetLengths(const std::vector<int>& units, std::vector<UnitResult>& res);
     // linear-space paths (reference obtainAlignmentHirschberg, edlib.cpp:1231-1396)
     struct Piece { long long qoff; int m; long long toff; int T; int score; };

@@ -310,7 +310,10 @@ long long ring_store_entries(int G, int qlen, int tlen) {
 //   1  LDS slice [symbol][lane], refilled from the pool whenever the lane re-arms for a new block
 //   2  the unit's whole Peq in LDS ([unit in wave][symbol][block], a.peqFullStride words per unit):
 //      no refills, chosen by the launcher when it fits 16 KB per wave
-template <int G, bool STORE, int PEQ>
+// MODE 0 NW as described; MODE 1 SHW / 2 HW: no band (the launcher only sends units whose blocks all fit
+// the ring), kinit is the end-location threshold as in scan_pairs_kernel, the lane of the last block
+// follows row m-1 and records best / count / positions (edlib.cpp:658-673).
+template <int G, int MODE, bool STORE, int PEQ>
 __global__ void __launch_bounds__(64)
 scan_pairs_ring_kernel(const PairScanArgs a)
 {
@@ -344,11 +347,12 @@ scan_pairs_ring_kernel(const PairScanArgs a)
     const int nb = num_blocks(m);
     const int D = (bandT ? bandT : T) - m, absD = D < 0 ? -D : D;     // the band is that of the whole problem
     const bool dumpCol = G == 64 && a.colP != nullptr && colOffU >= 0;   // Hirschberg halves run on whole waves
-    const bool active = have && K >= absD;
+    const bool active = have && (MODE != 0 || K >= absD);
     if (have && !active && rl == 0) { a.outScore[unit] = 0x3fffffff; a.outCount[unit] = 0; a.outLast[unit] = -1; }
     if (__builtin_amdgcn_ballot_w64(active) == 0ull) return;
-    const int p = (K - absD) >> 1;
+    const int p = MODE != 0 ? (1 << 28) : (K - absD) >> 1;            // semi-global: the whole matrix
     const int dmin = (D < 0 ? D : 0) - p, dmax = (D > 0 ? D : 0) + p;
+    int best = K, cnt = 0, lastCol = -1;                              // MODE != 0: columns scoring <= best qualify
     const u32 sh = (u32)(m - 1) & 63u;
     const int lastRows = m - 64 * (nb - 1);                           // query rows in the last block
     const int nbA = active ? nb : 0;                                  // idle rings own no block
@@ -428,7 +432,10 @@ scan_pairs_ring_kernel(const PairScanArgs a)
             const u64 eqNxt = peq_word(symNxt, b);
             const int symNN = s_tgt[(col + 2) & 255];
             const bool fromUp = (b > 0) && (col <= upLast);
-            const u32 hpos = fromUp ? ((u32)x & 1u) : 1u, hneg = fromUp ? (((u32)x >> 1) & 1u) : 0u;
+            // row -1 of the matrix: +1 per column, or 0 for HW (edlib.cpp:584); a block whose upstream left
+            // the band also takes +1
+            const u32 hpos = fromUp ? ((u32)x & 1u) : ((MODE == 2 && b == 0) ? 0u : 1u);
+            const u32 hneg = fromUp ? (((u32)x >> 1) & 1u) : 0u;
             u32 ph0, ph1, mh0, mh1;
             advance_block64(B, (u32)eqCur, (u32)(eqCur >> 32), hpos, hneg, ph0, ph1, mh0, mh1);
             hp = ph1 >> 31; hn = mh1 >> 31;
@@ -440,7 +447,17 @@ scan_pairs_ring_kernel(const PairScanArgs a)
             if (b == nb - 1) {
                 const u64 ph = ((u64)ph1 << 32) | ph0, mh = ((u64)mh1 << 32) | mh0;
                 sc += (int)((ph >> sh) & 1ull) - (int)((mh >> sh) & 1ull);
-                if (col == T - 1) { a.outScore[unit] = sc; a.outCount[unit] = 1; a.outLast[unit] = T - 1; }
+                if (MODE == 0) {
+                    if (col == T - 1) { a.outScore[unit] = sc; a.outCount[unit] = 1; a.outLast[unit] = T - 1; }
+                } else {
+                    if (sc <= best) {                                 // edlib.cpp:658-673
+                        if (sc < best) { best = sc; cnt = 0; }
+                        if (cnt < dp->posCap) a.posPool[dp->posOff + cnt] = col;
+                        ++cnt;
+                        lastCol = col;
+                    }
+                    if (col == T - 1) { a.outScore[unit] = cnt > 0 ? best : -1; a.outCount[unit] = cnt; a.outLast[unit] = lastCol; }
+                }
             }
             if (dumpCol && col == T - 1) {                            // stop column of a Hirschberg half
                 a.colP[colOffU + b] = ((u64)B.p1 << 32) | B.p0; a.colM[colOffU + b] = ((u64)B.m1 << 32) | B.m0;
@@ -459,33 +476,38 @@ scan_pairs_ring_kernel(const PairScanArgs a)
     }
 }
 
-template <int G, bool STORE>
+template <int G, int MODE, bool STORE>
 static hipError_t launch_scan_pairs_ring_t(const PairScanArgs& a, hipStream_t stream)
 {
     constexpr int U = 64 / G;
     const dim3 grid((a.numUnits + U - 1) / U);
     const size_t full = (size_t)U * a.peqFullStride * sizeof(u64);
     if (G < 64 && a.peqFullStride > 0 && full <= 16384) {     // whole-wave rings: the conflict-free slice is faster
-        hipLaunchKernelGGL((scan_pairs_ring_kernel<G, STORE, 2>), grid, dim3(64), full + 256 * U, stream, a);
+        hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 2>), grid, dim3(64), full + 256 * U, stream, a);
     } else if (a.sigmaT <= 32) {
         const size_t lds = (size_t)a.sigmaT * 64 * sizeof(u64) + 256 * U;
-        hipLaunchKernelGGL((scan_pairs_ring_kernel<G, STORE, 1>), grid, dim3(64), lds, stream, a);
+        hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 1>), grid, dim3(64), lds, stream, a);
     } else {
-        hipLaunchKernelGGL((scan_pairs_ring_kernel<G, STORE, 0>), grid, dim3(64), 256 * U, stream, a);
+        hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 0>), grid, dim3(64), 256 * U, stream, a);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_scan_pairs_ring(int G, bool store, const PairScanArgs& a, hipStream_t stream)
+hipError_t launch_scan_pairs_ring(int G, int mode, bool store, const PairScanArgs& a, hipStream_t stream)
 {
     if (a.numUnits == 0) return hipSuccess;
-    switch (G * 2 + (store ? 1 : 0)) {
-        case 8: return launch_scan_pairs_ring_t<4, false>(a, stream);
-        case 9: return launch_scan_pairs_ring_t<4, true>(a, stream);
-        case 32: return launch_scan_pairs_ring_t<16, false>(a, stream);
-        case 33: return launch_scan_pairs_ring_t<16, true>(a, stream);
-        case 128: return launch_scan_pairs_ring_t<64, false>(a, stream);
-        case 129: return launch_scan_pairs_ring_t<64, true>(a, stream);
+    if (mode != 0 && (store || G == 64)) return hipErrorInvalidValue;   // semi-global rings: packed, distance only
+    switch (G * 8 + mode * 2 + (store ? 1 : 0)) {
+        case 32: return launch_scan_pairs_ring_t<4, 0, false>(a, stream);
+        case 33: return launch_scan_pairs_ring_t<4, 0, true>(a, stream);
+        case 34: return launch_scan_pairs_ring_t<4, 1, false>(a, stream);
+        case 36: return launch_scan_pairs_ring_t<4, 2, false>(a, stream);
+        case 128: return launch_scan_pairs_ring_t<16, 0, false>(a, stream);
+        case 129: return launch_scan_pairs_ring_t<16, 0, true>(a, stream);
+        case 130: return launch_scan_pairs_ring_t<16, 1, false>(a, stream);
+        case 132: return launch_scan_pairs_ring_t<16, 2, false>(a, stream);
+        case 512: return launch_scan_pairs_ring_t<64, 0, false>(a, stream);
+        case 513: return launch_scan_pairs_ring_t<64, 0, true>(a, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -73,7 +73,9 @@ hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStr
 // the dump with "invalid").  store: also the column store in ring layout (ring_store_entries per unit).
 constexpr int ring_max_k(int G) { return 64 * G - 128; }
 constexpr int kMaxBandK = ring_max_k(64);
-hipError_t launch_scan_pairs_ring(int ringLanes, bool store, const PairScanArgs& a, hipStream_t stream);
+// mode 1 (SHW) / 2 (HW): packed rings only (ringLanes 4 or 16), every unit must have numBlocks <= ringLanes;
+// no band, kinit is the end-location threshold, outputs as launch_scan_pairs.
+hipError_t launch_scan_pairs_ring(int ringLanes, int mode, bool store, const PairScanArgs& a, hipStream_t stream);
 long long ring_store_entries(int ringLanes, int qlen, int tlen);
 
 // reference buildPeq (edlib.cpp:358-384) for every unit: Peq[sym][block] from the

@@ -157,3 +157,30 @@ def test_wide_alphabet_rings(engine, ref, oracle):
         qs.append(bytes(q)); ts.append(t)
     _check(engine, impl, qs, ts, "NW", "distance", -1, "wide alphabet")
     _check(engine, impl, qs[:20], ts[:20], "NW", "path", -1, "wide alphabet")
+
+
+def test_semiglobal_units_on_rings(engine, ref, oracle):
+    """SHW / HW pairs whose queries fit 4- or 16-lane rings (and some that do not, in the same batch):
+    distances, end locations (also more than the 16 kept per unit), start locations, position -1."""
+    rng = random.Random(4107)
+    impl = _impl(ref, oracle)
+    qs, ts = [], []
+    for m in (1, 2, 63, 64, 65, 150, 255, 256, 257, 700, 1024, 1025, 1500):
+        for _ in range(3):
+            n = rng.choice([m // 2 + 1, m, 2 * m + 7, 5 * m + 100])
+            t = synth.random_dna(rng.randrange(1 << 30), n).tobytes()
+            if n > m and rng.random() < 0.7:
+                a = rng.randrange(0, n - m + 1)
+                q, _ = synth.mutate(np.frombuffer(t[a:a + m], dtype=np.uint8), rng.randrange(1 << 30), 0.05, 0.02, 0.02)
+                q = q.tobytes() or b"A"
+            else:
+                q = synth.random_dna(rng.randrange(1 << 30), m).tobytes()
+            qs.append(q); ts.append(t)
+    # many end locations, and the empty-prefix location -1
+    qs += [b"A" * 30, b"ACGT" * 10, b"AA", b"AC" * 100, b"G" * 200]
+    ts += [b"A" * 500, b"T" * 50, b"B", b"AC" * 400, b"G" * 64]
+    for mode in ("HW", "SHW"):
+        for task in ("distance", "locations", "path"):
+            _check(engine, impl, qs, ts, mode, task, -1, "semi-global rings")
+        for k in (0, 5, 40):
+            _check(engine, impl, qs, ts, mode, "locations", k, "semi-global rings fixed k")
