@@ -631,6 +631,14 @@ int Batch::collectReads(std::vector<UnitResult>& res)
 
 static const int kPosCap = 16;
 
+// Row length of the LDS-resident Peq of the ring kernels: the next power of two up to 32 blocks, a
+// multiple of 32 above (bank-conflict-free lookups, scan_pairs_ring_kernel)
+static int peq_row_stride(long long nb) {
+    if (nb > 32) return (int)std::min<long long>((nb + 31) / 32 * 32, 1 << 20);
+    int s = 1; while (s < nb) s <<= 1;
+    return s;
+}
+
 int Batch::solve(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units, SolveOut& out,
                  int ring)
 {
@@ -665,7 +673,9 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
 {
     const size_t n = ub - ua;
     Lap lap;
-    std::vector<PairDesc> descs(n);
+    PinBuf descsPin;                                   // built in pinned staging: the H2D runs at link rate
+    EDLIB_AMD_HIP(descsPin.alloc(n * sizeof(PairDesc)));
+    PairDesc* descs = reinterpret_cast<PairDesc*>(descsPin.p);
     std::vector<long long> opsOff(n + 1, 0);
     long long peqWords = 0, auxInts = 0, storeEntries = 0, nbMax = 0;
     for (size_t i = 0; i < n; ++i) {
@@ -697,14 +707,15 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         EDLIB_AMD_HIP(d_opsLen_.ensure(n));
         EDLIB_AMD_HIP(hipMemcpyAsync(d_opsOff_.p, opsOff.data(), (n + 1) * sizeof(long long), hipMemcpyHostToDevice, stream_));
     }
-    EDLIB_AMD_HIP(hipMemcpyAsync(d_descs_.p, descs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
+    EDLIB_AMD_HIP(hipMemcpyAsync(d_descs_.p, descs, n * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
     EDLIB_AMD_HIP(launch_build_peq_pairs(d_descs_.p, (int)n, d_qpool_.p, d_eq8_.p, d_idToByte_.p, tab_.sigmaT,
                                          d_peq64_.p, stream_));
     lap("chunk: descs+alloc");
     PairScanArgs a{};
     a.descs = d_descs_.p; a.numUnits = (int)n; a.qpool = d_qpool_.p; a.tpool = d_tpool_.p;
     a.tlut = d_tlut_.p; a.sigmaT = tab_.sigmaT; a.peq = d_peq64_.p; a.aux = d_aux_.p;
-    a.peqFullStride = (int)std::min<long long>(nbMax * tab_.sigmaT, 1 << 20);
+    a.peqRowStride = peq_row_stride(nbMax);
+    a.peqFullStride = (int)std::min<long long>((long long)a.peqRowStride * tab_.sigmaT, 1 << 20);
     if (getenv("EDLIB_AMD_PEQFULL") && getenv("EDLIB_AMD_PEQFULL")[0] == '0') a.peqFullStride = 0;
     a.store = d_store_.p;
     a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p; a.posPool = d_posPool_.p;
@@ -881,7 +892,8 @@ int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& spli
     {
         long long nbMax = 0;
         for (const Piece& pc : big) nbMax = std::max<long long>(nbMax, (pc.m + 63) / 64);
-        a.peqFullStride = (int)std::min<long long>(nbMax * tab_.sigmaT, 1 << 20);
+        a.peqRowStride = peq_row_stride(nbMax);
+        a.peqFullStride = (int)std::min<long long>((long long)a.peqRowStride * tab_.sigmaT, 1 << 20);
     }
     a.colP = colP.p; a.colM = colM.p; a.colS = colS.p;
     if (nBanded) {
@@ -973,20 +985,28 @@ int Batch::solvePaths(const std::vector<Piece>& jobs, std::vector<OpsOut>& opsOu
     std::vector<const uint8_t*> leafPtr(units.size(), nullptr); std::vector<int> leafLen(units.size(), 0);
     {
         const bool bandOff = getenv("EDLIB_AMD_NWBAND") && getenv("EDLIB_AMD_NWBAND")[0] == '0';
-        static const int rings[4] = {4, 16, 64, 0};
+        static const int rings[5] = {4, 16, 32, 64, 0};
         std::vector<int> ringOfUnit(units.size(), 0);
         for (size_t u = 0; u < units.size(); ++u) {
             const int nb = (units[u].qlen + 63) / 64;
-            for (int g = 0; g < 3 && !bandOff; ++g)
+            for (int g = 0; g < 4 && !bandOff; ++g)
                 if (nb <= rings[g] || units[u].kinit <= ring_max_k(rings[g])) { ringOfUnit[u] = rings[g]; break; }
         }
-        for (int g = 0; g < 4; ++g) {
-            std::vector<UnitSpec> sel; std::vector<size_t> who;
-            for (size_t u = 0; u < units.size(); ++u) if (ringOfUnit[u] == rings[g]) { sel.push_back(units[u]); who.push_back(u); }
-            if (sel.empty()) continue;
+        size_t perRing[5] = {0, 0, 0, 0, 0};
+        for (size_t u = 0; u < units.size(); ++u) for (int g = 0; g < 5; ++g) if (ringOfUnit[u] == rings[g]) ++perRing[g];
+        for (int g = 0; g < 5; ++g) {
+            if (!perRing[g]) continue;
             SolveOut so;
-            if (solve(EDLIB_MODE_NW, false, true, sel, so, rings[g])) return 1;
-            for (size_t q = 0; q < sel.size(); ++q) { leafPtr[who[q]] = so.opsPtr[q]; leafLen[who[q]] = so.opsLen[q]; }
+            if (perRing[g] == units.size()) {                       // the usual case: one kind of leaf
+                if (solve(EDLIB_MODE_NW, false, true, units, so, rings[g])) return 1;
+                leafPtr.swap(so.opsPtr); leafLen.swap(so.opsLen);
+            } else {
+                std::vector<UnitSpec> sel; std::vector<size_t> who;
+                sel.reserve(perRing[g]); who.reserve(perRing[g]);
+                for (size_t u = 0; u < units.size(); ++u) if (ringOfUnit[u] == rings[g]) { sel.push_back(units[u]); who.push_back(u); }
+                if (solve(EDLIB_MODE_NW, false, true, sel, so, rings[g])) return 1;
+                for (size_t q = 0; q < sel.size(); ++q) { leafPtr[who[q]] = so.opsPtr[q]; leafLen[who[q]] = so.opsLen[q]; }
+            }
             opsKeep_.insert(opsKeep_.end(), so.opsBufs.begin(), so.opsBufs.end());
         }
     }
@@ -1038,7 +1058,8 @@ int Batch::solveSemiGlobal(int mode, bool wantPositions, const std::vector<UnitS
         if (!ringsOff) grp[i] = nb <= 4 ? 0 : (nb <= 16 ? 1 : 2);
         ++cnt[grp[i]];
     }
-    if (cnt[2] == n) return solve(mode, wantPositions, false, units, out, 0);
+    for (int g = 0; g < 3; ++g)
+        if (cnt[g] == n) return solve(mode, wantPositions, false, units, out, rings[g]);   // the usual case: one kind
     SolveOut part[3];
     std::vector<size_t> where(n);
     for (int g = 0; g < 3; ++g) {
@@ -1065,7 +1086,7 @@ int Batch::solveSemiGlobal(int mode, bool wantPositions, const std::vector<UnitS
 // The reference finds the NW distance by doubling k from 64 until the banded scan succeeds
 // (edlib.cpp:197-217); any threshold >= the distance gives the same answer, so the levels here are the
 // ring sizes of scan_pairs_ring_kernel: K = 128 on 4-lane rings (16 units per wave), K = 896 on 16-lane
-// rings, K = 3968 on whole waves, then the unbanded strips.  A unit whose blocks all fit a ring is exact on
+// rings, K = 1920 on half waves, K = 3968 on whole waves, then the unbanded strips.  A unit whose blocks all fit a ring is exact on
 // it for any distance (threshold max(m, T)).  A failed level costs 1/16 or 1/4 of the next one, which is
 // pure waste when the whole batch is divergent, so larger batches first measure the divergence of 64
 // strided units on their 1 kb prefixes (one small launch) and every unit starts at the level that holds
@@ -1076,7 +1097,8 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
     score.assign(n, -1);
     if (n == 0) return 0;
     const bool bandOff = getenv("EDLIB_AMD_NWBAND") && getenv("EDLIB_AMD_NWBAND")[0] == '0';
-    static const int ringOf[3] = {4, 16, 64};
+    static const int ringOf[4] = {4, 16, 32, 64};
+    const int nl = 4;                                                   // ring levels; level nl = unbanded strips
     const int kInf = 0x3fffffff;
     const int kcap = cfg_.k >= 0 ? cfg_.k : kInf;                       // answers above the caller's k are all alike
     auto blocks = [&](size_t i) { return (units[i].qlen + 63) / 64; };
@@ -1102,26 +1124,26 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
     auto first_level = [&](size_t i) {
         const UnitSpec& u = units[i];
         const double est = std::min<double>(kcap, 1.25 * rate * std::max(u.qlen, u.tlen) + std::abs(u.qlen - u.tlen) + 8);
-        for (int l = 0; l < 3; ++l)
+        for (int l = 0; l < nl; ++l)
             if (blocks(i) <= ringOf[l] || est <= ring_max_k(ringOf[l])) return l;
-        return est <= 2.0 * ring_max_k(64) ? 2 : 3;                     // far above every band: straight to the strips
+        return est <= 2.0 * ring_max_k(64) ? nl - 1 : nl;               // far above every band: straight to the strips
     };
     std::vector<int> lvl(n);
-    for (size_t i = 0; i < n; ++i) lvl[i] = bandOff ? 3 : first_level(i);
-    for (int l = 0; l <= 3; ++l) {
+    for (size_t i = 0; i < n; ++i) lvl[i] = bandOff ? nl : first_level(i);
+    for (int l = 0; l <= nl; ++l) {
         std::vector<UnitSpec> sel; std::vector<size_t> who;
         for (size_t i = 0; i < n; ++i) {
             if (lvl[i] != l) continue;
             UnitSpec u = units[i];
-            if (l < 3) u.kinit = std::min(kcap, blocks(i) <= ringOf[l] ? std::max(u.qlen, u.tlen) : ring_max_k(ringOf[l]));
+            if (l < nl) u.kinit = std::min(kcap, blocks(i) <= ringOf[l] ? std::max(u.qlen, u.tlen) : ring_max_k(ringOf[l]));
             sel.push_back(u); who.push_back(i);
         }
         if (sel.empty()) continue;
         SolveOut so;
-        if (solve(EDLIB_MODE_NW, false, false, sel, so, l < 3 ? ringOf[l] : 0)) return 1;
+        if (solve(EDLIB_MODE_NW, false, false, sel, so, l < nl ? ringOf[l] : 0)) return 1;
         for (size_t q = 0; q < sel.size(); ++q) {
             const size_t i = who[q];
-            if (l == 3 || so.score[q] <= sel[q].kinit) score[i] = so.score[q];          // exact
+            if (l == nl || so.score[q] <= sel[q].kinit) score[i] = so.score[q];         // exact
             else if (sel[q].kinit >= kcap) score[i] = kInf;                              // > k: final
             else lvl[i] = l + 1;                                                         // next level
         }
@@ -1159,7 +1181,9 @@ int Batch::run()
     if (runReads()) return 1;
     readsCollected_ = groups_.empty();
     // TASK_DISTANCE leaves the reads-path results in HBM until results(); LOC/PATH need them now
+    lap("run: reads scans");
     if (!readsCollected_ && cfg_.task != EDLIB_TASK_DISTANCE && collectReads(res)) return 1;
+    lap("run: collect reads");
     if (!pairUnits_.empty()) {
         std::vector<UnitSpec> units(pairUnits_.size());
         for (size_t i = 0; i < units.size(); ++i) {
@@ -1193,6 +1217,7 @@ int Batch::run()
     // ---- phase 2: start locations (edlib.cpp:228-272)
     if (cfg_.task == EDLIB_TASK_LOC || cfg_.task == EDLIB_TASK_PATH) {
         std::vector<UnitSpec> units; std::vector<std::pair<int, int>> where;
+        units.reserve(live.size() + live.size() / 8); where.reserve(live.size() + live.size() / 8);
         for (int u : live) {
             UnitResult& r = res[u];
             r.hasStarts = true;
@@ -1209,9 +1234,11 @@ int Batch::run()
                 where.push_back({u, (int)j});
             }
         }
+        lap("starts: units");
         if (!units.empty()) {
             SolveOut so;
             if (solveSemiGlobal(EDLIB_MODE_SHW, false, units, so)) return 1;
+            lap("starts: solve");
             for (size_t i = 0; i < units.size(); ++i) {
                 UnitResult& r = res[where[i].first];
                 // last reported position of the reverse scan (:260); -1 when only the empty prefix qualifies
@@ -1223,6 +1250,7 @@ int Batch::run()
     // ---- phase 3: alignment path of the first location (edlib.cpp:276-289, 1161-1213)
     if (cfg_.task == EDLIB_TASK_PATH) {
         std::vector<Piece> jobs; std::vector<int> where;
+        jobs.reserve(live.size()); where.reserve(live.size());
         for (int u : live) {
             UnitResult& r = res[u];
             if (r.ends.empty()) continue;
@@ -1233,6 +1261,7 @@ int Batch::run()
             jobs.push_back(Piece{qoff_[u], m, tbase(u) + s, len, r.editDistance});
             where.push_back(u);
         }
+        lap("paths: jobs");
         if (!jobs.empty()) {
             std::vector<OpsOut> ops; std::vector<int> st;
             if (solvePaths(jobs, ops, st)) return 1;

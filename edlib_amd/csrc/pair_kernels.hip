@@ -269,15 +269,16 @@ hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStr
 // first/lastBlock bookkeeping converges to, edlib.cpp:744-830): a path of cost <= K only visits
 // diagonals d = j - i in [dmin, dmax] = [min(0,D) - p, max(0,D) + p], D = T - m, p = (K - |D|) / 2.
 // Block b therefore lives for columns [64b + dmin, 64b + 63 + dmax], and fewer than G consecutive
-// blocks are alive at a time when K <= ring_max_k(G).  A RING of G lanes (G = 4, 16 or 64) therefore
+// blocks are alive at a time when K <= ring_max_k(G).  A RING of G lanes (G = 4, 16, 32 or 64) therefore
 // covers a query of any length, and a wave carries 64 / G independent units:
 //   * blocks are mapped to the ring's lanes round-robin (block b -> ring lane b % G).  When a lane's
 //     block leaves the band it re-arms for block b + G: state "+1 per row" below the upstream block's
 //     bottom score, exactly the reference's new block (edlib.cpp:803-808); cells outside the band only
 //     ever enter as such upper bounds, so values <= K stay exact (Ukkonen);
 //   * same anti-diagonal schedule as scan_pairs_kernel (block b updates column t - b at step t); the
-//     carry moves one lane up the ring per step in one DPP move (wave_ror:1 / row_ror:1 / quad_perm,
-//     the last ring lane feeds the first); a block whose upstream is outside the band (or block 0)
+//     carry moves one lane up the ring per step in one DPP move (wave_ror:1 / row_ror:1 / quad_perm; the
+//     32-lane ring patches two lanes of a wave_ror with v_readlane / v_writelane; the last ring lane
+//     feeds the first); a block whose upstream is outside the band (or block 0)
 //     takes hin = +1 (edlib.cpp:779);
 //   * target symbols are staged in a 256-entry LDS ring per unit, filled 64 columns at a time; each
 //     lane reads the symbol of its next-but-one column and the Peq word of its next column while it
@@ -290,6 +291,14 @@ hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStr
 template <int G> __device__ __forceinline__ int ring_ror(const int v)
 {
     if constexpr (G == 64) return __builtin_amdgcn_update_dpp(0, v, 0x13C /*wave_ror:1*/, 0xf, 0xf, false);
+    else if constexpr (G == 32) {
+        // no DPP rotates 32 lanes: rotate the wave and hand lanes 0 and 32 their ring's last lane
+        int x = __builtin_amdgcn_update_dpp(0, v, 0x13C, 0xf, 0xf, false);
+        const int lo = __builtin_amdgcn_readlane(v, 31), hi = __builtin_amdgcn_readlane(v, 63);
+        asm("v_writelane_b32 %0, %1, 0" : "+v"(x) : "s"(lo));
+        asm("v_writelane_b32 %0, %1, 32" : "+v"(x) : "s"(hi));
+        return x;
+    }
     else if constexpr (G == 16) return __builtin_amdgcn_update_dpp(0, v, 0x121 /*row_ror:1*/, 0xf, 0xf, false);
     else return __builtin_amdgcn_update_dpp(0, v, 0x93 /*quad_perm:[3,0,1,2]*/, 0xf, 0xf, false);
 }
@@ -308,8 +317,9 @@ long long ring_store_entries(int G, int qlen, int tlen) {
 // PEQ: where a lane finds the Peq word of (symbol, its block):
 //   0  HBM pool (more than 32 target symbols)
 //   1  LDS slice [symbol][lane], refilled from the pool whenever the lane re-arms for a new block
-//   2  the unit's whole Peq in LDS ([unit in wave][symbol][block], a.peqFullStride words per unit):
-//      no refills, chosen by the launcher when it fits 16 KB per wave
+//   2  the unit's whole Peq in LDS ([unit in wave][symbol][block], a.peqFullStride words per unit, rows
+//      of a.peqRowStride words):
+//      no refills, chosen by the launcher for packed rings when a wave needs at most 8 KB
 // MODE 0 NW as described; MODE 1 SHW / 2 HW: no band (the launcher only sends units whose blocks all fit
 // the ring), kinit is the end-location threshold as in scan_pairs_kernel, the lane of the last block
 // follows row m-1 and records best / count / positions (edlib.cpp:658-673).
@@ -369,12 +379,16 @@ scan_pairs_ring_kernel(const PairScanArgs a)
     };
     for (int i = rl; i < 256; i += G) s_tgt[i] = 0;                   // never index Peq with an unwritten slot
     if (active) { refill(); refill(); refill(); }                     // 192 columns ahead of column 0
+    // rows padded to a.peqRowStride words (a multiple of 32 for long queries): a ring's lanes, which hold
+    // consecutive blocks, then hit distinct bank pairs whatever symbols they look up
+    const int rowStride = PEQ == 2 ? a.peqRowStride : 0;
     if (PEQ == 2 && active) {
         const long long peqOff = peqOff_();
-        for (int i = rl; i < a.sigmaT * nb; i += G) s_peq[i] = a.peq[peqOff + i];
+        for (int sy = 0; sy < a.sigmaT; ++sy)
+            for (int i = rl; i < nb; i += G) s_peq[sy * rowStride + i] = a.peq[peqOff + (long long)sy * nb + i];
     }
     auto peq_word = [&](int sym, int blk) -> u64 {
-        if (PEQ == 2) return s_peq[sym * nb + blk];
+        if (PEQ == 2) return s_peq[sym * rowStride + blk];
         if (PEQ == 1) return s_peq[sym * 64 + lane];
         return a.peq[peqOff_() + (long long)sym * nb + blk];
     };
@@ -482,7 +496,9 @@ static hipError_t launch_scan_pairs_ring_t(const PairScanArgs& a, hipStream_t st
     constexpr int U = 64 / G;
     const dim3 grid((a.numUnits + U - 1) / U);
     const size_t full = (size_t)U * a.peqFullStride * sizeof(u64);
-    if (G < 64 && a.peqFullStride > 0 && full <= 16384) {     // whole-wave rings: the conflict-free slice is faster
+    // the whole-Peq mode saves the refills of packed rings, but only pays while LDS does not cap the
+    // occupancy (measured: 10 KB per wave costs config 4 a third of its rate)
+    if (G < 64 && a.peqFullStride > 0 && full + 256 * U <= 8192) {
         hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 2>), grid, dim3(64), full + 256 * U, stream, a);
     } else if (a.sigmaT <= 32) {
         const size_t lds = (size_t)a.sigmaT * 64 * sizeof(u64) + 256 * U;
@@ -496,7 +512,7 @@ static hipError_t launch_scan_pairs_ring_t(const PairScanArgs& a, hipStream_t st
 hipError_t launch_scan_pairs_ring(int G, int mode, bool store, const PairScanArgs& a, hipStream_t stream)
 {
     if (a.numUnits == 0) return hipSuccess;
-    if (mode != 0 && (store || G == 64)) return hipErrorInvalidValue;   // semi-global rings: packed, distance only
+    if (mode != 0 && (store || G >= 32)) return hipErrorInvalidValue;   // semi-global rings: 4 or 16 lanes, distance only
     switch (G * 8 + mode * 2 + (store ? 1 : 0)) {
         case 32: return launch_scan_pairs_ring_t<4, 0, false>(a, stream);
         case 33: return launch_scan_pairs_ring_t<4, 0, true>(a, stream);
@@ -506,6 +522,8 @@ hipError_t launch_scan_pairs_ring(int G, int mode, bool store, const PairScanArg
         case 129: return launch_scan_pairs_ring_t<16, 0, true>(a, stream);
         case 130: return launch_scan_pairs_ring_t<16, 1, false>(a, stream);
         case 132: return launch_scan_pairs_ring_t<16, 2, false>(a, stream);
+        case 256: return launch_scan_pairs_ring_t<32, 0, false>(a, stream);
+        case 257: return launch_scan_pairs_ring_t<32, 0, true>(a, stream);
         case 512: return launch_scan_pairs_ring_t<64, 0, false>(a, stream);
         case 513: return launch_scan_pairs_ring_t<64, 0, true>(a, stream);
     }

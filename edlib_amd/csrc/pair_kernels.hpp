@@ -47,7 +47,8 @@ struct PairScanArgs {
     const uint8_t* tlut;        // [256] target byte -> symbol id (row of Peq)
     int sigmaT;                 // number of target symbols (rows of Peq)
     const unsigned long long* peq;   // Peq pool, built by launch_build_peq_pairs
-    int peqFullStride;          // ring kernel: sigmaT * (largest block count of the launch), 0 = unknown
+    int peqFullStride;          // ring kernel: sigmaT * peqRowStride, 0 = unknown
+    int peqRowStride;           // largest block count of the launch, padded (see scan_pairs_ring_kernel)
     int* aux;                   // strip hand-off pool (horizontal deltas of a strip's bottom row)
     // column store for the traceback (may be null), see pair_kernels.hip for the two layouts
     StoreEntry* store;
@@ -67,7 +68,7 @@ hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStr
 
 // NW with Ukkonen's diagonal band for threshold desc.kinit (reference myersCalcEditDistanceNW with a
 // fixed k, edlib.cpp:730-928): exact whenever the distance is <= kinit, otherwise some value > kinit.
-// ringLanes G in {4, 16, 64}: the band must fit the ring (kinit <= ring_max_k(G), or numBlocks <= G and any
+// ringLanes G in {4, 16, 32, 64}: the band must fit the ring (kinit <= ring_max_k(G), or numBlocks <= G and any
 // kinit); a wave carries 64 / G units, whatever the query length (no strips).  Writes outScore and, when
 // colP is set, the (P, M, score) of the blocks alive at the last processed column (the caller pre-fills
 // the dump with "invalid").  store: also the column store in ring layout (ring_store_entries per unit).

@@ -3,7 +3,7 @@ the banded column store + traceback behind EDLIB_TASK_PATH, against the compiled
 oracle restatement where it did not travel).
 
 Directed at what the generic fuzz only hits by chance: distances right at the level thresholds
-(128, 896, 3968), block counts right at the ring sizes (4, 16, 64 blocks), mixed batches whose units
+(128, 896, 1920, 3968), block counts right at the ring sizes (4, 16, 32, 64 blocks), mixed batches whose units
 resolve at different levels, batches large enough to take the prefix divergence probe, fixed k, rings
 sharing a wave with idle rings, and paths that run along the edge of the band."""
 import random
@@ -52,19 +52,20 @@ def _pair_with_edits(rng, n, edits, indel_frac=0.5):
 
 
 def test_distances_at_level_thresholds(engine, ref, oracle):
-    """Distances just below / at / above 128, 896 and 3968 (ring_max_k of the three ring sizes)."""
+    """Distances just below / at / above 128, 896, 1920 and 3968 (ring_max_k of the four ring sizes)."""
     rng = random.Random(4101)
     impl = _impl(ref, oracle)
     qs, ts = [], []
     for n, edits in ((6000, 120), (6000, 127), (6000, 128), (6000, 129), (6000, 135),
                      (9000, 880), (9000, 896), (9000, 900), (9000, 930),
+                     (20000, 1500), (20000, 1915), (20000, 1920), (20000, 1923), (20000, 1990),
                      (30000, 3900), (30000, 3968), (30000, 3975), (30000, 4100)):
         for _ in range(2):
             q, t = _pair_with_edits(rng, n, edits, indel_frac=0.2)
             qs.append(q); ts.append(t)
     _check(engine, impl, qs, ts, "NW", "distance", -1, "thresholds")
-    for k in (127, 128, 129, 896, 3968, 5000):
-        _check(engine, impl, qs[:18], ts[:18], "NW", "distance", k, "thresholds fixed k")
+    for k in (127, 128, 129, 896, 1920, 3968, 5000):
+        _check(engine, impl, qs[:28], ts[:28], "NW", "distance", k, "thresholds fixed k")
 
 
 def test_block_counts_at_ring_sizes(engine, ref, oracle):
@@ -73,7 +74,7 @@ def test_block_counts_at_ring_sizes(engine, ref, oracle):
     impl = _impl(ref, oracle)
     for task in ("distance", "path"):
         qs, ts = [], []
-        for m in (1, 63, 64, 65, 255, 256, 257, 320, 960, 1023, 1024, 1025, 1088, 4032, 4096, 4097, 4160):
+        for m in (1, 63, 64, 65, 255, 256, 257, 320, 960, 1023, 1024, 1025, 1088, 2040, 2048, 2049, 2112, 4032, 4096, 4097, 4160):
             if task == "path" and m > 1100:
                 continue
             for rate in (0.0, 0.03, 0.25):
