@@ -290,17 +290,18 @@ hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStr
 // the whole matrix.
 template <int G> __device__ __forceinline__ int ring_ror(const int v)
 {
-    if constexpr (G == 64) return __builtin_amdgcn_update_dpp(0, v, 0x13C /*wave_ror:1*/, 0xf, 0xf, false);
+    // every lane has a source lane: no `old` operand to initialise (v_mov_b32_dpp ... bound_ctrl:1)
+    if constexpr (G == 64) return __builtin_amdgcn_mov_dpp(v, 0x13C /*wave_ror:1*/, 0xf, 0xf, true);
     else if constexpr (G == 32) {
         // no DPP rotates 32 lanes: rotate the wave and hand lanes 0 and 32 their ring's last lane
-        int x = __builtin_amdgcn_update_dpp(0, v, 0x13C, 0xf, 0xf, false);
+        int x = __builtin_amdgcn_mov_dpp(v, 0x13C, 0xf, 0xf, true);
         const int lo = __builtin_amdgcn_readlane(v, 31), hi = __builtin_amdgcn_readlane(v, 63);
         asm("v_writelane_b32 %0, %1, 0" : "+v"(x) : "s"(lo));
         asm("v_writelane_b32 %0, %1, 32" : "+v"(x) : "s"(hi));
         return x;
     }
-    else if constexpr (G == 16) return __builtin_amdgcn_update_dpp(0, v, 0x121 /*row_ror:1*/, 0xf, 0xf, false);
-    else return __builtin_amdgcn_update_dpp(0, v, 0x93 /*quad_perm:[3,0,1,2]*/, 0xf, 0xf, false);
+    else if constexpr (G == 16) return __builtin_amdgcn_mov_dpp(v, 0x121 /*row_ror:1*/, 0xf, 0xf, true);
+    else return __builtin_amdgcn_mov_dpp(v, 0x93 /*quad_perm:[3,0,1,2]*/, 0xf, 0xf, true);
 }
 
 // Ring layout of the column store: one row of T entries per ring lane, block b in row b % G (blocks b and
@@ -393,17 +394,24 @@ scan_pairs_ring_kernel(const PairScanArgs a)
         return a.peq[peqOff_() + (long long)sym * nb + blk];
     };
 
-    // ---- per-lane block bookkeeping
+    // ---- per-lane block bookkeeping.  Block b is updated at steps t with t - tstart in [0, span]; its
+    // upstream block delivers deltas up to step upLastT (edlib.cpp:779: +1 per column once it left the band)
     int b = rl;                                                       // current (or next) block of this lane
     auto first_col = [&](int blk) { const int c = 64 * blk + dmin; return c < 0 ? 0 : c; };
     auto last_col = [&](int blk) { const int c = 64 * blk + 63 + dmax; return c > T - 1 ? T - 1 : c; };
-    int tstart = (b < nbA && first_col(b) <= last_col(b)) ? first_col(b) + b : 0x7fffffff;
-    int tend = (b < nbA) ? last_col(b) + b : -1;
-    int upLast = (b > 0) ? last_col(b - 1) : -1;                      // last column the upstream block delivers
+    int tstart, span, upLastT;
+    u32 topPos;                                                       // hin bit at the top of a block with no upstream
+    auto arm = [&]() {
+        const bool ok = b < nbA && first_col(b) <= last_col(b);       // blocks below the band never get a column
+        tstart = ok ? first_col(b) + b : 0x7fffffff;
+        span = ok ? last_col(b) + b - tstart : 0;
+        upLastT = (b > 0) ? last_col(b - 1) + b : -1;
+        topPos = (MODE == 2 && b == 0) ? 0u : 1u;                     // row -1: +1 per column, 0 for HW (edlib.cpp:584)
+    };
+    arm();
 
     Block64 B{~0u, ~0u, 0u, 0u};
-    int bscore = 0, sc = 0, carry = 0, symNxt = 0;
-    u64 eqCur = 0;
+    int bscore = 0, sc = 0, carry = 0;
     int nsteps = active ? T + nb - 1 : 0;
     if constexpr (G == 64) nsteps = __builtin_amdgcn_readfirstlane(nsteps);
     else {                                          // the wave runs for its longest unit
@@ -413,16 +421,14 @@ scan_pairs_ring_kernel(const PairScanArgs a)
         nsteps = w;
     }
 
-    for (int t = 0; t < nsteps; ++t) {
-        if ((t & 63) == 0) {                                          // pace the ring by the largest column in use
-            int bt = t - 63 - dmax; bt = bt <= 0 ? 0 : (bt + 64) / 65;
-            if (t - T + 1 > bt) bt = t - T + 1;
-            const int jmax = t - bt;
-            while (active && loaded < T && loaded < jmax + 64 + 67) refill();
-        }
+    // One step.  eqCur / symCur: Peq word of this step's column and symbol of the next column (fetched by
+    // the previous step); eqNxt / symNxt are fetched here for the next step -- the caller swaps the two
+    // register sets every step instead of moving them.
+    auto step = [&](const int t, u64& eqCur, u64& eqNxt, int& symCur, int& symNxt) {
         const int x = ring_ror<G>(carry);
+        const int dt = t - tstart;
         // upstream's bottom score travels only when some lane starts a block at this step
-        const bool starting = (t == tstart);
+        const bool starting = (dt == 0);
         int upScore = 0;
         if (__builtin_amdgcn_ballot_w64(starting) != 0ull) upScore = ring_ror<G>(bscore);
         const int col = t - b;
@@ -439,16 +445,14 @@ scan_pairs_ring_kernel(const PairScanArgs a)
             if (b == nb - 1) sc = above + lastRows;
             const int s0 = s_tgt[col & 255];
             eqCur = peq_word(s0, b);
-            symNxt = s_tgt[(col + 1) & 255];
+            symCur = s_tgt[(col + 1) & 255];
         }
         u32 hp = 0, hn = 0;
-        if (t >= tstart && t <= tend) {
-            const u64 eqNxt = peq_word(symNxt, b);
-            const int symNN = s_tgt[(col + 2) & 255];
-            const bool fromUp = (b > 0) && (col <= upLast);
-            // row -1 of the matrix: +1 per column, or 0 for HW (edlib.cpp:584); a block whose upstream left
-            // the band also takes +1
-            const u32 hpos = fromUp ? ((u32)x & 1u) : ((MODE == 2 && b == 0) ? 0u : 1u);
+        if ((u32)dt <= (u32)span) {
+            eqNxt = peq_word(symCur, b);
+            symNxt = s_tgt[(col + 2) & 255];
+            const bool fromUp = t <= upLastT;
+            const u32 hpos = fromUp ? ((u32)x & 1u) : topPos;
             const u32 hneg = fromUp ? (((u32)x >> 1) & 1u) : 0u;
             u32 ph0, ph1, mh0, mh1;
             advance_block64(B, (u32)eqCur, (u32)(eqCur >> 32), hpos, hneg, ph0, ph1, mh0, mh1);
@@ -477,16 +481,25 @@ scan_pairs_ring_kernel(const PairScanArgs a)
                 a.colP[colOffU + b] = ((u64)B.p1 << 32) | B.p0; a.colM[colOffU + b] = ((u64)B.m1 << 32) | B.m0;
                 a.colS[colOffU + b] = bscore;
             }
-            eqCur = eqNxt; symNxt = symNN;
         }
         carry = (int)(hp | (hn << 1));
-        if (t >= tend && b < nbA) {                                   // block done: re-arm this lane for block b + G
+        if (dt >= span && b < nbA) {                                  // block done: re-arm this lane for block b + G
             b += G;
-            const bool ok = b < nbA && first_col(b) <= last_col(b);
-            tstart = ok ? first_col(b) + b : 0x7fffffff;
-            tend = (b < nbA) ? last_col(b) + b : -1;
-            upLast = last_col(b - 1);
+            arm();
         }
+    };
+
+    u64 eqA = 0, eqB = 0;
+    int symA = 0, symB = 0;
+    for (int t = 0; t < nsteps; t += 2) {
+        if ((t & 63) == 0) {                                          // pace the ring by the largest column in use
+            int bt = t - 63 - dmax; bt = bt <= 0 ? 0 : (bt + 64) / 65;
+            if (t - T + 1 > bt) bt = t - T + 1;
+            const int jmax = t - bt;
+            while (active && loaded < T && loaded < jmax + 64 + 67) refill();
+        }
+        step(t, eqA, eqB, symA, symB);
+        if (t + 1 < nsteps) step(t + 1, eqB, eqA, symB, symA);
     }
 }
 
