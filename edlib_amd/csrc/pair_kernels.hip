@@ -56,7 +56,9 @@ long long pair_store_entries(int qlen, int tlen) {
 
 // ------------------------------------------------------------------ buildPeq
 
-// One workgroup per unit; thread i handles (symbol, block) items i, i+256, ...
+// One workgroup per unit.  The equality relation of 32 target symbols at a time is folded into a
+// 256-entry LDS table (query byte -> bit s set iff it equals symbol s); a thread then owns one block of
+// four symbols: 64 query bytes, one table lookup each, four 64-bit words out.
 // bit r of Peq[sym][b] = eq8[query[64b+r]][byte of sym]; rows past the query end are 0
 // (the kernels follow row m-1 explicitly, so the reference's wildcard padding,
 // edlib.cpp:373-375, is not needed).
@@ -65,20 +67,37 @@ build_peq_pairs_kernel(const PairDesc* __restrict__ descs, const uint8_t* __rest
                        const uint8_t* __restrict__ eq8, const uint8_t* __restrict__ idToByte,
                        int sigmaT, u64* __restrict__ peq)
 {
+    __shared__ u32 s_mask[256];
     const PairDesc d = descs[blockIdx.x];
     const int nb = num_blocks(d.qlen);
-    const int items = nb * sigmaT;
-    for (int it = threadIdx.x; it < items; it += blockDim.x) {
-        const int s = it / nb, b = it - s * nb;
-        const uint8_t* row = eq8 + idToByte[s];            // eq8[q*256 + tbyte]
-        u64 w = 0;
-        const int r0 = b * 64;
-        const int rn = (d.qlen - r0) < 64 ? (d.qlen - r0) : 64;
-        for (int r = 0; r < rn; ++r) {
-            const u32 q = qpool[d.qoff + (long long)(r0 + r) * d.qstep];
-            w |= (u64)(row[q * 256] & 1) << r;
+    for (int g0 = 0; g0 < sigmaT; g0 += 32) {
+        const int ns = (sigmaT - g0) < 32 ? (sigmaT - g0) : 32;
+        __syncthreads();
+        {
+            u32 mk = 0;
+            for (int sy = 0; sy < ns; ++sy) mk |= (u32)(eq8[threadIdx.x * 256 + idToByte[g0 + sy]] & 1) << sy;
+            s_mask[threadIdx.x] = mk;
         }
-        peq[d.peqOff + (long long)s * nb + b] = w;
+        __syncthreads();
+        const int nch = (ns + 3) >> 2;
+        for (int it = threadIdx.x; it < nb * nch; it += blockDim.x) {
+            const int ch = it / nb, blk = it - ch * nb;            // neighbouring threads: neighbouring blocks
+            const int r0 = blk * 64;
+            const int rn = (d.qlen - r0) < 64 ? (d.qlen - r0) : 64;
+            const uint8_t* qp = qpool + d.qoff + (long long)r0 * d.qstep;
+            u64 w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+            for (int r = 0; r < rn; ++r) {
+                const u32 mk = s_mask[qp[(long long)r * d.qstep]] >> (4 * ch);
+                w0 |= (u64)(mk & 1u) << r; w1 |= (u64)((mk >> 1) & 1u) << r;
+                w2 |= (u64)((mk >> 2) & 1u) << r; w3 |= (u64)((mk >> 3) & 1u) << r;
+            }
+            const int s0 = g0 + 4 * ch;
+            u64* out = peq + d.peqOff + (long long)s0 * nb + blk;
+            out[0] = w0;
+            if (s0 + 1 < g0 + ns) out[nb] = w1;
+            if (s0 + 2 < g0 + ns) out[2LL * nb] = w2;
+            if (s0 + 3 < g0 + ns) out[3LL * nb] = w3;
+        }
     }
 }
 
