@@ -589,6 +589,8 @@ scan_reads_banded_kernel(const ReadScanArgs a)
     const int w0 = cw >> 4, wmain = c0 >> 4, wend = (c1 + 15) >> 4;
     int nw = NWD;
     unsigned int bandWork = 0;                                        // sum of nw over the dwords (wave-uniform)
+    // (fetching the next packed dword one iteration ahead through an opaque-zero VGPR address measured
+    // no gain: with 7 waves per SIMD the load latency is already covered)
     for (int w = w0; w < wend; ++w) {
         const u32 tw = a.tpk[w];
         const bool track = w >= wmain;                                // warm-up columns record nothing
@@ -600,8 +602,10 @@ scan_reads_banded_kernel(const ReadScanArgs a)
         }
     }
     if (live) {
-        a.segBest[item] = tr.best;
-        a.segCnt[item] = tr.cnt;
+        // recomputed rather than kept in two VGPRs through the scan (the kernel sits at an occupancy edge)
+        const long long it = (long long)((blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63)) * a.numSegments + blockIdx.y;
+        a.segBest[it] = tr.best;
+        a.segCnt[it] = tr.cnt;
     }
     if (a.wordSteps && lane == 0) atomicAdd(a.wordSteps, (unsigned long long)bandWork * 16ull * 64ull);
 }

@@ -185,3 +185,35 @@ def test_semiglobal_units_on_rings(engine, ref, oracle):
             _check(engine, impl, qs, ts, mode, task, -1, "semi-global rings")
         for k in (0, 5, 40):
             _check(engine, impl, qs, ts, mode, "locations", k, "semi-global rings fixed k")
+
+
+def test_switches_do_not_change_results(engine):
+    """EDLIB_AMD_NWBAND / NOPROBE / PEQFULL / BAND only choose kernels: every result field stays the same."""
+    import os
+    rng = random.Random(4108)
+    qs, ts = [], []
+    for i in range(320):
+        n = rng.choice([150, 700, 1000, 2500, 6000])
+        rate = rng.choice([0.0, 0.02, 0.1, 0.3])
+        t = synth.random_dna(rng.randrange(1 << 30), n)
+        q, _ = synth.mutate(t, rng.randrange(1 << 30), rate, rate / 3, rate / 3)
+        qs.append(q.tobytes() or b"A"); ts.append(t.tobytes())
+    target = synth.random_dna(5, 30000)
+    reads = synth.illumina_reads(target, 256, m=150, seed=9)["reads"]
+
+    def everything():
+        out = []
+        for mode, task in (("NW", "distance"), ("NW", "path"), ("HW", "locations"), ("SHW", "path")):
+            sel = slice(0, 320) if task != "path" else slice(0, 120)
+            out.append(engine.align_pairs(qs[sel], ts[sel], mode=mode, task=task, k=-1, raw=True))
+        out.append(engine.align_batch([r.tobytes() for r in reads], target.tobytes(), mode="HW", task="path", k=-1, raw=True))
+        return out
+
+    base = everything()
+    for var, val in (("EDLIB_AMD_NWBAND", "0"), ("EDLIB_AMD_NOPROBE", "1"), ("EDLIB_AMD_PEQFULL", "0"), ("EDLIB_AMD_BAND", "0")):
+        os.environ[var] = val
+        try:
+            got = everything()
+        finally:
+            del os.environ[var]
+        assert got == base, var
