@@ -394,10 +394,16 @@ __device__ __forceinline__ void column_step_eq1(const u32 eq0, u32 (&Pv)[NWD], u
 // here the row is picked by M0 and fetched with ds_read_addtid_b32 (address = M0 + offset + 4*lane: no
 // address VGPR, no VALU), one column ahead of its use.  hipcc does not count asm loads, so the wait is
 // explicit and names the destinations (cdna_hip_programming.md §5.7).
-#define EDLIB_AMD_LDS_LOAD2(sym, N0, N1)                                                                \
-    { const u32 m0v_ = ldsBase + ((sym) << 9);                                                           \
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:256" \
-                   : "=v"(N0), "=v"(N1) : "s"(m0v_) : "memory"); }
+// J = position (0..3) of the column's symbol in the quad byte sym4.  The wave's slice is 2 KB-aligned, so
+// the row offset (symbol << 9) is OR-ed into M0 directly: s_lshl + s_and + s_or per load (scalar issue is
+// not free here: tools/narrow_ubench.hip, 6 SALU per column cost as much as the LDS fetch itself).  These
+// SALU ops write SCC: it is declared clobbered (without that hipcc kept a loop condition in SCC across the
+// block and the kernel never terminated).
+#define EDLIB_AMD_LDS_LOAD2(sym4, J, N0, N1)                                                             \
+    { u32 off_;                                                                                           \
+      asm volatile("s_lshl_b32 %2, %3, %4\n\ts_and_b32 %2, %2, 0x600\n\ts_or_b32 m0, %2, %5\n\ts_nop 0\n\t" \
+                   "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:256"                  \
+                   : "=v"(N0), "=v"(N1), "=&s"(off_) : "s"(sym4), "n"(9 - 2 * (J)), "s"(ldsBase) : "memory", "scc"); }
 #define EDLIB_AMD_LDS_WAIT2(N0, N1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(N0), "+v"(N1))
 
 template <int NA, int NWD>
@@ -450,35 +456,47 @@ struct HwTrack {            // per-lane tracking state of the banded kernel
     int* pos;
 };
 
-// 16 columns (one packed dword) with NA active words, then the band checkpoint.  Returns the new nw.
+// Four columns (one byte of the packed target) with NA active words, then -- depending on NA and on the
+// position q of the quad in its dword -- the band checkpoint.  Returns the new number of active words.
+//
+// Checkpoint intervals: a band of ONE word is re-examined every 4 columns, of two words every 8, of more
+// every 16 (at the end of the dword).  With an interval of c columns the band must grow when the score S of
+// its bottom row is <= k + c: rows differ by at most 1, so S > k + c - 1 puts the bottom c rows above k, and
+// a cell <= k descends at most one row per column (values never decrease along a diagonal), so nothing below
+// the band can reach k before the next checkpoint.  The short interval is what keeps the first pass of the
+// k-doubling on one word: against unrelated sequence the score 32 rows down hovers around 13, far above
+// k + 4 for k <= 8 but not above k + 16.
+//
+// Narrow modes (NA <= 2 of more than two words) run on the LDS-staged Peq rows.
 template <int NA, int NWD>
-__device__ __forceinline__ int band_dword(const u32 tw, const int colBase, const int colEnd, const bool track,
-                                          const u32 (&E0)[NWD], const u32 (&E1)[NWD], const u32 (&E2)[NWD],
-                                          const u32 (&E3)[NWD], u32 (&Pv)[NWD], u32 (&Mv)[NWD],
-                                          int& e, int& flag, HwTrack& tr, const u32 sh, const int lastRows,
-                                          const u32 ldsBase)
+__device__ __forceinline__ int band_quad(const u32 sym4, const int q, const int colBase,
+                                         const int colEnd, const bool track,
+                                         const u32 (&E0)[NWD], const u32 (&E1)[NWD], const u32 (&E2)[NWD],
+                                         const u32 (&E3)[NWD], u32 (&Pv)[NWD], u32 (&Mv)[NWD],
+                                         int& e, int& flag, HwTrack& tr, const u32 sh, const int lastRows,
+                                         const u32 ldsBase, const ReadScanArgs& a)
 {
-  if constexpr (NA <= 2 && NWD > 2) {
-    // narrow band: straight-line code, Peq rows from LDS one column ahead (nothing is tracked: the
-    // bottom row is outside the band)
-    // (a two-column-deep prefetch with lgkmcnt(2) measured 2 % slower: with 7 waves per SIMD the LDS
-    // latency is already covered)
-    u32 n0, n1;
-    EDLIB_AMD_LDS_LOAD2(tw & 3u, n0, n1)
+    constexpr bool narrow = NA <= 2 && NWD > 2;
+    if constexpr (narrow) {
+        // straight-line code, Peq rows from LDS one column ahead (nothing is tracked: the bottom row is
+        // outside the band).  The first load of a quad is exposed; the other waves of the SIMD cover it
+        // (carrying the request across quads costs two VGPRs and with them a wave of occupancy).
+        u32 n0, n1;
+        EDLIB_AMD_LDS_LOAD2(sym4, 0, n0, n1)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        EDLIB_AMD_LDS_WAIT2(n0, n1);
-        const u32 e0 = n0, e1 = n1;
-        if (j < 15) { EDLIB_AMD_LDS_LOAD2((tw >> (2 * (j + 1))) & 3u, n0, n1) }
-        if constexpr (NA == 2) column_step_eq2<NWD>(e0, e1, Pv, Mv); else column_step_eq1<NWD>(e0, Pv, Mv);
-    }
-  } else {
-#pragma unroll
-    for (int blk = 0; blk < 4; ++blk) {
+        for (int j = 0; j < 4; ++j) {
+            EDLIB_AMD_LDS_WAIT2(n0, n1);
+            const u32 e0 = n0, e1 = n1;
+            if (j == 0) { EDLIB_AMD_LDS_LOAD2(sym4, 1, n0, n1) }
+            if (j == 1) { EDLIB_AMD_LDS_LOAD2(sym4, 2, n0, n1) }
+            if (j == 2) { EDLIB_AMD_LDS_LOAD2(sym4, 3, n0, n1) }
+            if constexpr (NA == 2) column_step_eq2<NWD>(e0, e1, Pv, Mv); else column_step_eq1<NWD>(e0, Pv, Mv);
+        }
+    } else {
         int eh[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const u32 sym = (tw >> (2 * (blk * 4 + j))) & 3u;
+            const u32 sym = (sym4 >> (2 * j)) & 3u;
             EDLIB_AMD_DISPATCH_HW(sym)
             eh[j] = e;
         }
@@ -487,7 +505,7 @@ __device__ __forceinline__ int band_dword(const u32 tw, const int colBase, const
                 const int bestIn = tr.best;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int col = colBase + blk * 4 + j;
+                    const int col = colBase + j;
                     const int sc = eh[j] + bestIn + 1;
                     const bool hit = (sc <= tr.best) && (col < colEnd);     // edlib.cpp:658-673
                     const bool better = hit && (sc < tr.best);
@@ -501,30 +519,60 @@ __device__ __forceinline__ int band_dword(const u32 tw, const int colBase, const
             }
         }
     }
-  }
-    // ---- band checkpoint: scores of the bottom rows of the last two active words (computed values:
-    // exact when <= k, otherwise upper bounds that still exceed k, which is all the rules below use)
-    int Sprev = 0;
-#pragma unroll
-    for (int i = 0; i + 1 < NA; ++i) Sprev += __popc(Pv[i]) - __popc(Mv[i]);
-    const int S = Sprev + __popc(Pv[NA - 1]) - __popc(Mv[NA - 1]);
-    if (NA < NWD) {
-        // grow unless the bottom 16 rows of the band all exceed k (adjacent rows differ by <= 1, so
-        // S > k+15 is sufficient); cells <= k descend at most one row per column, hence nothing below
-        // the band can reach k before the next checkpoint
-        if (__builtin_amdgcn_ballot_w64(S <= tr.best + 16) != 0ull) {
-            Pv[NA] = ~0u; Mv[NA] = 0u;                                      // "+1 per row", edlib.cpp:605-608
-            if (NA + 1 == NWD) { e = S + lastRows - tr.best - 1; flag = 0; } // row m-1 is lastRows rows below
-            return NA + 1;
+    // ---- band checkpoints.  Scores are computed values: exact when <= k, otherwise upper bounds that still
+    // exceed k, which is all the rules use.  HW: the row above the band's top is all zeros.
+    if constexpr (NA == 1) {
+        if constexpr (NWD > 1) {
+            const int s1p = __popc(Pv[0]) + __popc(~Mv[0]);                 // S1 + 32
+            if (__builtin_amdgcn_ballot_w64(s1p <= tr.best + 36) != 0ull) { // S1 <= k + 4: second word
+                Pv[1] = ~0u; Mv[1] = 0u;                                    // "+1 per row", edlib.cpp:605-608
+                if (NWD == 2) { e = (s1p - 32) + lastRows - tr.best - 1; flag = 0; }
+                return 2;
+            }
         }
+        return 1;
+    } else if constexpr (NA == 2) {
+        if (q & 1) {                                                        // every 8 columns
+            const int S1 = __popc(Pv[0]) - __popc(Mv[0]);
+            const int S2 = S1 + __popc(Pv[1]) - __popc(Mv[1]);
+            if constexpr (NWD > 2) {
+                if (__builtin_amdgcn_ballot_w64(S2 <= tr.best + 8) != 0ull) {
+                    Pv[2] = ~0u; Mv[2] = 0u;
+                    if (NWD == 3) { e = S2 + lastRows - tr.best - 1; flag = 0; }
+                    return 3;
+                }
+            }
+            // back to one word when (a) every cell of the second word exceeds k -- in a span of 8 rows between
+            // scores A (row above it) and B (its last row) a cell j rows down is >= max(A - j, B - (8 - j))
+            // >= (A + B - 8) / 2 -- and (b) the bottom 4 rows of the first word do too
+            const int k2 = 2 * tr.best + 9;
+            const int sa = S1 + __popc(Pv[1] & 0xffu) - __popc(Mv[1] & 0xffu);
+            const int sb = S1 + __popc(Pv[1] & 0xffffu) - __popc(Mv[1] & 0xffffu);
+            const int sc = S1 + __popc(Pv[1] & 0xffffffu) - __popc(Mv[1] & 0xffffffu);
+            const bool keep = (S1 <= tr.best + 4) || (S1 + sa <= k2) || (sa + sb <= k2) || (sb + sc <= k2) || (sc + S2 <= k2);
+            if (__builtin_amdgcn_ballot_w64(keep) == 0ull) return 1;
+        }
+        return 2;
+    } else {
+        if (q == 3) {                                                       // end of the dword: every 16 columns
+            int Sprev = 0;
+#pragma unroll
+            for (int i = 0; i + 1 < NA; ++i) Sprev += __popc(Pv[i]) - __popc(Mv[i]);
+            const int S = Sprev + __popc(Pv[NA - 1]) - __popc(Mv[NA - 1]);
+            if constexpr (NA < NWD) {
+                if (__builtin_amdgcn_ballot_w64(S <= tr.best + 16) != 0ull) {
+                    Pv[NA < NWD ? NA : 0] = ~0u; Mv[NA < NWD ? NA : 0] = 0u;
+                    if (NA + 1 == NWD) { e = S + lastRows - tr.best - 1; flag = 0; } // row m-1 is lastRows rows below
+                    return NA + 1;
+                }
+            }
+            // drop the last word when (a) every cell of it exceeds k: a cell j rows below Sprev's row is
+            // >= max(Sprev - j, S - (32 - j)) >= (Sprev + S - 32) / 2, and (b) the new bottom 16 rows do too
+            const bool keep = (Sprev <= tr.best + 16) || (Sprev + S <= 2 * tr.best + 34);
+            if (__builtin_amdgcn_ballot_w64(keep) == 0ull) return NA - 1;
+        }
+        return NA;
     }
-    if (NA > 1) {
-        // drop the last word when (a) every cell of it exceeds k: a cell j rows below Sprev's row is
-        // >= max(Sprev - j, S - (32 - j)) >= (Sprev + S - 32) / 2, and (b) the new bottom 16 rows do too
-        const bool keep = (Sprev <= tr.best + 16) || (Sprev + S <= 2 * tr.best + 34);
-        if (__builtin_amdgcn_ballot_w64(keep) == 0ull) return NA - 1;
-    }
-    return NA;
 }
 
 template <int NWD>
@@ -556,7 +604,7 @@ scan_reads_banded_kernel(const ReadScanArgs a)
         }
     }
     // first two words of the four Peq rows -> LDS (narrow-band path)
-    __shared__ u32 s_eq[4][4][2][64];
+    __shared__ __attribute__((aligned(2048))) u32 s_eq[4][4][2][64];   // 2 KB per wave (EDLIB_AMD_LDS_LOAD2)
     const int wv = threadIdx.x >> 6;
     {
         const u32* e[4] = {E0, E1, E2, E3};
@@ -569,16 +617,18 @@ scan_reads_banded_kernel(const ReadScanArgs a)
     }
     const u32 ldsBase = __builtin_amdgcn_readfirstlane(
         (u32)(size_t)(__attribute__((address_space(3))) u32*)&s_eq[wv][0][0][0]);
-    const long long item = (long long)idx * a.numSegments + seg;
     HwTrack tr;
     {
         const int k0 = a.kinit[slot];
         tr.best = k0 < a.kcap ? k0 : a.kcap;
     }
     tr.cnt = 0;
-    // lanes past nlanes (the tail of the last wave) own no record: they must not even read the tables
-    tr.cap = live ? (a.posCap ? a.posCap[item] : a.cap) : 0;
-    tr.pos = a.segPos + (!live ? 0 : (a.posOff ? a.posOff[item] : item * a.cap));
+    {
+        // lanes past nlanes (the tail of the last wave) own no record: they must not even read the tables
+        const long long item = (long long)idx * a.numSegments + seg;   // (lane, segment) record
+        tr.cap = live ? (a.posCap ? a.posCap[item] : a.cap) : 0;
+        tr.pos = a.segPos + (!live ? 0 : (a.posOff ? a.posOff[item] : item * a.cap));
+    }
     int e = m - tr.best - 1;                                          // score at column -1 is m
     int flag = 0;
 
@@ -588,15 +638,26 @@ scan_reads_banded_kernel(const ReadScanArgs a)
     int cw = c0 - a.warm; if (cw < 0) cw = 0;
     const int w0 = cw >> 4, wmain = c0 >> 4, wend = (c1 + 15) >> 4;
     int nw = NWD;
-    unsigned int bandWork = 0;                                        // sum of nw over the dwords (wave-uniform)
-    // (fetching the next packed dword one iteration ahead through an opaque-zero VGPR address measured
-    // no gain: with 7 waves per SIMD the load latency is already covered)
-    for (int w = w0; w < wend; ++w) {
-        const u32 tw = a.tpk[w];
-        const bool track = w >= wmain;                                // warm-up columns record nothing
-        bandWork += (unsigned int)nw;
+    unsigned int bandWork = 0;                                        // sum of nw over the quads (wave-uniform)
+    // One inner loop per band height: a quad that leaves the height unchanged jumps straight back into the
+    // same code with every live value where it was (one switch around single quads made hipcc shuffle
+    // ~26 registers per quad between the cases).
+    int w = w0, q = 0;
+    u32 tw = w0 < wend ? a.tpk[w0] : 0u;
+    while (w < wend) {
         switch (nw) {
-#define CASE(NA) case NA: if (NA <= NWD) nw = band_dword<(NA <= NWD ? NA : NWD), NWD>(tw, w * 16, c1, track, E0, E1, E2, E3, Pv, Mv, e, flag, tr, sh, lastRows, ldsBase); break;
+#define CASE(NA) case NA:                                                                                   \
+            if (NA <= NWD) {                                                                                \
+                do {                                                                                        \
+                    bandWork += (unsigned int)NA;                                                           \
+                    nw = band_quad<(NA <= NWD ? NA : NWD), NWD>((tw >> (8 * q)) & 0xffu, q, w * 16 + q * 4, c1, \
+                             w >= wmain /* warm-up columns record nothing */, E0, E1, E2, E3, Pv, Mv, e, flag, \
+                             tr, sh, lastRows, ldsBase, a);                                                 \
+                    q = (q + 1) & 3;                                                                        \
+                    if (q == 0) { ++w; if (w < wend) tw = a.tpk[w]; }                                       \
+                } while (nw == NA && w < wend);                                                             \
+            }                                                                                               \
+            break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
         }
@@ -607,7 +668,7 @@ scan_reads_banded_kernel(const ReadScanArgs a)
         a.segBest[it] = tr.best;
         a.segCnt[it] = tr.cnt;
     }
-    if (a.wordSteps && lane == 0) atomicAdd(a.wordSteps, (unsigned long long)bandWork * 16ull * 64ull);
+    if (a.wordSteps && lane == 0) atomicAdd(a.wordSteps, (unsigned long long)bandWork * 4ull * 64ull);
 }
 
 hipError_t launch_scan_reads_banded(int nwords, const ReadScanArgs& a, hipStream_t stream)
