@@ -455,7 +455,7 @@ int Batch::runReads()
     // unknown mode values are computed as NW (edlib.cpp:205-215)
     const int mode = (cfg_.mode == EDLIB_MODE_HW || cfg_.mode == EDLIB_MODE_SHW) ? (int)cfg_.mode : (int)EDLIB_MODE_NW;
     const bool banded = banded_ && mode == EDLIB_MODE_HW;
-    const int kFirst = 8;                   // first threshold of the k-doubling (edlib.cpp:197-217 starts at 64)
+    const int kFirstMax = 8;                // first threshold of the k-doubling (edlib.cpp:197-217 starts at 64)
     const int kNoCap = 0x3fffffff;
     stats.path |= 1;
     EDLIB_AMD_HIP(hipMemsetAsync(d_wordSteps_.p, 0, sizeof(unsigned long long), stream_));
@@ -466,6 +466,7 @@ int Batch::runReads()
                                              d_eqtbl4_.p, d_presence_.p, cfg_.k, g.d_peq.p, g.d_qlen.p,
                                              g.d_kinit.p, g.d_alphaExtra.p, stream_));
         // ---- pass 1: all slots; banded: threshold min(k, kFirst)
+        int kFirst = kFirstMax;
         bool twoPass = banded && (cfg_.k < 0 || cfg_.k > kFirst) && 32 * g.nwords > kFirst;
         if (twoPass && g.nslots >= 16384) {
             // k-doubling only pays when most units resolve at the small threshold (pass 1 costs ~2/NWD of a
@@ -483,14 +484,28 @@ int Batch::runReads()
             EDLIB_AMD_HIP(hipMemcpyAsync(d_map.p, probe.data(), np * sizeof(int), hipMemcpyHostToDevice, stream_));
             if (scanGroup(g, mode, d_map.p, np, kFirst, g.d_kinit.p, S2, segLen2, warm2,
                           d_sb.p, d_sc.p, d_sb.p /*unused*/, 0, nullptr, nullptr)) return 1;
-            std::vector<int> cnts(items);
+            std::vector<int> cnts(items), bests(items);
             EDLIB_AMD_HIP(hipMemcpyAsync(cnts.data(), d_sc.p, items * sizeof(int), hipMemcpyDeviceToHost, stream_));
+            EDLIB_AMD_HIP(hipMemcpyAsync(bests.data(), d_sb.p, items * sizeof(int), hipMemcpyDeviceToHost, stream_));
             EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
             int resolved = 0, real = 0;
+            std::vector<int> hist(kFirstMax + 1, 0);                  // distances of the resolved probe reads
             for (int i = 0; i < np; ++i) {
                 if (g.perm[probe[i]] < 0) continue;
                 ++real;
-                for (int sg = 0; sg < S2; ++sg) if (cnts[(size_t)i * S2 + sg] > 0) { ++resolved; break; }
+                int b = 0x7fffffff;
+                for (int sg = 0; sg < S2; ++sg)
+                    if (cnts[(size_t)i * S2 + sg] > 0) b = std::min(b, bests[(size_t)i * S2 + sg]);
+                if (b <= kFirstMax) { ++resolved; ++hist[std::max(b, 0)]; }
+            }
+            // The band of pass 1 is one 32-row word while the score 32 rows down stays above k + 4; against
+            // unrelated sequence that score hovers around 13, so every unit of k below 8 keeps the second
+            // word out more often.  Take the smallest threshold (>= 4) that still resolves 99.5 % of what 8
+            // resolves: the few reads above it just join pass 2.
+            if (resolved > 0) {
+                int acc = 0, kq = kFirstMax;
+                for (int d = 0; d <= kFirstMax; ++d) { acc += hist[d]; if (acc * 1000LL >= resolved * 995LL) { kq = d; break; } }
+                kFirst = std::max(4, std::min(kFirstMax, kq));
             }
             if (real > 0 && resolved * 10 < real * 3) twoPass = false;
         }
