@@ -523,10 +523,12 @@ __device__ __forceinline__ int band_quad(const u32 sym4, const int q, const int 
     // exceed k, which is all the rules use.  HW: the row above the band's top is all zeros.
     if constexpr (NA == 1) {
         if constexpr (NWD > 1) {
-            const int s1p = __popc(Pv[0]) + __popc(~Mv[0]);                 // S1 + 32
-            if (__builtin_amdgcn_ballot_w64(s1p <= tr.best + 36) != 0ull) { // S1 <= k + 4: second word
+            // S1 = popc(Pv) - popc(Mv) <= k + 4: second word.  Written so that the loop-invariant k + 4 rides
+            // in the accumulator operand of v_bcnt: two v_bcnt and one v_cmp per quad
+            const int up = __popc(Pv[0]), dn = __popc(Mv[0]) + (tr.best + 4);
+            if (__builtin_amdgcn_ballot_w64(up <= dn) != 0ull) {
                 Pv[1] = ~0u; Mv[1] = 0u;                                    // "+1 per row", edlib.cpp:605-608
-                if (NWD == 2) { e = (s1p - 32) + lastRows - tr.best - 1; flag = 0; }
+                if (NWD == 2) { e = (up - __popc(Mv[0])) + lastRows - tr.best - 1; flag = 0; }
                 return 2;
             }
         }
