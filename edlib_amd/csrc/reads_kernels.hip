@@ -389,25 +389,66 @@ __device__ __forceinline__ void column_step_eq1(const u32 eq0, u32 (&Pv)[NWD], u
     Mv[0] = ph & Xv;
 }
 
-// Peq rows of the first two words staged in LDS, [wave][symbol][word][lane]: with one or two active
-// words the branchy dispatch would be scalar-issue bound (~12 SALU + 3 taken branches per 17 VALU);
-// here the row is picked by M0 and fetched with ds_read_addtid_b32 (address = M0 + offset + 4*lane: no
-// address VGPR, no VALU), one column ahead of its use.  hipcc does not count asm loads, so the wait is
-// explicit and names the destinations (cdna_hip_programming.md §5.7).
-// J = position (0..3) of the column's symbol in the quad byte sym4.  The wave's slice is 2 KB-aligned, so
-// the row offset (symbol << 9) is OR-ed into M0 directly: s_lshl + s_and + s_or per load (scalar issue is
-// not free here: tools/narrow_ubench.hip, 6 SALU per column cost as much as the LDS fetch itself).  These
-// SALU ops write SCC: it is declared clobbered (without that hipcc kept a loop condition in SCC across the
-// block and the kernel never terminated).
-#define EDLIB_AMD_LDS_LOAD2(sym4, J, N0, N1)                                                             \
-    { u32 off_;                                                                                           \
-      asm volatile("s_lshl_b32 %2, %3, %4\n\ts_and_b32 %2, %2, 0x600\n\ts_or_b32 m0, %2, %5\n\ts_nop 0\n\t" \
-                   "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:256"                  \
-                   : "=v"(N0), "=v"(N1), "=&s"(off_) : "s"(sym4), "n"(9 - 2 * (J)), "s"(ldsBase) : "memory", "scc"); }
-#define EDLIB_AMD_LDS_WAIT2(N0, N1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(N0), "+v"(N1))
+// All Peq rows of the wave's 64 queries live in LDS as [wave][word][symbol][lane] (1 KB per word).  The row of
+// a column's symbol is picked by M0 = slice base | symbol << 8 and fetched with ds_read_addtid_b32 (address =
+// M0 + offset + 4*lane: no address VGPR, no VALU), word w at offset 1024*w, one column ahead of its use:
+// no symbol dispatch in the instruction stream and no Peq registers (4 x NWD VGPRs less than the
+// register-resident version, one more wave per SIMD at NWD = 5).  hipcc does not count asm loads, so the wait
+// is explicit and names the destinations (cdna_hip_programming.md §5.7).
+// J = position (0..3) of the column's symbol in the quad byte sym4.  The wave's slice is 1 KB-aligned, so the
+// row offset is OR-ed into M0 directly: s_lshl + s_and + s_or per column (scalar issue is not free here:
+// tools/narrow_ubench.hip, 6 SALU per column cost as much as the LDS fetch itself).  These SALU ops write
+// SCC: it is declared clobbered (without that hipcc kept a loop condition in SCC across the block and the
+// kernel never terminated).
+#define EDLIB_AMD_M0_ROW "s_lshl_b32 %[t], %[s4], %[sh]\n\ts_and_b32 %[t], %[t], 0x300\n\ts_or_b32 m0, %[t], %[base]\n\ts_nop 0\n\t"
+#define EDLIB_AMD_M0_OPS [t] "=&s"(off_) : [s4] "s"(sym4), [sh] "n"(8 - 2 * J), [base] "s"(ldsBase) : "memory", "scc"
+template <int NA, int J>
+__device__ __forceinline__ void lds_rows_request(u32 (&n)[NA], const u32 sym4, const u32 ldsBase)
+{
+    u32 off_;
+    static_assert(NA >= 1 && NA <= 8, "band height");
+    if constexpr (NA == 1) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0" : "=v"(n[0]), EDLIB_AMD_M0_OPS);
+    if constexpr (NA == 2) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024"
+                                        : "=v"(n[0]), "=v"(n[1]), EDLIB_AMD_M0_OPS);
+    if constexpr (NA == 3) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024\n\t"
+                                        "ds_read_addtid_b32 %2 offset:2048" : "=v"(n[0]), "=v"(n[1]), "=v"(n[2]), EDLIB_AMD_M0_OPS);
+    if constexpr (NA == 4) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024\n\t"
+                                        "ds_read_addtid_b32 %2 offset:2048\n\tds_read_addtid_b32 %3 offset:3072"
+                                        : "=v"(n[0]), "=v"(n[1]), "=v"(n[2]), "=v"(n[3]), EDLIB_AMD_M0_OPS);
+    if constexpr (NA == 5) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024\n\t"
+                                        "ds_read_addtid_b32 %2 offset:2048\n\tds_read_addtid_b32 %3 offset:3072\n\t"
+                                        "ds_read_addtid_b32 %4 offset:4096"
+                                        : "=v"(n[0]), "=v"(n[1]), "=v"(n[2]), "=v"(n[3]), "=v"(n[4]), EDLIB_AMD_M0_OPS);
+    if constexpr (NA == 6) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024\n\t"
+                                        "ds_read_addtid_b32 %2 offset:2048\n\tds_read_addtid_b32 %3 offset:3072\n\t"
+                                        "ds_read_addtid_b32 %4 offset:4096\n\tds_read_addtid_b32 %5 offset:5120"
+                                        : "=v"(n[0]), "=v"(n[1]), "=v"(n[2]), "=v"(n[3]), "=v"(n[4]), "=v"(n[5]), EDLIB_AMD_M0_OPS);
+    if constexpr (NA == 7) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024\n\t"
+                                        "ds_read_addtid_b32 %2 offset:2048\n\tds_read_addtid_b32 %3 offset:3072\n\t"
+                                        "ds_read_addtid_b32 %4 offset:4096\n\tds_read_addtid_b32 %5 offset:5120\n\t"
+                                        "ds_read_addtid_b32 %6 offset:6144"
+                                        : "=v"(n[0]), "=v"(n[1]), "=v"(n[2]), "=v"(n[3]), "=v"(n[4]), "=v"(n[5]), "=v"(n[6]), EDLIB_AMD_M0_OPS);
+    if constexpr (NA == 8) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024\n\t"
+                                        "ds_read_addtid_b32 %2 offset:2048\n\tds_read_addtid_b32 %3 offset:3072\n\t"
+                                        "ds_read_addtid_b32 %4 offset:4096\n\tds_read_addtid_b32 %5 offset:5120\n\t"
+                                        "ds_read_addtid_b32 %6 offset:6144\n\tds_read_addtid_b32 %7 offset:7168"
+                                        : "=v"(n[0]), "=v"(n[1]), "=v"(n[2]), "=v"(n[3]), "=v"(n[4]), "=v"(n[5]), "=v"(n[6]), "=v"(n[7]), EDLIB_AMD_M0_OPS);
+}
+template <int NA>
+__device__ __forceinline__ void lds_rows_wait(u32 (&n)[NA])
+{
+    if constexpr (NA == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]));
+    if constexpr (NA == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]), "+v"(n[1]));
+    if constexpr (NA == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]));
+    if constexpr (NA == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]));
+    if constexpr (NA == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]), "+v"(n[4]));
+    if constexpr (NA == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]), "+v"(n[4]), "+v"(n[5]));
+    if constexpr (NA == 7) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]), "+v"(n[4]), "+v"(n[5]), "+v"(n[6]));
+    if constexpr (NA == 8) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]), "+v"(n[4]), "+v"(n[5]), "+v"(n[6]), "+v"(n[7]));
+}
 
 template <int NA, int NWD>
-__device__ __forceinline__ void column_step_hw(const u32 (&Eq)[NWD], u32 (&Pv)[NWD], u32 (&Mv)[NWD],
+__device__ __forceinline__ void column_step_hw(const u32 (&Eq)[NA], u32 (&Pv)[NWD], u32 (&Mv)[NWD],
                                                int& e, int& flag, const u32 sh)
 {
     u32 Ph[NA], Mh[NA];
@@ -443,14 +484,6 @@ __device__ __forceinline__ void column_step_hw(const u32 (&Eq)[NWD], u32 (&Pv)[N
     }
 }
 
-#define EDLIB_AMD_DISPATCH_HW(sym)                                                              \
-    switch (sym) {                                                                              \
-        case 0:  column_step_hw<NA, NWD>(E0, Pv, Mv, e, flag, sh); asm volatile("; sym0"); break;  \
-        case 1:  column_step_hw<NA, NWD>(E1, Pv, Mv, e, flag, sh); asm volatile("; sym1"); break;  \
-        case 2:  column_step_hw<NA, NWD>(E2, Pv, Mv, e, flag, sh); asm volatile("; sym2"); break;  \
-        default: column_step_hw<NA, NWD>(E3, Pv, Mv, e, flag, sh); asm volatile("; sym3"); break;  \
-    }
-
 struct HwTrack {            // per-lane tracking state of the banded kernel
     int best, cnt, cap;
     int* pos;
@@ -466,57 +499,48 @@ struct HwTrack {            // per-lane tracking state of the banded kernel
 // the band can reach k before the next checkpoint.  The short interval is what keeps the first pass of the
 // k-doubling on one word: against unrelated sequence the score 32 rows down hovers around 13, far above
 // k + 4 for k <= 8 but not above k + 16.
-//
-// Narrow modes (NA <= 2 of more than two words) run on the LDS-staged Peq rows.
 template <int NA, int NWD>
 __device__ __forceinline__ int band_quad(const u32 sym4, const int q, const int colBase,
-                                         const int colEnd, const bool track,
-                                         const u32 (&E0)[NWD], const u32 (&E1)[NWD], const u32 (&E2)[NWD],
-                                         const u32 (&E3)[NWD], u32 (&Pv)[NWD], u32 (&Mv)[NWD],
+                                         const int colEnd, const bool track, u32 (&Pv)[NWD], u32 (&Mv)[NWD],
                                          int& e, int& flag, HwTrack& tr, const u32 sh, const int lastRows,
-                                         const u32 ldsBase, const ReadScanArgs& a)
+                                         const u32 ldsBase)
 {
-    constexpr bool narrow = NA <= 2 && NWD > 2;
-    if constexpr (narrow) {
-        // straight-line code, Peq rows from LDS one column ahead (nothing is tracked: the bottom row is
-        // outside the band).  The first load of a quad is exposed; the other waves of the SIMD cover it
-        // (carrying the request across quads costs two VGPRs and with them a wave of occupancy).
-        u32 n0, n1;
-        EDLIB_AMD_LDS_LOAD2(sym4, 0, n0, n1)
+    // straight-line code: the Peq rows of a column arrive from LDS while the previous column is computed.
+    // The first request of a quad is exposed; the other waves of the SIMD cover it (carrying it across quads
+    // costs registers, and with them occupancy; tools/narrow_ubench.hip: deeper prefetch buys nothing).
+    int eh[4];
+    u32 nx[NA];
+    lds_rows_request<NA, 0>(nx, sym4, ldsBase);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            EDLIB_AMD_LDS_WAIT2(n0, n1);
-            const u32 e0 = n0, e1 = n1;
-            if (j == 0) { EDLIB_AMD_LDS_LOAD2(sym4, 1, n0, n1) }
-            if (j == 1) { EDLIB_AMD_LDS_LOAD2(sym4, 2, n0, n1) }
-            if (j == 2) { EDLIB_AMD_LDS_LOAD2(sym4, 3, n0, n1) }
-            if constexpr (NA == 2) column_step_eq2<NWD>(e0, e1, Pv, Mv); else column_step_eq1<NWD>(e0, Pv, Mv);
-        }
-    } else {
-        int eh[4];
+    for (int j = 0; j < 4; ++j) {
+        lds_rows_wait<NA>(nx);
+        u32 eq[NA];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const u32 sym = (sym4 >> (2 * j)) & 3u;
-            EDLIB_AMD_DISPATCH_HW(sym)
-            eh[j] = e;
-        }
-        if (NA == NWD) {
-            if (track && __builtin_amdgcn_ballot_w64(flag < 0) != 0ull) {   // wave-uniform
-                const int bestIn = tr.best;
+        for (int i = 0; i < NA; ++i) eq[i] = nx[i];
+        if (j == 0) lds_rows_request<NA, 1>(nx, sym4, ldsBase);
+        if (j == 1) lds_rows_request<NA, 2>(nx, sym4, ldsBase);
+        if (j == 2) lds_rows_request<NA, 3>(nx, sym4, ldsBase);
+        if constexpr (NA == 1 && NWD > 1) column_step_eq1<NWD>(eq[0], Pv, Mv);          // nothing tracked: the
+        else if constexpr (NA == 2 && NWD > 2) column_step_eq2<NWD>(eq[0], eq[1], Pv, Mv);   // bottom row is outside
+        else column_step_hw<NA, NWD>(eq, Pv, Mv, e, flag, sh);
+        eh[j] = e;
+    }
+    if (NA == NWD) {
+        if (track && __builtin_amdgcn_ballot_w64(flag < 0) != 0ull) {   // wave-uniform
+            const int bestIn = tr.best;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int col = colBase + j;
-                    const int sc = eh[j] + bestIn + 1;
-                    const bool hit = (sc <= tr.best) && (col < colEnd);     // edlib.cpp:658-673
-                    const bool better = hit && (sc < tr.best);
-                    tr.cnt = better ? 0 : tr.cnt;
-                    tr.best = better ? sc : tr.best;
-                    if (hit && tr.cnt < tr.cap) tr.pos[tr.cnt] = col;
-                    tr.cnt += hit ? 1 : 0;
-                }
-                e = eh[3] + bestIn - tr.best;                               // rebase e on the new best
-                flag = 0;
+            for (int j = 0; j < 4; ++j) {
+                const int col = colBase + j;
+                const int sc = eh[j] + bestIn + 1;
+                const bool hit = (sc <= tr.best) && (col < colEnd);     // edlib.cpp:658-673
+                const bool better = hit && (sc < tr.best);
+                tr.cnt = better ? 0 : tr.cnt;
+                tr.best = better ? sc : tr.best;
+                if (hit && tr.cnt < tr.cap) tr.pos[tr.cnt] = col;
+                tr.cnt += hit ? 1 : 0;
             }
+            e = eh[3] + bestIn - tr.best;                               // rebase e on the new best
+            flag = 0;
         }
     }
     // ---- band checkpoints.  Scores are computed values: exact when <= k, otherwise upper bounds that still
@@ -589,33 +613,23 @@ scan_reads_banded_kernel(const ReadScanArgs a)
     const bool live = idx < a.nlanes;
     const int slot = live ? (a.slotmap ? a.slotmap[idx] : idx) : 0;
 
-    u32 E0[NWD], E1[NWD], E2[NWD], E3[NWD], Pv[NWD], Mv[NWD];
+    u32 Pv[NWD], Mv[NWD];
     const int m = a.qlen[slot];
     const u32 sh = (u32)(m - 1) & 31u;                                // row m-1 inside the last word
     const int lastRows = m - 32 * (NWD - 1);                          // query rows in the last word
+    // the four Peq rows of the wave's queries: HBM -> LDS, [wave][word][symbol][lane] (1 KB-aligned slices)
+    __shared__ __attribute__((aligned(1024))) u32 s_eq[4][NWD][4][64];
+    const int wv = threadIdx.x >> 6;
     {
         const size_t pb = (size_t)(slot >> 6) * 4 * NWD * 64 + (slot & 63);
 #pragma unroll
         for (int d = 0; d < NWD; ++d) {
-            E0[d] = a.peq[pb + (size_t)(0 * NWD + d) * 64];
-            E1[d] = a.peq[pb + (size_t)(1 * NWD + d) * 64];
-            E2[d] = a.peq[pb + (size_t)(2 * NWD + d) * 64];
-            E3[d] = a.peq[pb + (size_t)(3 * NWD + d) * 64];
+#pragma unroll
+            for (int sy = 0; sy < 4; ++sy) s_eq[wv][d][sy][lane] = a.peq[pb + (size_t)(sy * NWD + d) * 64];
             Pv[d] = ~0u;                                             // column -1: D[i][-1] = i+1
             Mv[d] = 0u;
         }
-    }
-    // first two words of the four Peq rows -> LDS (narrow-band path)
-    __shared__ __attribute__((aligned(2048))) u32 s_eq[4][4][2][64];   // 2 KB per wave (EDLIB_AMD_LDS_LOAD2)
-    const int wv = threadIdx.x >> 6;
-    {
-        const u32* e[4] = {E0, E1, E2, E3};
-#pragma unroll
-        for (int sy = 0; sy < 4; ++sy) {
-            s_eq[wv][sy][0][lane] = e[sy][0];
-            s_eq[wv][sy][1][lane] = (NWD > 1) ? e[sy][NWD > 1 ? 1 : 0] : 0u;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     const u32 ldsBase = __builtin_amdgcn_readfirstlane(
         (u32)(size_t)(__attribute__((address_space(3))) u32*)&s_eq[wv][0][0][0]);
@@ -645,7 +659,8 @@ scan_reads_banded_kernel(const ReadScanArgs a)
     // same code with every live value where it was (one switch around single quads made hipcc shuffle
     // ~26 registers per quad between the cases).
     int w = w0, q = 0;
-    u32 tw = w0 < wend ? a.tpk[w0] : 0u;
+    // (v_readfirstlane: the "s" asm operands below do not scalarise a uniform value that sits in a VGPR)
+    u32 tw = w0 < wend ? (u32)__builtin_amdgcn_readfirstlane(a.tpk[w0]) : 0u;
     while (w < wend) {
         switch (nw) {
 #define CASE(NA) case NA:                                                                                   \
@@ -653,10 +668,10 @@ scan_reads_banded_kernel(const ReadScanArgs a)
                 do {                                                                                        \
                     bandWork += (unsigned int)NA;                                                           \
                     nw = band_quad<(NA <= NWD ? NA : NWD), NWD>((tw >> (8 * q)) & 0xffu, q, w * 16 + q * 4, c1, \
-                             w >= wmain /* warm-up columns record nothing */, E0, E1, E2, E3, Pv, Mv, e, flag, \
-                             tr, sh, lastRows, ldsBase, a);                                                 \
+                             w >= wmain /* warm-up columns record nothing */, Pv, Mv, e, flag, \
+                             tr, sh, lastRows, ldsBase);                                                 \
                     q = (q + 1) & 3;                                                                        \
-                    if (q == 0) { ++w; if (w < wend) tw = a.tpk[w]; }                                       \
+                    if (q == 0) { ++w; if (w < wend) tw = (u32)__builtin_amdgcn_readfirstlane(a.tpk[w]); }  \
                 } while (nw == NA && w < wend);                                                             \
             }                                                                                               \
             break;
