@@ -602,7 +602,7 @@ __device__ __forceinline__ int band_quad(const u32 sym4, const int q, const int 
 }
 
 template <int NWD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NWD <= 5 ? 8 : 1, 8)))
 scan_reads_banded_kernel(const ReadScanArgs a)
 {
     const int lane = threadIdx.x & 63;
