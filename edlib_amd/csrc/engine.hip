@@ -404,7 +404,7 @@ static void finalize_global(UnitResult& r, int kcfg, int mode, int T, int score)
 // One scan launch over a group's slots (or a subset through d_slotmap), banded or not.
 int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, int kcap, const int* d_kinit,
                      int numSegments, int segLen, int warm, int* segBest, int* segCnt, int* segPos, int cap,
-                     const long long* posOff, const int* posCap)
+                     const long long* posOff, const int* posCap, bool unbanded, unsigned long long* wordSteps)
 {
     ReadScanArgs a{};
     a.peq = g.d_peq.p; a.tpk = d_tpk_.p; a.targetLength = tlen(0);
@@ -412,7 +412,7 @@ int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, i
     a.numSegments = numSegments; a.segLen = segLen; a.warm = warm;
     a.segBest = segBest; a.segCnt = segCnt; a.segPos = segPos; a.cap = cap;
     a.posOff = posOff; a.posCap = posCap;
-    a.kcap = kcap; a.wordSteps = d_wordSteps_.p;
+    a.kcap = kcap; a.wordSteps = wordSteps ? wordSteps : d_wordSteps_.p;
     static const bool dbg = getenv("EDLIB_AMD_DEBUG") != nullptr;
     if (dbg) {
         EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
@@ -420,7 +420,7 @@ int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, i
                 g.nwords, mode, nlanes, numSegments, segLen, warm, cap, kcap, (const void*)d_slotmap, (const void*)posOff);
     }
     scanTimerStart();
-    if (banded_ && mode == EDLIB_MODE_HW) EDLIB_AMD_HIP(launch_scan_reads_banded(g.nwords, a, stream_));
+    if (banded_ && mode == EDLIB_MODE_HW && !unbanded) EDLIB_AMD_HIP(launch_scan_reads_banded(g.nwords, a, stream_));
     else {
         EDLIB_AMD_HIP(launch_scan_reads(g.nwords, mode, a, stream_));
         stats.word_steps += (long long)((nlanes + 63) / 64 * 64) * g.nwords *
@@ -534,8 +534,34 @@ int Batch::runReads()
                 EDLIB_AMD_HIP(d_map.alloc(no)); EDLIB_AMD_HIP(d_sb.alloc(items)); EDLIB_AMD_HIP(d_sc.alloc(items));
                 EDLIB_AMD_HIP(d_sp.alloc(items * 8));
                 EDLIB_AMD_HIP(hipMemcpyAsync(d_map.p, todo.data(), no * sizeof(int), hipMemcpyHostToDevice, stream_));
+                // What pass 1 left over is usually unrelated sequence whose band is the whole query; there the
+                // plain full-height kernel (register-resident Peq rows, no band bookkeeping) is ~12 % faster per
+                // column than the banded one.  256 strided leftovers tell: the banded kernel reports its band
+                // height (word-steps), and a band above 85 % of the words sends the pass to the plain kernel.
+                bool plain = false;
+                if (no >= 4096) {
+                    const int np2 = 256;
+                    std::vector<int> sub(np2);
+                    for (int i = 0; i < np2; ++i) sub[i] = todo[(size_t)((long long)i * no / np2)];
+                    int S3, segLen3, warm3;
+                    plan_segments(np2, T, mode, g.warm, 16384, S3, segLen3, warm3);
+                    const size_t it3 = (size_t)np2 * S3;
+                    DevBuf<int> d_m3, d_b3, d_c3, d_p3; DevBuf<unsigned long long> d_ws;
+                    EDLIB_AMD_HIP(d_m3.alloc(np2)); EDLIB_AMD_HIP(d_b3.alloc(it3)); EDLIB_AMD_HIP(d_c3.alloc(it3));
+                    EDLIB_AMD_HIP(d_p3.alloc(it3 * 8)); EDLIB_AMD_HIP(d_ws.alloc(1));
+                    EDLIB_AMD_HIP(hipMemcpyAsync(d_m3.p, sub.data(), np2 * sizeof(int), hipMemcpyHostToDevice, stream_));
+                    EDLIB_AMD_HIP(hipMemsetAsync(d_ws.p, 0, sizeof(unsigned long long), stream_));
+                    if (scanGroup(g, mode, d_m3.p, np2, kNoCap, g.d_kinit.p, S3, segLen3, warm3,
+                                  d_b3.p, d_c3.p, d_p3.p, 8, nullptr, nullptr, false, d_ws.p)) return 1;
+                    unsigned long long ws = 0;
+                    EDLIB_AMD_HIP(hipMemcpyAsync(&ws, d_ws.p, sizeof ws, hipMemcpyDeviceToHost, stream_));
+                    EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+                    const double cols = (double)np2 * ((double)T + (double)(S3 - 1) * warm3);
+                    plain = (double)ws >= 0.85 * g.nwords * cols;
+                    stats.word_steps += (long long)ws;
+                }
                 if (scanGroup(g, mode, d_map.p, (int)no, kNoCap, g.d_kinit.p, S2, segLen2, warm2,
-                              d_sb.p, d_sc.p, d_sp.p, 8, nullptr, nullptr)) return 1;
+                              d_sb.p, d_sc.p, d_sp.p, 8, nullptr, nullptr, plain)) return 1;
                 EDLIB_AMD_HIP(launch_merge_segments(d_sb.p, d_sc.p, d_sp.p, S2, 8, (int)no, d_map.p, 16,
                                                     g.d_best.p, g.d_total.p, g.d_pos.p, g.d_flags.p, stream_));
                 EDLIB_AMD_HIP(hipStreamSynchronize(stream_));            // temporaries die here

@@ -111,7 +111,8 @@ private:
     bool readsCollected_ = true;
     int scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, int kcap, const int* d_kinit,
                   int numSegments, int segLen, int warm, int* segBest, int* segCnt, int* segPos, int cap,
-                  const long long* posOff, const int* posCap);
+                  const long long* posOff, const int* posCap, bool unbanded = false,
+                  unsigned long long* wordSteps = nullptr);
 
     // ---- block-per-lane path
     DevBuf<PairDesc> d_descs_;
