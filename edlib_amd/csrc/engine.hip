@@ -9,8 +9,11 @@
 //                                       (edlib.cpp:230-266)
 //   phase 3  alignment path             NW units with column store + traceback kernel
 //                                       (edlib.cpp:276-289, 1161-1213)
-// There is no k-doubling and no band: the kernels compute the full matrix and the
-// user's k only filters the result (SURVEY.md §7 "results are band-independent").
+// Work is narrowed like in the reference (Ukkonen band, thresholds that grow until they hold the
+// distance), but per batch and with thresholds chosen for the hardware: reads run a banded first pass
+// at a small k and only the leftovers a full pass (runReads), NW pairs climb lane-ring sizes
+// (solveGlobalDistances).  Thresholds only steer work: every result is a function of the full DP
+// matrix, so the user's k merely filters it (SURVEY.md §7 "results are band-independent").
 #include "engine.hpp"
 
 #include <algorithm>

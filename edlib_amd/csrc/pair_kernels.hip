@@ -22,8 +22,10 @@
 //     the 64 lanes are looking at.  The slice is refilled per strip from the
 //     HBM Peq pool with coalesced loads; the target is read 64 symbols per
 //     coalesced load and handed to lane 0 with v_readlane.
-//   * no Ukkonen band and no k-doubling: all outputs are functions of the full
-//     DP matrix, so every block of every column is computed once.
+//   * this strip kernel computes every block of every column (all outputs are functions of the full
+//     DP matrix); the banded lane-ring kernel further down (scan_pairs_ring_kernel)
+//     is what NW pairs, PATH leaves and short semi-global units actually run on, the strips take
+//     what no ring holds.
 //   * PATH: each block-step also stores (Pv, Mv, block score) in anti-diagonal
 //     order ([step][lane], one coalesced line per step); a second kernel walks
 //     back with the reference's candidate order up > left > diagonal.

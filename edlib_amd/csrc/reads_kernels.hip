@@ -6,10 +6,10 @@
 //
 //   * one wave64 = 64 queries ("slots") x one segment of the target; every
 //     lane owns one query, so the target symbol of a column is WAVE-UNIFORM:
-//     it is fetched with scalar loads from the 2-bit packed target and picks,
-//     by a scalar 4-way branch (or, in the narrow band, by M0 for an LDS read),
-//     which of the lane's four Peq rows feeds the column.  No cross-lane traffic
-//     and no divergence in the DP itself.
+//     it comes from the 2-bit packed target as a scalar and picks which of the
+//     lane's four Peq rows feeds the column -- by M0 for an LDS read in the banded
+//     kernel, by a scalar 4-way branch over register rows in the plain one.  No
+//     cross-lane traffic and no divergence in the DP itself.
 //   * the query column lives in VGPRs as NWD 32-bit words (Pv, Mv) instead of
 //     the reference's 64-bit blocks: 150 rows need 5 words (160 rows) rather
 //     than 3 blocks (192 rows).  The 64-bit add of calculateBlock becomes a
@@ -25,7 +25,8 @@
 //     batches; merge_segments() joins them.
 //
 // Two scan kernels:
-//   scan_reads_kernel<NWD, MODE>        every row of every column (SHW, NW; HW with EDLIB_AMD_BAND=0).
+//   scan_reads_kernel<NWD, MODE>        every row of every column (SHW, NW; HW for the leftovers of the
+//                                       k-doubling whose band is the whole query, and with EDLIB_AMD_BAND=0).
 //                                       All outputs are functions of the full DP matrix, so no band is
 //                                       needed for correctness and the kernel never branches on data.
 //   scan_reads_banded_kernel<NWD>       HW: Ukkonen band per wave + k-doubling (the bench kernel, §3b).
