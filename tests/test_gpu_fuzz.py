@@ -1,6 +1,7 @@
 """-m gpu: seeded differential fuzz of the batch entry points against the oracle, aimed at the band
 logic of the reads kernel (word-count groups, thresholds around the first k of the doubling, low
 complexity targets where the band stays tall, fixed k) and at the pair kernels (strips, banded NW)."""
+import os
 import random
 
 import numpy as np
@@ -28,9 +29,9 @@ def _mut(rng, s, rate, sigma_bytes):
 
 
 def test_fuzz_shared_target_batches(engine, oracle):
-    rng = random.Random(2024)
+    rng = random.Random(int(os.environ.get("EDLIB_FUZZ_SEED", "2024")))
     nbad = 0
-    for it in range(70):
+    for it in range(int(os.environ.get("EDLIB_FUZZ_ITERS", "70"))):   # soak runs: EDLIB_FUZZ_ITERS=500 EDLIB_FUZZ_SEED=n
         sigma = rng.choice([1, 2, 2, 3, 4, 4, 4])
         alpha = b"ACGT"[:sigma]
         tn = rng.choice([40, 300, 1000, 5000, 20000, 70000])

@@ -122,3 +122,41 @@ def test_oneshot_entry_points_shard_over_devices(engine, oracle, monkeypatch):
         got = engine.align_batch_oneshot(qs, None, targets=ts, mode="NW", task="distance")
         for q, t, g in zip(qs, ts, got):
             assert same(g, oracle.align(q, t, "NW", "distance", -1)), devs
+
+
+def test_large_batch_takes_probe_and_leftover_paths(engine, ref, oracle):
+    """A batch big enough for everything the k-doubling does above 16,384 reads: the 2048-read probe with its
+    adaptive first threshold, a second pass with more than 4096 leftovers (band sample, plain full-height kernel),
+    and leftovers of a middling distance.  A strided sample of 1,500 reads is checked against the reference on
+    all host cores; whole-batch invariants cover the rest."""
+    import os
+    impl = ref if ref is not None else oracle
+    target = synth.random_dna(77, 120000)
+    n = 24000
+    rd = synth.illumina_reads(target, n, m=150, seed=78, frac_random=0.22)
+    reads = rd["reads"].copy()
+    rng = np.random.default_rng(79)
+    noisy = np.arange(0, n, 9)                      # ~11 %: 6 % substitutions on top -> distances around 8..14
+    for i in noisy:
+        pos = rng.choice(150, size=9, replace=False)
+        reads[i, pos] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=9)
+    tbytes = target.tobytes()
+    got = engine.align_batch([r.tobytes() for r in reads], tbytes, mode="HW", task="distance", k=-1, raw=True)
+    ed = np.array([g["editDistance"] for g in got])
+    assert ((ed >= 0) & (ed <= 150)).all()
+    planted = ~rd["random"]
+    clean = planted.copy(); clean[noisy] = False
+    assert (ed[clean] <= rd["edits"][clean]).all()
+    idx = list(range(0, n, 16))
+    want = [None] * len(idx)
+    cores = min(os.cpu_count() or 1, 64)
+
+    def work(k):
+        for j in range(k, len(idx), cores):
+            want[j] = impl.align(reads[idx[j]].tobytes(), tbytes, "HW", "distance", -1)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    bad = [i for j, i in enumerate(idx) if not same(got[i], want[j])]
+    assert not bad, (len(bad), bad[:5])
