@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (default: the BASELINE config)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling (BASELINE config 3): --reads is the TOTAL, split evenly over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a dry run)")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses device 0")
@@ -114,9 +116,17 @@ def main():
     import edlib_amd
     from edlib_amd import synth
 
-    # synthetic inputs: same target everywhere, each rank its own reads (weak scaling)
+    # synthetic inputs: same target everywhere, each rank its own reads (weak scaling: --reads per rank;
+    # --strong: the same global batch cut into contiguous shards, edlib_amd.parallel.shard_range)
     target = synth.random_dna(12345, TARGET_LEN)
-    rd = synth.illumina_reads(target, args.reads, m=READ_LEN, seed=12346 + rank)
+    if args.strong and world > 1:
+        from edlib_amd.parallel import shard_range
+        lo, hi = shard_range(args.reads, rank, world)
+        rd = synth.illumina_reads(target, args.reads, m=READ_LEN, seed=12346)
+        rd = {k: v[lo:hi] for k, v in rd.items()}
+        args.reads = hi - lo
+    else:
+        rd = synth.illumina_reads(target, args.reads, m=READ_LEN, seed=12346 + rank)
     batch = edlib_amd.SharedBatch(rd["reads"], target, mode="HW", task="distance", k=-1, device=local_rank)
 
     def sync():
@@ -161,7 +171,7 @@ def main():
             "metric": "GCUPS (cell updates/s), 1M x 150bp HW reads vs 5Mb target",
             "value": round(value, 1), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "per GPU: %d x %dbp reads (1%% sub, 0.05%% ins/del, 5%% unrelated), "
                                    "EDLIB_MODE_HW, k=-1, EDLIB_TASK_DISTANCE, vs one %d-base uniform ACGT target"
