@@ -401,38 +401,44 @@ __device__ __forceinline__ void column_step_eq1(const u32 eq0, u32 (&Pv)[NWD], u
 // tools/narrow_ubench.hip, 6 SALU per column cost as much as the LDS fetch itself).  These SALU ops write
 // SCC: it is declared clobbered (without that hipcc kept a loop condition in SCC across the block and the
 // kernel never terminated).
-#define EDLIB_AMD_M0_ROW "s_lshl_b32 %[t], %[s4], %[sh]\n\ts_and_b32 %[t], %[t], 0x300\n\ts_or_b32 m0, %[t], %[base]\n\ts_nop 0\n\t"
-#define EDLIB_AMD_M0_OPS [t] "=&s"(off_) : [s4] "s"(sym4), [sh] "n"(8 - 2 * J), [base] "s"(ldsBase) : "memory", "scc"
+// The wait state that M0 needs before the LDS instruction is filled with the first half of the NEXT column's
+// row offset (off_ -> offNext, masked after the loads), so a column costs s_or + s_lshl + s_and and no s_nop.
+#define EDLIB_AMD_M0_ROW "s_or_b32 m0, %[o], %[base]\n\ts_lshl_b32 %[t], %[s4], %[sh]\n\t"
+#define EDLIB_AMD_M0_TAIL "\n\ts_and_b32 %[t], %[t], 0x300"
+#define EDLIB_AMD_M0_OPS [t] "=&s"(offNext) : [o] "s"(off), [s4] "s"(sym4), [sh] "n"(6 - 2 * J), [base] "s"(ldsBase) : "memory", "scc"
+// row offset of the quad's first column
+__device__ __forceinline__ u32 lds_row_offset0(const u32 sym4) { return (sym4 << 8) & 0x300u; }
 template <int NA, int J>
-__device__ __forceinline__ void lds_rows_request(u32 (&n)[NA], const u32 sym4, const u32 ldsBase)
+__device__ __forceinline__ void lds_rows_request(u32 (&n)[NA], const u32 off, u32& offNext, const u32 sym4, const u32 ldsBase)
 {
-    u32 off_;
     static_assert(NA >= 1 && NA <= 8, "band height");
-    if constexpr (NA == 1) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0" : "=v"(n[0]), EDLIB_AMD_M0_OPS);
-    if constexpr (NA == 2) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024"
+    if constexpr (NA == 1) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0" EDLIB_AMD_M0_TAIL
+                                        : "=v"(n[0]), EDLIB_AMD_M0_OPS);
+    if constexpr (NA == 2) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024" EDLIB_AMD_M0_TAIL
                                         : "=v"(n[0]), "=v"(n[1]), EDLIB_AMD_M0_OPS);
     if constexpr (NA == 3) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024\n\t"
-                                        "ds_read_addtid_b32 %2 offset:2048" : "=v"(n[0]), "=v"(n[1]), "=v"(n[2]), EDLIB_AMD_M0_OPS);
+                                        "ds_read_addtid_b32 %2 offset:2048" EDLIB_AMD_M0_TAIL
+                                        : "=v"(n[0]), "=v"(n[1]), "=v"(n[2]), EDLIB_AMD_M0_OPS);
     if constexpr (NA == 4) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024\n\t"
-                                        "ds_read_addtid_b32 %2 offset:2048\n\tds_read_addtid_b32 %3 offset:3072"
+                                        "ds_read_addtid_b32 %2 offset:2048\n\tds_read_addtid_b32 %3 offset:3072" EDLIB_AMD_M0_TAIL
                                         : "=v"(n[0]), "=v"(n[1]), "=v"(n[2]), "=v"(n[3]), EDLIB_AMD_M0_OPS);
     if constexpr (NA == 5) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024\n\t"
                                         "ds_read_addtid_b32 %2 offset:2048\n\tds_read_addtid_b32 %3 offset:3072\n\t"
-                                        "ds_read_addtid_b32 %4 offset:4096"
+                                        "ds_read_addtid_b32 %4 offset:4096" EDLIB_AMD_M0_TAIL
                                         : "=v"(n[0]), "=v"(n[1]), "=v"(n[2]), "=v"(n[3]), "=v"(n[4]), EDLIB_AMD_M0_OPS);
     if constexpr (NA == 6) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024\n\t"
                                         "ds_read_addtid_b32 %2 offset:2048\n\tds_read_addtid_b32 %3 offset:3072\n\t"
-                                        "ds_read_addtid_b32 %4 offset:4096\n\tds_read_addtid_b32 %5 offset:5120"
+                                        "ds_read_addtid_b32 %4 offset:4096\n\tds_read_addtid_b32 %5 offset:5120" EDLIB_AMD_M0_TAIL
                                         : "=v"(n[0]), "=v"(n[1]), "=v"(n[2]), "=v"(n[3]), "=v"(n[4]), "=v"(n[5]), EDLIB_AMD_M0_OPS);
     if constexpr (NA == 7) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024\n\t"
                                         "ds_read_addtid_b32 %2 offset:2048\n\tds_read_addtid_b32 %3 offset:3072\n\t"
                                         "ds_read_addtid_b32 %4 offset:4096\n\tds_read_addtid_b32 %5 offset:5120\n\t"
-                                        "ds_read_addtid_b32 %6 offset:6144"
+                                        "ds_read_addtid_b32 %6 offset:6144" EDLIB_AMD_M0_TAIL
                                         : "=v"(n[0]), "=v"(n[1]), "=v"(n[2]), "=v"(n[3]), "=v"(n[4]), "=v"(n[5]), "=v"(n[6]), EDLIB_AMD_M0_OPS);
     if constexpr (NA == 8) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024\n\t"
                                         "ds_read_addtid_b32 %2 offset:2048\n\tds_read_addtid_b32 %3 offset:3072\n\t"
                                         "ds_read_addtid_b32 %4 offset:4096\n\tds_read_addtid_b32 %5 offset:5120\n\t"
-                                        "ds_read_addtid_b32 %6 offset:6144\n\tds_read_addtid_b32 %7 offset:7168"
+                                        "ds_read_addtid_b32 %6 offset:6144\n\tds_read_addtid_b32 %7 offset:7168" EDLIB_AMD_M0_TAIL
                                         : "=v"(n[0]), "=v"(n[1]), "=v"(n[2]), "=v"(n[3]), "=v"(n[4]), "=v"(n[5]), "=v"(n[6]), "=v"(n[7]), EDLIB_AMD_M0_OPS);
 }
 template <int NA>
@@ -511,16 +517,17 @@ __device__ __forceinline__ int band_quad(const u32 sym4, const int q, const int 
     // costs registers, and with them occupancy; tools/narrow_ubench.hip: deeper prefetch buys nothing).
     int eh[4];
     u32 nx[NA];
-    lds_rows_request<NA, 0>(nx, sym4, ldsBase);
+    u32 o1, o2, o3, o4;
+    lds_rows_request<NA, 0>(nx, lds_row_offset0(sym4), o1, sym4, ldsBase);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         lds_rows_wait<NA>(nx);
         u32 eq[NA];
 #pragma unroll
         for (int i = 0; i < NA; ++i) eq[i] = nx[i];
-        if (j == 0) lds_rows_request<NA, 1>(nx, sym4, ldsBase);
-        if (j == 1) lds_rows_request<NA, 2>(nx, sym4, ldsBase);
-        if (j == 2) lds_rows_request<NA, 3>(nx, sym4, ldsBase);
+        if (j == 0) lds_rows_request<NA, 1>(nx, o1, o2, sym4, ldsBase);
+        if (j == 1) lds_rows_request<NA, 2>(nx, o2, o3, sym4, ldsBase);
+        if (j == 2) lds_rows_request<NA, 3>(nx, o3, o4, sym4, ldsBase);
         if constexpr (NA == 1 && NWD > 1) column_step_eq1<NWD>(eq[0], Pv, Mv);          // nothing tracked: the
         else if constexpr (NA == 2 && NWD > 2) column_step_eq2<NWD>(eq[0], eq[1], Pv, Mv);   // bottom row is outside
         else column_step_hw<NA, NWD>(eq, Pv, Mv, e, flag, sh);
@@ -660,6 +667,8 @@ scan_reads_banded_kernel(const ReadScanArgs a)
     // same code with every live value where it was (one switch around single quads made hipcc shuffle
     // ~26 registers per quad between the cases).
     int w = w0, q = 0;
+    // tw: the symbols of dword w that are still ahead, the quad's own in its low byte (the row requests mask
+    // what they need; every scalar instruction per quad counts, profiles/README.md: 0.54 SALU per VALU).
     // (v_readfirstlane: the "s" asm operands below do not scalarise a uniform value that sits in a VGPR)
     u32 tw = w0 < wend ? (u32)__builtin_amdgcn_readfirstlane(a.tpk[w0]) : 0u;
     while (w < wend) {
@@ -668,9 +677,10 @@ scan_reads_banded_kernel(const ReadScanArgs a)
             if (NA <= NWD) {                                                                                \
                 do {                                                                                        \
                     bandWork += (unsigned int)NA;                                                           \
-                    nw = band_quad<(NA <= NWD ? NA : NWD), NWD>((tw >> (8 * q)) & 0xffu, q, w * 16 + q * 4, c1, \
+                    nw = band_quad<(NA <= NWD ? NA : NWD), NWD>(tw, q, w * 16 + q * 4, c1,                  \
                              w >= wmain /* warm-up columns record nothing */, Pv, Mv, e, flag, \
                              tr, sh, lastRows, ldsBase);                                                 \
+                    tw >>= 8;                                                                               \
                     q = (q + 1) & 3;                                                                        \
                     if (q == 0) { ++w; if (w < wend) tw = (u32)__builtin_amdgcn_readfirstlane(a.tpk[w]); }  \
                 } while (nw == NA && w < wend);                                                             \
