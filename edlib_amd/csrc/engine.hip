@@ -884,21 +884,31 @@ int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& spli
                            std::vector<int>& leftScore, std::vector<int>& rightScore)
 {
     const size_t np = big.size();
-    // Long queries whose distance fits the band take the banded kernel (one wave per scan, the band of the
-    // WHOLE piece with k = its distance, stopped at the half's last column -- exactly the reference's
-    // two calls, edlib.cpp:1252-1260); the others the unbanded strips.  Both dump their last column.
+    // Each piece scans inside the band of the WHOLE piece with k = its distance, stopped at the half's last
+    // column -- exactly the reference's two calls, edlib.cpp:1252-1260 -- on the smallest lane ring that holds
+    // that band (or all its blocks); pieces no ring holds take the unbanded strips.  Both dump their last column.
+    static const int rings[5] = {4, 16, 32, 64, 0};
+    // (packing only pays with enough pieces to fill the chip: a handful of long pieces runs faster one per wave)
+    const bool packed = np >= 256;
+    auto ring_of = [&](const Piece& pc) {
+        const bool off = getenv("EDLIB_AMD_NWBAND") && getenv("EDLIB_AMD_NWBAND")[0] == '0';
+        if (off) return 4;
+        if (!packed) return (pc.m > 64 * 64 && pc.score <= kMaxBandK) ? 3 : 4;
+        for (int g = 0; g < 4; ++g) if (pc.score <= ring_max_k(rings[g])) return g;
+        return (pc.m + 63) / 64 <= 64 ? 3 : 4;
+    };
     std::vector<size_t> order; order.reserve(np);
-    size_t nBanded = 0;
-    for (size_t p = 0; p < np; ++p)
-        if (big[p].m > 64 * 64 && big[p].score <= kMaxBandK) { order.push_back(p); ++nBanded; }
-    for (size_t p = 0; p < np; ++p)
-        if (!(big[p].m > 64 * 64 && big[p].score <= kMaxBandK)) order.push_back(p);
+    size_t groupCount[5] = {0, 0, 0, 0, 0};
+    std::vector<int> groupOf(np);
+    for (size_t p = 0; p < np; ++p) { groupOf[p] = ring_of(big[p]); ++groupCount[groupOf[p]]; }
+    for (int g = 0; g < 5; ++g) for (size_t p = 0; p < np; ++p) if (groupOf[p] == g) order.push_back(p);
     std::vector<PairDesc> descs(2 * np);
     std::vector<int> best(np);
     long long peqWords = 0, auxInts = 0, colBlocks = 0;
     for (size_t q = 0; q < np; ++q) {
         const Piece& pc = big[order[q]];
-        const bool banded = q < nBanded;
+        const int ring = rings[groupOf[order[q]]];
+        const bool banded = ring != 0;
         const int lw = pc.T / 2, rw = pc.T - lw;                         // :1247-1248
         const long long nb = (pc.m + 63) / 64;
         best[q] = pc.score;
@@ -911,7 +921,7 @@ int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& spli
             d.peqOff = peqWords; peqWords += nb * tab_.sigmaT;
             d.auxOff = auxInts; if (nb > 64 && !banded) auxInts += d.tlen;
             d.colOff = colBlocks; colBlocks += nb;
-            stats.word_steps += banded ? 2LL * 64 * ((long long)d.tlen + nb - 1) : 2 * nb * (long long)d.tlen;
+            stats.word_steps += banded ? 2LL * ring * ((long long)d.tlen + nb - 1) : 2 * nb * (long long)d.tlen;
         }
     }
     const size_t n = descs.size();
@@ -940,19 +950,16 @@ int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& spli
         a.peqFullStride = (int)std::min<long long>((long long)a.peqRowStride * tab_.sigmaT, 1 << 20);
     }
     a.colP = colP.p; a.colM = colM.p; a.colS = colS.p;
-    if (nBanded) {
-        a.descs = d_descs_.p; a.numUnits = (int)(2 * nBanded);
-        a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p;
+    size_t first = 0;
+    for (int g = 0; g < 5; ++g) {
+        if (!groupCount[g]) continue;
+        a.descs = d_descs_.p + 2 * first; a.numUnits = (int)(2 * groupCount[g]);
+        a.outScore = d_outScore_.p + 2 * first; a.outCount = d_outCount_.p + 2 * first; a.outLast = d_outLast_.p + 2 * first;
         scanTimerStart();
-        EDLIB_AMD_HIP(launch_scan_pairs_ring(64, 0, false, a, stream_));
+        if (rings[g]) EDLIB_AMD_HIP(launch_scan_pairs_ring(rings[g], 0, false, a, stream_));
+        else EDLIB_AMD_HIP(launch_scan_pairs(EDLIB_MODE_NW, false, a, stream_));
         scanTimerStop();
-    }
-    if (np > nBanded) {
-        a.descs = d_descs_.p + 2 * nBanded; a.numUnits = (int)(2 * (np - nBanded));
-        a.outScore = d_outScore_.p + 2 * nBanded; a.outCount = d_outCount_.p + 2 * nBanded; a.outLast = d_outLast_.p + 2 * nBanded;
-        scanTimerStart();
-        EDLIB_AMD_HIP(launch_scan_pairs(EDLIB_MODE_NW, false, a, stream_));
-        scanTimerStop();
+        first += groupCount[g];
     }
     SplitArgs sa{};
     sa.descs = d_descs_.p; sa.numPieces = (int)np; sa.best = d_best.p;

@@ -378,7 +378,8 @@ scan_pairs_ring_kernel(const PairScanArgs a)
     const long long storeOff = STORE ? uni64(dp->storeOff) : 0;
     const int nb = num_blocks(m);
     const int D = (bandT ? bandT : T) - m, absD = D < 0 ? -D : D;     // the band is that of the whole problem
-    const bool dumpCol = G == 64 && a.colP != nullptr && colOffU >= 0;   // Hirschberg halves run on whole waves
+    // last-column dump of Hirschberg halves: the packed rings look their slot up when they get there
+    const bool dumpCol = a.colP != nullptr && (G != 64 || colOffU >= 0);
     const bool active = have && (MODE != 0 || K >= absD);
     if (have && !active && rl == 0) { a.outScore[unit] = 0x3fffffff; a.outCount[unit] = 0; a.outLast[unit] = -1; }
     if (__builtin_amdgcn_ballot_w64(active) == 0ull) return;
@@ -499,8 +500,11 @@ scan_pairs_ring_kernel(const PairScanArgs a)
                 }
             }
             if (dumpCol && col == T - 1) {                            // stop column of a Hirschberg half
-                a.colP[colOffU + b] = ((u64)B.p1 << 32) | B.p0; a.colM[colOffU + b] = ((u64)B.m1 << 32) | B.m0;
-                a.colS[colOffU + b] = bscore;
+                const long long co = G == 64 ? colOffU : dp->colOff;
+                if (co >= 0) {
+                    a.colP[co + b] = ((u64)B.p1 << 32) | B.p0; a.colM[co + b] = ((u64)B.m1 << 32) | B.m0;
+                    a.colS[co + b] = bscore;
+                }
             }
         }
         carry = (int)(hp | (hn << 1));
