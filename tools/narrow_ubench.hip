@@ -31,11 +31,15 @@ __device__ __forceinline__ void col1(const u32 eq, u32& Pv, u32& Mv)
     Mv = ph & Xv;
 }
 
-template <int KIND>
+// PADKB: extra LDS per workgroup (KB), to run a variant at the occupancy the real kernel would have with its
+// other LDS tables (160 KB per CU: 52 KB per workgroup = 3 workgroups = 3 waves per SIMD)
+template <int KIND, int PADKB = 0>
 __global__ void __launch_bounds__(256) k_narrow(u32* out, const u32* __restrict__ tpk, int nwords, u32 seed)
 {
     __shared__ u32 s_eq[4][4][64];            // [wave][sym][lane]
     __shared__ unsigned long long s_pair[4][16][64];
+    __shared__ u32 s_pad[PADKB > 0 ? PADKB * 256 : 1];
+    if (PADKB > 0 && seed == 0xdeadbeefu) s_pad[threadIdx.x] = seed;   // keeps the padding allocated
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     u32 E[4];
     for (int i = 0; i < 4; ++i) { E[i] = seed * (threadIdx.x + 3) * (2654435761u + 40503u * i); s_eq[wv][i][lane] = E[i]; }
@@ -110,7 +114,7 @@ __global__ void __launch_bounds__(256) k_narrow(u32* out, const u32* __restrict_
             }
         }
     }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = Pv ^ Mv ^ acc;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = Pv ^ Mv ^ acc ^ (PADKB > 0 ? s_pad[(threadIdx.x * 7) & 255] & (seed == 0xdeadbeefu) : 0u);
 }
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -127,7 +131,7 @@ template <typename F> static float time_ms(F launch)
 int main()
 {
     const int wps = 7, blocks = 256 * wps, nwords = 1 << 15;       // 512k columns
-    u32* out; CK(hipMalloc(&out, (size_t)blocks * 256 * sizeof(u32)));
+    u32* out; CK(hipMalloc(&out, (size_t)256 * 8 * 256 * sizeof(u32)));
     std::vector<u32> h(nwords); u32 x = 12345; for (auto& v : h) { x = x * 1664525u + 1013904223u; v = x; }
     u32* tpk; CK(hipMalloc(&tpk, nwords * 4)); CK(hipMemcpy(tpk, h.data(), nwords * 4, hipMemcpyHostToDevice));
     const char* names[6] = {"fixed row (VALU floor)", "m0 + ds_read_addtid, 1 ahead", "v_lshl_add + ds_read_b32, 1 ahead",
@@ -136,5 +140,13 @@ int main()
 #define RUN(K) { float ms = time_ms([&] { hipLaunchKernelGGL(k_narrow<K>, dim3(blocks), dim3(256), 0, 0, out, tpk, nwords, 7u); }); \
                  printf("%-42s %8.3f ms  %6.2f ns per wave-column per SIMD  (%5.1f cycles at 2.1 GHz)\n", names[K], ms, ms * 1e6 / (cols * wps), ms * 1e6 / (cols * wps) * 2.1); }
     RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5)
+    // occupancy: the M0 fetch with 20 KB per workgroup (7-8 waves per SIMD, as in the kernel) against the pair
+    // table with 52 KB per workgroup (3 waves per SIMD: what its 8 KB per wave would leave next to the rows)
+#define RUNP(K, PAD, WPS, LABEL) { const int bl = 256 * WPS; float ms = time_ms([&] { hipLaunchKernelGGL((k_narrow<K, PAD>), dim3(bl), dim3(256), 0, 0, out, tpk, nwords, 7u); }); \
+                 printf("%-42s %8.3f ms  %6.2f ns per wave-column per SIMD  (%5.1f cycles at 2.1 GHz)\n", LABEL, ms, ms * 1e6 / (cols * WPS), ms * 1e6 / (cols * WPS) * 2.1); }
+    RUNP(1, 0, 8, "m0 fetch, 8 waves per SIMD")
+    RUNP(4, 15, 3, "pair table, 52 KB LDS: 3 waves per SIMD")
+    RUNP(4, 15, 6, "pair table, 52 KB LDS, 6 waves queued")
+    RUNP(4, 0, 4, "pair table, 36 KB LDS: 4 waves per SIMD")
     return 0;
 }
