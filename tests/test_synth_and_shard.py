@@ -67,3 +67,22 @@ def test_two_rank_gloo_sharding(tmp_path, oracle):
     assert full.tolist() == want
     cells, secs = np.load(tmp_path / "agg.npy")
     assert cells == 37 * 60 * 3000 and secs == 2.0
+
+
+def test_strong_scaling_shards_partition_the_global_batch():
+    """bench.py --strong: every rank generates the same global batch and keeps its contiguous slice;
+    the slices must tile the batch exactly (no read twice, none dropped), for sizes that do not divide."""
+    from edlib_amd.parallel import shard_range
+    target = synth.random_dna(12345, 4000)
+    n = 1003
+    full = synth.illumina_reads(target, n, m=50, seed=12346)
+    for world in (1, 2, 3, 8):
+        parts, covered = [], 0
+        for rank in range(world):
+            lo, hi = shard_range(n, rank, world)
+            assert lo == covered and hi >= lo
+            covered = hi
+            again = synth.illumina_reads(target, n, m=50, seed=12346)      # what that rank would generate
+            parts.append(again["reads"][lo:hi])
+        assert covered == n
+        assert np.array_equal(np.concatenate(parts), full["reads"])
