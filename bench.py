@@ -1,30 +1,41 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on MI355X.
 
-Workload (BASELINE.json configs[1]): per GPU, 1,000,000
-synthetic 150 bp reads (1 % sub, 0.05 % ins, 0.05 % del, 5 % unrelated reads) in
-HW (infix) mode, k = -1, TASK_DISTANCE, against one 5,000,000-base uniform ACGT
-target.  A "step" is one pass of the device path over the whole resident batch:
-target encoding, buildPeq, the scan kernel, the segment merge and (when a read
-has more end locations than the first pass keeps) the exact second pass.
-Inputs are resident in HBM before the timed region; results stay on the device.
-
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|4|5] [--strong] ...
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  metric = GCUPS = sum(queryLen*targetLen)/s/1e9 over
-all ranks (weak scaling: every rank owns its own 1M reads, no collective on the
-data path).  `roofline` prices the dominant kernel (scan_reads_banded_kernel<5>, all its launches of a step)
-against HBM with the ALGORITHMIC bytes of SURVEY.md §8d (each pair counted as if it
-streamed its own target); `valu_roofline` is the bound that actually binds this
-integer kernel.  `cpu_baseline` times the unmodified reference
-(oracle/_ref) on the host cores on a bounded sample and doubles as a parity check.
+Workloads (BASELINE.json `configs`):
+  --config 2 (default, the headline; configs[1] at N=1, configs[2] sharded at N>1): per GPU 1,000,000 synthetic
+      150 bp reads (1 % sub, 0.05 % ins, 0.05 % del, 5 % unrelated) in HW mode, k = -1, TASK_DISTANCE, against
+      one 5,000,000-base uniform ACGT target.
+  --config 4 (configs[3]): per GPU 100,000 ONT-like 10 kb pairs (4 % sub / ins / del), NW, TASK_DISTANCE.
+  --config 5 (configs[4]): per GPU 10,000 1 kb pairs (3 % sub, 1 % ins, 1 % del), NW, TASK_PATH; both CIGAR
+      formats of every op string are part of the parity check.
+A "step" is one pass of the device path over the whole resident batch (edlibAmdBatchRun: target encoding /
+buildPeq, every scan pass, merges, for PATH the storing scan + traceback + D2H of the op strings).  Inputs are
+resident in HBM before the timed region.
+
+--gpus N: one process per GPU.  Under torch.distributed.run (RANK set) this process is one rank; without it and
+with N > 1 bench.py re-executes itself under torch.distributed.run with N ranks on 127.0.0.1.  It refuses to
+run when N differs from the world size, and `n_gpus` in the line is the number of ranks that ran (each on its
+own device unless --share-gpu, the 1-GPU dry run).  Weak scaling by default (the per-GPU batch is fixed);
+--strong cuts ONE global batch into contiguous shards (edlib_amd.parallel.shard_range).  No collective on the
+data path; RCCL carries the barrier and the MAX / SUM of time and cells.
+
+Rank 0 prints ONE JSON line: metric = GCUPS = sum(queryLen * targetLen) / s / 1e9 over all ranks.
+`roofline` prices the dominant scan kernel against HBM with the ALGORITHMIC bytes of SURVEY.md §8d (each pair
+as if it streamed its own target); `valu_roofline` is the bound that actually binds this integer path.
+`cpu_baseline` is the unmodified reference (oracle/_ref) driven by a native std::thread pool (oracle/ref_pool.cpp)
+on all host cores over a bounded sample of the same batch, which doubles as the bit-exact parity check;
+`e2e` is one call of the one-shot C entry point with host buffers in and malloc'd EdlibAlignResults out.
 """
 import argparse
+import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
-import threading
 import time
 
 import numpy as np
@@ -32,102 +43,278 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TARGET_LEN = 5_000_000
-READ_LEN = 150
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz (MI355X_MICROARCH.md)
-VALU_OPS_PER_WORD_STEP = 10.0  # DP ops per 32-row word-column (7 logic + add + 2 shift), counted from gfx950 ISA
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9        # CUs x SIMDs x lanes/clk x Hz (MI355X_MICROARCH.md)
+VALU_OPS_PER_WORD_STEP = 10.0               # DP ops per 32-row word-column (7 logic + add + 2 shift), from the gfx950 ISA
+CONFIGS = {
+    2: dict(units=1_000_000, name="1M x 150bp HW reads vs 5Mb target", mode="HW", task="distance",
+            kernel="scan_reads_banded_kernel<5> (+ scan_reads_kernel<5,2> for pass 2)", dtype="u32"),
+    4: dict(units=100_000, name="100k x 10kb NW pairs, distance", mode="NW", task="distance",
+            kernel="scan_pairs_ring_kernel<32,0,false,1>", dtype="u64 (2 x u32)"),
+    5: dict(units=10_000, name="10k x 1kb NW pairs, path + CIGAR", mode="NW", task="path",
+            kernel="scan_pairs_ring_kernel<4,0,*,2> + traceback_kernel", dtype="u64 (2 x u32)"),
+}
+TARGET_LEN, READ_LEN = 5_000_000, 150
 
 
-def cpu_baseline(reads, target, gpu_results, seconds_budget=20.0):
-    """Reference edlib (oracle/_ref) on the host cores, one thread per core, on a
-    bounded sample of the same reads; also the bit-exact parity check of that sample."""
-    from oracle.oracle import load_oracle, load_ref
-    impl = load_ref()
-    kind = "reference"
-    if impl is None:
-        impl = load_oracle()
-        kind = "port"
-    cores = os.cpu_count() or 1
-    tbytes = target.tobytes()
-    # calibrate on one read, then size the sample to ~seconds_budget of total CPU work
-    t0 = time.perf_counter()
-    impl.align(reads[0].tobytes(), tbytes, "HW", "distance", -1)
-    per_read = max(time.perf_counter() - t0, 1e-4)
-    n = int(max(cores, min(len(reads), seconds_budget / per_read)))
-    n = (n // cores) * cores or cores
-    idx = np.linspace(0, len(reads) - 1, n).astype(np.int64)
-    out = [None] * n
+# ------------------------------------------------------------------------------------------ launch
 
-    def work(k):
-        for j in range(k, n, cores):
-            out[j] = impl.align(reads[idx[j]].tobytes(), tbytes, "HW", "distance", -1)
+def reexec_under_torchrun(n):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
-    threads = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
-    t0 = time.perf_counter()
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    dt = time.perf_counter() - t0
-    ok = 0
-    for j in range(n):
-        i = idx[j]
-        w = out[j]
-        if (gpu_results["editDistance"][i] == w["editDistance"]
-                and gpu_results["ends"][i].tolist() == (w["endLocations"] or [])
-                and gpu_results["numLocations"][i] == w["numLocations"]
-                and gpu_results["alphabetLength"][i] == w["alphabetLength"]):
-            ok += 1
-    gcups = n * READ_LEN * len(target) / dt / 1e9
-    return ({"value": round(gcups, 2), "unit": "GCUPS", "cores": cores, "kind": kind,
-             "sample": "%d of the batch's reads (evenly strided), full %d-base target, %d threads, %.1f s wall"
-                       % (n, len(target), cores, dt)},
-            {"checked": n, "bit_exact": ok})
 
+# ------------------------------------------------------------------------------------------ workloads
+
+def make_workload(cfg_id, units, rank, world, strong):
+    """(batch factory, packed host arrays for the checker, bookkeeping)"""
+    from edlib_amd import synth
+    from edlib_amd.parallel import shard_range
+    w = {"config": cfg_id}
+    workers = max(1, min(os.cpu_count() or 1, 64) // max(1, world))
+    if cfg_id == 2:
+        target = synth.random_dna(12345, TARGET_LEN)
+        if strong and world > 1:
+            lo, hi = shard_range(units, rank, world)
+            rd = synth.illumina_reads(target, units, m=READ_LEN, seed=12346)
+            rd = {k: v[lo:hi] for k, v in rd.items()}
+        else:
+            rd = synth.illumina_reads(target, units, m=READ_LEN, seed=12346 + rank)
+        reads = np.ascontiguousarray(rd["reads"])
+        n = len(reads)
+        w.update(reads=reads, rd=rd, target=target, n=n, shared=True,
+                 qpool=reads.reshape(-1), qoff=np.arange(n + 1, dtype=np.int64) * READ_LEN,
+                 tpool=target, toff=np.array([0, len(target)], dtype=np.int64))
+        w["describe"] = ("per GPU: %d x %dbp reads (1%% sub, 0.05%% ins/del, 5%% unrelated), EDLIB_MODE_HW, k=-1, "
+                         "EDLIB_TASK_DISTANCE, vs one %d-base uniform ACGT target" % (n, READ_LEN, TARGET_LEN))
+    else:
+        length, seed, rates = (10000, 12349, (0.04, 0.04, 0.04)) if cfg_id == 4 else (1000, 12350, (0.03, 0.01, 0.01))
+        if strong and world > 1:
+            lo, hi = shard_range(units, rank, world)
+        else:
+            lo, hi = rank * units, (rank + 1) * units
+        qs, ts = synth.mutated_pairs(hi - lo, length, seed, *rates, workers=workers, first=lo)
+        n = len(qs)
+        qoff = np.zeros(n + 1, dtype=np.int64); qoff[1:] = np.cumsum([len(q) for q in qs])
+        toff = np.arange(n + 1, dtype=np.int64) * length
+        w.update(qs=qs, ts=ts, n=n, shared=False, qpool=np.concatenate(qs), qoff=qoff,
+                 tpool=np.concatenate(ts), toff=toff)
+        w["describe"] = ("per GPU: %d pairs, %d-base uniform ACGT targets, queries = target with %g%% sub / %g%% ins / "
+                         "%g%% del, EDLIB_MODE_NW, k=-1, EDLIB_TASK_%s" % (n, length, rates[0] * 100, rates[1] * 100,
+                                                                         rates[2] * 100, CONFIGS[cfg_id]["task"].upper()))
+    return w
+
+
+def make_batch(w, device):
+    import edlib_amd
+    c = CONFIGS[w["config"]]
+    if w["config"] == 2:
+        return edlib_amd.SharedBatch(w["reads"], w["target"], mode=c["mode"], task=c["task"], k=-1, device=device)
+    return edlib_amd.PairBatch(w["qs"], w["ts"], mode=c["mode"], task=c["task"], k=-1, device=device)
+
+
+# ------------------------------------------------------------------------------------------ checker
+
+def segment_sum(values, starts, counts):
+    """sum of values[starts[i] : starts[i] + counts[i]] for every i (empty segments give 0)"""
+    cs = np.concatenate([[0], np.cumsum(values.astype(np.int64))])
+    return cs[starts + counts] - cs[starts]
+
+
+def cigars_of(flat):
+    """both CIGAR strings of every op string through the product's edlibAlignmentToCigar, concatenated"""
+    import edlib_amd
+    L = edlib_amd.lib()
+    ops, off = flat["alignment"], flat["alnOff"]
+    ext, std = [], []
+    base = ops.ctypes.data if ops is not None and len(ops) else 0
+    for i in range(len(off) - 1):
+        n = int(off[i + 1] - off[i])
+        for fmt, out in ((1, ext), (0, std)):
+            p = L.edlibAlignmentToCigar(C.cast(base + int(off[i]), C.c_char_p), n, fmt)
+            out.append(C.string_at(p) if p else b"")
+            if p:
+                L.libc.free(p)
+    return b"".join(ext), b"".join(std)
+
+
+def cpu_baseline_and_parity(w, flat, sample_target):
+    """The reference on all host cores over a bounded sample of the batch (native thread pool), compared
+    field by field with the GPU results of the same units."""
+    from oracle import oracle as O
+    c = CONFIGS[w["config"]]
+    lib, kind = O.checker_library()
+    threads = os.cpu_count() or 1
+    n = w["n"]
+    want_cigar = c["task"] == "path"
+
+    def run(sel):
+        return O.pool_align(w["qpool"], w["qoff"], w["tpool"], w["toff"], w["shared"], c["mode"], c["task"], -1,
+                            select=sel, threads=threads, want_cigar=want_cigar, libpath=lib)
+    if sample_target >= n:
+        sel = np.arange(n, dtype=np.int32)
+    else:
+        # calibrate on one unit per thread, then size the sample for ~25 s of wall time
+        cal = run(np.linspace(0, n - 1, min(n, threads)).astype(np.int32))
+        per_unit = max(cal["wall_seconds"], 1e-3) / max(1, cal["n"]) * min(cal["n"], threads)   # thread-seconds per unit
+        fit = int(25.0 * threads / per_unit)
+        cnt = max(min(2000, n), min(sample_target, fit))
+        half = cnt // 2                                   # first half + evenly strided half (SURVEY.md §8d)
+        sel = np.unique(np.concatenate([np.arange(half), np.linspace(0, n - 1, cnt - half).astype(np.int64)])).astype(np.int32)
+    ref = run(sel)
+    # ---- parity: every field of EdlibAlignResult
+    bad = np.zeros(len(sel), dtype=bool)
+    for f in ("status", "editDistance", "numLocations", "alphabetLength"):
+        bad |= flat[f][sel] != ref[f]
+    gl = flat["locOff"]
+    cnts = (gl[1:] - gl[:-1])[sel]
+    bad |= cnts != (ref["locOff"][1:] - ref["locOff"][:-1])
+    if not bad.any():
+        first = np.cumsum(cnts) - cnts
+        idx = np.repeat(gl[:-1][sel], cnts) + (np.arange(int(cnts.sum())) - np.repeat(first, cnts))
+        same_ends = flat["ends"][idx] == ref["ends"]
+        if flat["starts"] is not None:
+            same_ends &= flat["starts"][idx] == ref["starts"]
+        elif ref["hasStarts"].any():
+            same_ends[:] = False
+        bad |= segment_sum(~same_ends, first, cnts) > 0
+    detail = {}
+    if want_cigar:
+        ga, ra = flat["alnOff"], ref["alnOff"]
+        alen = (ga[1:] - ga[:-1])[sel]
+        bad |= alen != (ra[1:] - ra[:-1])
+        if len(sel) == n and not bad.any():
+            same = np.array_equal(flat["alignment"], ref["alignment"])
+            ext, std = cigars_of(flat)
+            detail = {"op_bytes_equal": bool(same), "cigar_extended_equal": ext == ref["cigExt"],
+                      "cigar_standard_equal": std == ref["cigStd"], "op_bytes": int(ga[-1])}
+            if not (same and detail["cigar_extended_equal"] and detail["cigar_standard_equal"]):
+                bad[:] = True
+    cells = float(np.sum((w["qoff"][1:] - w["qoff"][:-1])[sel].astype(np.float64) *
+                         (float(w["toff"][1] - w["toff"][0]) if w["shared"] else (w["toff"][1:] - w["toff"][:-1])[sel])))
+    gcups = cells / ref["wall_seconds"] / 1e9
+    phys = O.physical_cores()
+    base = {"value": round(gcups, 2), "unit": "GCUPS", "cores": ref["threads"], "kind": kind,
+            "physical_cores": phys, "per_thread": round(gcups / ref["threads"], 3),
+            "per_physical_core": round(gcups / max(1, min(phys or ref["threads"], ref["threads"])), 3),
+            "wall_seconds": round(ref["wall_seconds"], 2),
+            "sample": "%d of the batch's %d units (%s), native std::thread pool (oracle/ref_pool.cpp), %d threads, "
+                      "one edlibAlign() per unit" % (len(sel), n, "the whole batch" if len(sel) == n else
+                                                      "first half + evenly strided half", ref["threads"])}
+    parity = {"checked": int(len(sel)), "bit_exact": int(len(sel) - bad.sum()),
+              "fields": "status, editDistance, numLocations, endLocations, startLocations, alphabetLength" +
+                        (", alignment, both CIGAR strings" if want_cigar else "")}
+    parity.update(detail)
+    return base, parity
+
+
+def invariants_config2(w, flat):
+    """whole-batch invariants of SURVEY.md §8d"""
+    rd = w["rd"]
+    ed = flat["editDistance"]
+    planted = ~rd["random"]
+    out = {"ed_le_planted_edits": bool(np.all(ed[planted] <= rd["edits"][planted])),
+           "ed_le_read_len": bool(np.all((ed >= 0) & (ed <= READ_LEN)))}
+    # a read without planted indels is its genome window with `edits` substitutions: when the distance equals
+    # that count, the window's last column start + m - 1 must be among the end locations
+    who = np.nonzero(planted & (rd["indels"] == 0) & (ed == rd["edits"]))[0]
+    loc = flat["locOff"]
+    cnts = (loc[1:] - loc[:-1])[who]
+    first = np.cumsum(cnts) - cnts
+    idx = np.repeat(loc[:-1][who], cnts) + (np.arange(int(cnts.sum())) - np.repeat(first, cnts))
+    hit = flat["ends"][idx] == np.repeat(rd["start"][who] + READ_LEN - 1, cnts)
+    out["planted_position_in_end_locations"] = bool((segment_sum(hit, first, cnts) > 0).all())
+    out["planted_position_reads_checked"] = int(len(who))
+    return out
+
+
+def e2e_config2(w):
+    """SURVEY.md §8d metric (i): host buffers in -> EdlibAlignResult[] out through ONE call of the one-shot C
+    entry point (upload, target packing, buildPeq, every scan pass, download, one malloc per result array)."""
+    import edlib_amd
+    L = edlib_amd.lib()
+    reads = w["reads"]
+    n, m = reads.shape
+    ptrs = (reads.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(m)).astype(np.uint64)
+    qlen = np.full(n, m, dtype=np.int32)
+    tbytes = w["target"].tobytes()
+    cfg, keep = edlib_amd._make_config("HW", "distance", -1, None)
+    res = (edlib_amd.AlignResult * n)()
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        rc = L.edlibAlignBatchSharedTarget(ptrs.ctypes.data_as(C.POINTER(C.c_char_p)), qlen.ctypes.data_as(C.POINTER(C.c_int)),
+                                           n, tbytes, len(tbytes), cfg, res)
+        dt = time.perf_counter() - t0
+        if rc != 0:
+            return {"error": edlib_amd.last_error()}
+        ed = np.frombuffer(res, dtype=np.uint8).reshape(n, C.sizeof(edlib_amd.AlignResult))[:, 4:8].copy().view(np.int32).ravel()
+        L.edlibAmdFreeResults(res, n)
+        best = dt if best is None else min(best, dt)
+    return {"value": round(n * m * len(tbytes) / best / 1e9, 1), "unit": "GCUPS", "seconds": round(best, 4),
+            "what": "edlibAlignBatchSharedTarget(): %d host query pointers + host target in, %d malloc'd EdlibAlignResult "
+                    "out; best of 2 calls" % (n, n)}, ed
+
+
+# ------------------------------------------------------------------------------------------ main
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (default: the BASELINE config)")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--reads", "--units", dest="units", type=int, default=None,
+                    help="units per GPU (default: the BASELINE size of the config); with --strong the TOTAL")
     ap.add_argument("--strong", action="store_true",
-                    help="strong scaling (BASELINE config 3): --reads is the TOTAL, split evenly over the ranks")
+                    help="strong scaling (BASELINE config 3): --units is the TOTAL, split evenly over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a dry run)")
-    ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses device 0")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--parity-sample", type=int, default=None,
+                    help="units checked against the reference (default: 20000 for config 2, the whole batch for 4 / 5)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo with --share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true", help="dry run on a 1-GPU box: every rank uses device 0")
+    ap.add_argument("--dump", default=None, help="rank 0 writes the gathered editDistance of all ranks to this .npy")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(reexec_under_torchrun(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s): refusing to report a wrong n_gpus"
+                         % (args.gpus, world))
     import torch
-    dist = None
-    if args.share_gpu:
-        local_rank = 0
-    if world > 1 or "RANK" in os.environ:        # launched by torch.distributed.run (also with one rank)
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend)
     import edlib_amd
-    from edlib_amd import synth
+    ndev = edlib_amd.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py: no HIP device (%s); there is no CPU path" % edlib_amd.last_error())
+    device = 0 if args.share_gpu else local_rank
+    if device >= ndev:
+        raise SystemExit("bench.py: rank %d needs device %d but only %d device(s) are visible (use --share-gpu for a dry run)"
+                         % (rank, device, ndev))
+    backend = args.backend or ("gloo" if args.share_gpu else "nccl")
+    dist = None
+    torch.cuda.set_device(device)
+    if "RANK" in os.environ:                     # launched by torch.distributed.run (also with one rank)
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
+    coll_dev = ("cuda" if backend == "nccl" else "cpu") if dist is not None else None
 
-    # synthetic inputs: same target everywhere, each rank its own reads (weak scaling: --reads per rank;
-    # --strong: the same global batch cut into contiguous shards, edlib_amd.parallel.shard_range)
-    target = synth.random_dna(12345, TARGET_LEN)
-    if args.strong and world > 1:
-        from edlib_amd.parallel import shard_range
-        lo, hi = shard_range(args.reads, rank, world)
-        rd = synth.illumina_reads(target, args.reads, m=READ_LEN, seed=12346)
-        rd = {k: v[lo:hi] for k, v in rd.items()}
-        args.reads = hi - lo
-    else:
-        rd = synth.illumina_reads(target, args.reads, m=READ_LEN, seed=12346 + rank)
-    batch = edlib_amd.SharedBatch(rd["reads"], target, mode="HW", task="distance", k=-1, device=local_rank)
+    c = CONFIGS[args.config]
+    units = args.units if args.units is not None else c["units"]
+    w = make_workload(args.config, units, rank, world, args.strong)
+    batch = make_batch(w, device)
 
     def sync():
         torch.cuda.synchronize()
@@ -141,49 +328,72 @@ def main():
     t0 = time.perf_counter()
     scan_ms = 0.0
     launches = 0
+    st = batch.stats()
     for _ in range(args.steps):
         st = batch.run()
         scan_ms += st["scan_ms"]
         launches += st["scan_launches"]
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
     sync()
-    dt = time.perf_counter() - t0
-    from edlib_amd.parallel import aggregate_throughput
-    # whole-job cells (SUM over ranks) and the slowest rank's time (MAX over ranks)
-    cells_all, dt = aggregate_throughput(st["cells"] * args.steps, dt, dist,
-                                         ("cuda" if args.backend == "nccl" else "cpu") if dist is not None else None)
+    dt_sync = time.perf_counter() - t0
+    from edlib_amd.parallel import aggregate_throughput, gather_int_results
+    # whole-job cells (SUM over ranks) and the slowest rank's time (MAX over ranks, barrier included)
+    cells_all, dt = aggregate_throughput(st["cells"] * args.steps, dt_sync, dist, coll_dev)
+    per_rank_ms = [round(dt_local / max(1, args.steps) * 1e3, 2)]
+    devices = ["%s:%d" % (socket.gethostname(), device)]
+    if dist is not None and world > 1:
+        tl = [None] * world
+        dist.all_gather_object(tl, (per_rank_ms[0], devices[0]))
+        per_rank_ms = [x[0] for x in tl]
+        devices = [x[1] for x in tl]
+    flat = None
+    if args.dump or (rank == 0 and world == 1 and not args.no_cpu_baseline):
+        flat = batch.results_flat()
+    if args.dump:
+        total = units if args.strong else units * world
+        full = gather_int_results(flat["editDistance"], total, dist, coll_dev)    # shard order = rank order
+        if rank == 0:
+            np.save(args.dump, full)
     value = cells_all / dt / 1e9
     out = None
     if rank == 0:
-        # dominant kernel: the first scan launch of a step covers the whole batch
-        main_scan_ms = scan_ms / args.steps          # all scan launches of a step (incl. exact pass)
+        steps = max(1, args.steps)
+        main_scan_ms = scan_ms / steps               # all scan launches of a step (HIP events on the batch's stream)
         algo_bytes = st["algo_bytes"]
-        achieved = algo_bytes / (main_scan_ms * 1e-3) / 1e9
-        traffic = None
+        achieved = algo_bytes / (main_scan_ms * 1e-3) / 1e9 if main_scan_ms > 0 else 0.0
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch")
+                tj = json.load(open(tpath))
+                ent = tj.get("configs", {}).get(str(args.config))
+                if ent and ent.get("units") == w["n"]:
+                    traffic = ent.get("bytes_per_step")
+                    traffic_src = {"file": "profiles/hbm_traffic.json", "commit": ent.get("commit"),
+                                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_traffic.sh) at that "
+                                           "commit, not measured inside this run"}
             except Exception:
                 traffic = None
         lane_ops = st["word_steps"] * VALU_OPS_PER_WORD_STEP
-        valu_achieved = lane_ops / (main_scan_ms * 1e-3)
+        valu_achieved = lane_ops / (main_scan_ms * 1e-3) if main_scan_ms > 0 else 0.0
         out = {
-            "metric": "GCUPS (cell updates/s), 1M x 150bp HW reads vs 5Mb target",
+            "metric": "GCUPS (cell updates/s), %s" % c["name"],
             "value": round(value, 1), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "warmup": args.warmup, "ms_per_step": round(dt / steps * 1e3, 2),
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "per GPU: %d x %dbp reads (1%% sub, 0.05%% ins/del, 5%% unrelated), "
-                                   "EDLIB_MODE_HW, k=-1, EDLIB_TASK_DISTANCE, vs one %d-base uniform ACGT target"
-                                   % (args.reads, READ_LEN, TARGET_LEN),
-                       "reads_per_gpu": args.reads, "read_len": READ_LEN, "target_len": TARGET_LEN,
-                       "parallelism": "reads sharded over %d GPU(s), target replicated, no collective" % world},
-            "roofline": {"bound": "hbm", "kernel": "scan_reads_banded_kernel<5>",
+            "dtype": c["dtype"], "data": "synthetic",
+            "config": {"workload": w["describe"], "baseline_config": args.config, "units_per_gpu": w["n"],
+                       "parallelism": "units sharded over %d rank(s), one per GPU, target replicated, no collective"
+                                      % world},
+            "per_rank_ms_per_step": per_rank_ms,
+            "devices": devices, "devices_distinct": len(set(devices)),
+            "roofline": {"bound": "hbm", "kernel": c["kernel"],
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_step": algo_bytes,
-                         "scan_ms_per_step": round(main_scan_ms, 2),
-                         "scan_launches_per_step": launches / args.steps},
+                         "scan_ms_per_step": round(main_scan_ms, 3),
+                         "scan_launches_per_step": launches / steps},
             "valu_roofline": {"bound": "valu-int32", "achieved": round(valu_achieved / 1e12, 2),
                               "peak": round(VALU_LANE_OPS / 1e12, 2), "unit": "T lane-ops/s",
                               "frac": round(valu_achieved / VALU_LANE_OPS, 4),
@@ -191,18 +401,23 @@ def main():
                               "valu_ops_per_word_step": VALU_OPS_PER_WORD_STEP},
             "overflow_units": st["overflow_units"],
         }
+        if args.share_gpu:
+            out["dry_run_shared_gpu"] = True
         if world == 1 and not args.no_cpu_baseline:
-            res = batch.results_arrays()
-            base, parity = cpu_baseline(rd["reads"], target, res)
+            sample = args.parity_sample if args.parity_sample is not None else (20000 if args.config == 2 else w["n"])
+            base, parity = cpu_baseline_and_parity(w, flat, sample)
             out["cpu_baseline"] = base
             out["parity_sample"] = parity
-            # whole-batch invariants: ed <= planted edits, ed <= read length
-            ed = res["editDistance"]
-            planted = ~rd["random"]
-            out["invariants"] = {
-                "ed_le_planted_edits": bool(np.all(ed[planted] <= rd["edits"][planted])),
-                "ed_le_read_len": bool(np.all((ed >= 0) & (ed <= READ_LEN))),
-            }
+            if args.config == 2:
+                out["invariants"] = invariants_config2(w, flat)
+        if world == 1 and args.config == 2 and not args.no_e2e:
+            r = e2e_config2(w)
+            if isinstance(r, tuple):
+                out["e2e"] = r[0]
+                if flat is not None:
+                    out["e2e"]["distances_equal_resident"] = bool(np.array_equal(r[1], flat["editDistance"]))
+            else:
+                out["e2e"] = r
     batch.close()
     if dist is not None:
         dist.barrier()

@@ -79,6 +79,10 @@ def lib():
                                                AlignConfig, C.c_int]
         L.edlibAmdBatchRun.argtypes = [C.c_void_p]
         L.edlibAmdBatchResults.argtypes = [C.c_void_p, C.POINTER(AlignResult)]
+        L.edlibAmdBatchResultsFlat.argtypes = [C.c_void_p] + [C.c_void_p] * 9
+        L.edlibAmdFreeResults.argtypes = [C.POINTER(AlignResult), C.c_int]
+        L.edlibAmdFreeResults.restype = None
+        L.edlibAmdTrim.restype = None
         L.edlibAmdBatchStats.argtypes = [C.c_void_p, C.POINTER(BatchStats)]
         L.edlibAmdBatchDestroy.argtypes = [C.c_void_p]
         L.edlibAmdBatchDestroy.restype = None
@@ -225,48 +229,42 @@ def align(query, target, mode="NW", task="distance", k=-1, additionalEqualities=
     return _nice_result(raw)
 
 
+# how each extended-CIGAR op fills the three display rows: (takes a query symbol, takes a target symbol, marker)
+_NICE_OPS = {"=": (True, True, "|"), "X": (True, True, "."), "I": (True, False, None), "D": (False, True, None)}
+
+
 def getNiceAlignment(alignResult, query, target, gapSymbol="-"):
-    """Human-readable three-line alignment (edlib.pyx:158-238)."""
-    if type(alignResult) is not dict:
-        raise Exception("The object alignResult is expected to be a python dictionary. "
-                        "Please check the input alignResult.")
-    if "locations" not in alignResult:
-        raise Exception("The object alignResult is expected to contain a field 'locations'. "
-                        "Please check the input alignResult.")
-    target_pos = alignResult["locations"][0][0]
-    if target_pos is None:
-        target_pos = 0
-    query_pos = 0
-    target_aln = match_aln = query_aln = ""
-    if "cigar" not in alignResult:
-        raise Exception("The object alignResult is expected to contain a CIGAR string. "
-                        "Please check the input alignResult.")
+    """Three display rows for a result of ``align(..., task="path")``: the query and target with gap symbols
+    inserted, and between them a row of '|' (match), '.' (mismatch) and gap symbols.
+
+    Same call and result keys as the reference binding's helper (bindings/python/edlib.pyx:158-238:
+    ``query_aligned`` / ``matched_aligned`` / ``target_aligned``); like it, raises ``Exception`` when the
+    argument is not an ``align()`` dictionary with a CIGAR.  The rows are assembled column by column from
+    the expanded CIGAR; the target row starts at the first reported start location (0 when there is none)."""
+    if not isinstance(alignResult, dict) or type(alignResult) is not dict:
+        raise Exception("getNiceAlignment() needs the dictionary returned by align().")
+    for key in ("locations", "cigar"):
+        if key not in alignResult:
+            raise Exception("getNiceAlignment(): the align() result has no '%s' entry." % key)
     cigar = alignResult["cigar"]
-    if cigar == "" or cigar is None:
-        raise Exception("The object alignResult contains an empty CIGAR string. Users must run "
-                        "align() with task='path'. Please check the input alignResult.")
-    for num, op in re.findall(r"(\d+)(\D)", cigar):
-        num = int(num)
-        if op in "=X":
-            target_aln += target[target_pos:target_pos + num]
-            target_pos += num
-            query_aln += query[query_pos:query_pos + num]
-            query_pos += num
-            match_aln += ("|" if op == "=" else ".") * num
-        elif op == "D":
-            target_aln += target[target_pos:target_pos + num]
-            target_pos += num
-            query_aln += gapSymbol * num
-            match_aln += gapSymbol * num
-        elif op == "I":
-            target_aln += gapSymbol * num
-            query_aln += query[query_pos:query_pos + num]
-            query_pos += num
-            match_aln += gapSymbol * num
-        else:
-            raise Exception("The CIGAR string from alignResult contains a symbol not '=', 'X', 'D', 'I'. "
-                            "Please check the validity of alignResult and alignResult.cigar")
-    return {"query_aligned": query_aln, "matched_aligned": match_aln, "target_aligned": target_aln}
+    if not cigar:
+        raise Exception("getNiceAlignment(): empty CIGAR -- run align() with task='path'.")
+    runs = re.findall(r"(\d+)(\D)", cigar)
+    if any(op not in _NICE_OPS for _, op in runs) or "".join(n + op for n, op in runs) != cigar:
+        raise Exception("getNiceAlignment(): the CIGAR must be in the extended format (=, X, I, D only).")
+    start = alignResult["locations"][0][0] if alignResult["locations"] else None
+    qi, ti = 0, (start or 0)
+    rows = ([], [], [])                       # query, markers, target
+    for count, op in runs:
+        count = int(count)
+        from_q, from_t, mark = _NICE_OPS[op]
+        gaps = gapSymbol * count
+        rows[0].append(query[qi:qi + count] if from_q else gaps)
+        rows[2].append(target[ti:ti + count] if from_t else gaps)
+        rows[1].append(mark * count if mark else gaps)
+        qi += count if from_q else 0
+        ti += count if from_t else 0
+    return {"query_aligned": "".join(rows[0]), "matched_aligned": "".join(rows[1]), "target_aligned": "".join(rows[2])}
 
 
 # ------------------------------------------------------------ batches
@@ -317,25 +315,44 @@ class _Batch:
             out.append(d if raw else _nice_result(d))
         return out
 
-    def results_arrays(self):
-        """editDistance / numLocations / first end location as numpy arrays (large batches)."""
+    def results_flat(self):
+        """Every field of every result as flat numpy arrays (edlibAmdBatchResultsFlat: no per-unit malloc):
+        status / editDistance / numLocations / alphabetLength [n], locOff [n+1] into ends / starts
+        (starts is None unless the task produced start locations), alnOff [n+1] into alignment (op bytes)."""
         L = lib()
-        arr = (AlignResult * max(self.n, 1))()
-        if L.edlibAmdBatchResults(self._h, arr) != 0:
+        n = self.n
+        st = np.empty(max(n, 1), dtype=np.int32); ed = np.empty(max(n, 1), dtype=np.int32)
+        nl = np.empty(max(n, 1), dtype=np.int32); al = np.empty(max(n, 1), dtype=np.int32)
+        loc = np.zeros(n + 1, dtype=np.int64); aln = np.zeros(n + 1, dtype=np.int64)
+        pe, ps, pa = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        if L.edlibAmdBatchResultsFlat(self._h, st.ctypes.data, ed.ctypes.data, nl.ctypes.data, al.ctypes.data,
+                                      loc.ctypes.data, C.addressof(pe), C.addressof(ps), aln.ctypes.data,
+                                      C.addressof(pa)) != 0:
             raise RuntimeError("edlib_amd: results failed: " + last_error())
-        ed = np.empty(self.n, dtype=np.int32); nl = np.empty(self.n, dtype=np.int32)
-        first = np.full(self.n, -2, dtype=np.int64); alpha = np.empty(self.n, dtype=np.int32)
-        ends = []
-        for i in range(self.n):
-            r = arr[i]
-            ed[i] = r.editDistance; nl[i] = r.numLocations; alpha[i] = r.alphabetLength
-            if r.endLocations and r.numLocations > 0:
-                first[i] = r.endLocations[0]
-                ends.append(np.ctypeslib.as_array(r.endLocations, shape=(r.numLocations,)).copy())
-            else:
-                ends.append(np.zeros(0, dtype=np.int32))
-            L.edlibFreeAlignResult(r)
-        return {"editDistance": ed, "numLocations": nl, "firstEnd": first, "alphabetLength": alpha, "ends": ends}
+
+        def take(ptr, count, ctype, dtype):
+            out = None
+            if ptr.value:
+                out = (np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(count,)).astype(dtype, copy=True)
+                       if count else np.zeros(0, dtype=dtype))
+                L.libc.free(ptr)
+            return out
+        ends = take(pe, int(loc[-1]), C.c_int, np.int32)
+        starts = take(ps, int(loc[-1]), C.c_int, np.int32)
+        ops = take(pa, int(aln[-1]), C.c_ubyte, np.uint8)
+        return {"status": st[:n], "editDistance": ed[:n], "numLocations": nl[:n], "alphabetLength": al[:n],
+                "locOff": loc, "ends": ends, "starts": starts, "alnOff": aln, "alignment": ops}
+
+    def results_arrays(self):
+        """editDistance / numLocations / first end location / per-unit end lists (kept for older callers;
+        built from results_flat())."""
+        f = self.results_flat()
+        loc = f["locOff"]
+        first = np.full(self.n, -2, dtype=np.int64)
+        has = f["numLocations"] > 0
+        first[has] = f["ends"][loc[:-1][has]]
+        return {"editDistance": f["editDistance"], "numLocations": f["numLocations"], "firstEnd": first,
+                "alphabetLength": f["alphabetLength"], "ends": np.split(f["ends"], loc[1:-1])}
 
     def close(self):
         if self._h:

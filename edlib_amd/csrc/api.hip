@@ -130,6 +130,24 @@ EDLIB_API int edlibAmdBatchResults(EdlibAmdBatch* b, EdlibAlignResult* results) 
     return b->impl.results(results) ? EDLIB_STATUS_ERROR : EDLIB_STATUS_OK;
 }
 
+EDLIB_API int edlibAmdBatchResultsFlat(EdlibAmdBatch* b, int* status, int* editDistance, int* numLocations,
+                                       int* alphabetLength, long long* locOffsets, int** endLocations,
+                                       int** startLocations, long long* alnOffsets, unsigned char** alignment) {
+    if (!b) { set_error("null argument"); return EDLIB_STATUS_ERROR; }
+    return b->impl.resultsFlat(status, editDistance, numLocations, alphabetLength, locOffsets, endLocations,
+                               startLocations, alnOffsets, alignment) ? EDLIB_STATUS_ERROR : EDLIB_STATUS_OK;
+}
+
+EDLIB_API void edlibAmdFreeResults(EdlibAlignResult* results, int n) {
+    if (!results) return;
+    for (int i = 0; i < n; ++i) {
+        edlibFreeAlignResult(results[i]);
+        results[i].endLocations = nullptr; results[i].startLocations = nullptr; results[i].alignment = nullptr;
+    }
+}
+
+EDLIB_API void edlibAmdTrim(void) { pool_trim(); }
+
 EDLIB_API int edlibAmdBatchStats(EdlibAmdBatch* b, EdlibAmdBatchStats* out) {
     if (!b || !out) { set_error("null argument"); return EDLIB_STATUS_ERROR; }
     *out = b->impl.stats;
@@ -138,13 +156,18 @@ EDLIB_API int edlibAmdBatchStats(EdlibAmdBatch* b, EdlibAmdBatchStats* out) {
 
 EDLIB_API void edlibAmdBatchDestroy(EdlibAmdBatch* b) { delete b; }
 
-static void pack(const char* const* seqs, const int* lens, int n, std::vector<char>& bytes,
+// false if a length is negative (edlibAlign answers EDLIB_STATUS_ERROR for those: so does the batch)
+static bool pack(const char* const* seqs, const int* lens, int n, std::vector<char>& bytes,
                  std::vector<long long>& off) {
     off.assign(n + 1, 0);
-    for (int i = 0; i < n; ++i) off[i + 1] = off[i] + (lens[i] > 0 ? lens[i] : 0);
+    for (int i = 0; i < n; ++i) {
+        if (lens[i] < 0) { set_error("negative sequence length at index %d", i); return false; }
+        off[i + 1] = off[i] + lens[i];
+    }
     bytes.resize((size_t)off[n] + 1);
     for (int i = 0; i < n; ++i)
         if (lens[i] > 0) memcpy(bytes.data() + off[i], seqs[i], (size_t)lens[i]);
+    return true;
 }
 
 // Devices the one-shot batch entry points shard over (contiguous slices of the units,
@@ -163,7 +186,7 @@ static std::vector<int> oneshot_devices() {
             p = (*e == ',') ? e + 1 : e;
         }
     }
-    if (devs.empty()) devs.push_back(0);
+    if (devs.empty()) devs.push_back(default_device());
     return devs;
 }
 
@@ -214,8 +237,8 @@ EDLIB_API int edlibAlignBatchSharedTarget(const char* const* queries, const int*
                                           EdlibAlignResult* results) {
     if (numQueries < 0 || targetLength < 0) { set_error("negative size"); return EDLIB_STATUS_ERROR; }
     std::vector<char> qb; std::vector<long long> qo;
-    pack(queries, queryLengths, numQueries, qb, qo);
     for (int i = 0; i < numQueries; ++i) results[i] = blank_result(EDLIB_STATUS_ERROR);
+    if (!pack(queries, queryLengths, numQueries, qb, qo)) return EDLIB_STATUS_ERROR;
     return run_sharded(qb.data(), qo.data(), target, nullptr, targetLength, numQueries, config, results,
                        "edlibAlignBatchSharedTarget");
 }
@@ -225,9 +248,8 @@ EDLIB_API int edlibAlignBatchPairs(const char* const* queries, const int* queryL
                                    EdlibAlignConfig config, EdlibAlignResult* results) {
     if (numPairs < 0) { set_error("negative size"); return EDLIB_STATUS_ERROR; }
     std::vector<char> qb, tb; std::vector<long long> qo, to;
-    pack(queries, queryLengths, numPairs, qb, qo);
-    pack(targets, targetLengths, numPairs, tb, to);
     for (int i = 0; i < numPairs; ++i) results[i] = blank_result(EDLIB_STATUS_ERROR);
+    if (!pack(queries, queryLengths, numPairs, qb, qo) || !pack(targets, targetLengths, numPairs, tb, to)) return EDLIB_STATUS_ERROR;
     return run_sharded(qb.data(), qo.data(), tb.data(), to.data(), 0, numPairs, config, results,
                        "edlibAlignBatchPairs");
 }

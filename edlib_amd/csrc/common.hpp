@@ -19,6 +19,7 @@ void set_error(const char* fmt, ...);
         if (e_ != hipSuccess) {                                                        \
             ::edlib_amd::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
                                    __FILE__, __LINE__);                                \
+            ::edlib_amd::pool_quarantine(true);                                        \
             return 1;                                                                  \
         }                                                                              \
     } while (0)
@@ -31,6 +32,12 @@ void pool_free(void* p, size_t granted);
 // cached like the device blocks.  Never handed to the caller.
 hipError_t pinned_alloc(void** p, size_t bytes, size_t* granted);
 void pinned_free(void* p, size_t granted);
+// After a failed HIP call the early return drops local buffers while work on the batch's stream may still be in
+// flight; until the next entry point clears the flag this thread's frees go straight to hipFree / hipHostFree
+// (which wait for the device) instead of into the cache, so no other batch can be handed a block that is still in use.
+void pool_quarantine(bool on);
+// Releases every cached device / pinned block and idle stream (edlibAmdTrim()).
+void pool_trim();
 hipError_t pool_stream(hipStream_t* s);
 void pool_stream_release(hipStream_t s);
 
@@ -73,6 +80,21 @@ struct PinBuf {
         n = bytes;
         return pinned_alloc(reinterpret_cast<void**>(&p), bytes, &granted);
     }
+};
+
+// Makes `device` current for the scope and restores the caller's device afterwards: a host application with
+// its own HIP context (PyTorch on cuda:3 calling the drop-in binding) must not find its device switched.
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t status = hipSuccess;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        if (prev != device) status = hipSetDevice(device);
+        else prev = -1;                                   // nothing to restore
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
 struct Event {

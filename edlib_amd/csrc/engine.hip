@@ -58,9 +58,30 @@ int size_class(size_t bytes, size_t* rounded) {
 }
 }  // namespace
 
+static thread_local bool tl_quarantine = false;
+void pool_quarantine(bool on) { tl_quarantine = on; }
+
 static bool pool_enabled() {
     static const bool on = !(getenv("EDLIB_AMD_NOPOOL") && getenv("EDLIB_AMD_NOPOOL")[0] == '1');
-    return on;
+    return on && !tl_quarantine;
+}
+
+void pool_trim() {
+    Pool& P = pool();
+    std::vector<std::pair<int, void*>> dev; std::vector<void*> pin; std::vector<std::pair<int, hipStream_t>> str;
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        for (int d = 0; d < Pool::kMaxDev; ++d) {
+            for (auto& v : P.blocks[d]) { for (void* p : v) dev.push_back({d, p}); v.clear(); }
+            for (hipStream_t s : P.streams[d]) str.push_back({d, s});
+            P.streams[d].clear();
+        }
+        for (auto& v : P.pinned) { for (void* p : v) pin.push_back(p); v.clear(); }
+        P.cachedBytes = 0; P.cachedPinned = 0;
+    }
+    for (auto& b : dev) (void)hipFree(b.second);
+    for (void* p : pin) (void)hipHostFree(p);
+    for (auto& s : str) { DeviceGuard g(s.first); (void)hipStreamDestroy(s.second); }
 }
 
 hipError_t pool_alloc(void** p, size_t bytes, size_t* granted) {
@@ -144,6 +165,19 @@ int device_count() {
     return n;
 }
 
+// Device of edlibAlign() and of the one-shot entry points when EDLIB_AMD_DEVICES is unset: EDLIB_AMD_DEVICE
+// if given, else the calling thread's current HIP device (a host application that selected a GPU keeps it).
+int default_device() {
+    const int ndev = device_count();
+    if (const char* env = getenv("EDLIB_AMD_DEVICE")) {
+        char* e; const long d = strtol(env, &e, 10);
+        if (e != env && d >= 0 && d < ndev) return (int)d;
+    }
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = 0; }
+    return (cur >= 0 && cur < ndev) ? cur : 0;
+}
+
 // ------------------------------------------------------------------- tables
 
 static void build_tables(Tables& tab, const uint8_t* targets, long long totalTargetBytes,
@@ -225,7 +259,7 @@ count_flags_kernel(const int* __restrict__ flags, int n, int* __restrict__ count
 // --------------------------------------------------------------- Batch: init
 
 Batch::~Batch() {
-    (void)hipSetDevice(device_);
+    DeviceGuard guard(device_);
     for (auto& p : scanEvents_) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (stream_) { (void)hipStreamSynchronize(stream_); pool_stream_release(stream_); }
 }
@@ -271,7 +305,9 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
     build_tables(tab_, reinterpret_cast<const uint8_t*>(targets) + toff_[0], tbytes,
                  eqs_.data(), (int)eqs_.size());
 
-    EDLIB_AMD_HIP(hipSetDevice(device_));
+    pool_quarantine(false);
+    DeviceGuard guard(device_);
+    EDLIB_AMD_HIP(guard.status);
     EDLIB_AMD_HIP(pool_stream(&stream_));
     EDLIB_AMD_HIP(evRun0_.create()); EDLIB_AMD_HIP(evRun1_.create());
 
@@ -1206,7 +1242,9 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
 
 int Batch::run()
 {
-    EDLIB_AMD_HIP(hipSetDevice(device_));
+    pool_quarantine(false);
+    DeviceGuard guard(device_);
+    EDLIB_AMD_HIP(guard.status);
     const long long cells = stats.cells;
     stats = EdlibAmdBatchStats{};
     stats.cells = cells;
@@ -1364,7 +1402,8 @@ int Batch::results(EdlibAlignResult* out)
 {
     if (!haveResults_) { set_error("results() before a successful run()"); return 1; }
     if (!readsCollected_) {
-        EDLIB_AMD_HIP(hipSetDevice(device_));
+        DeviceGuard guard(device_);
+        EDLIB_AMD_HIP(guard.status);
         if (collectReads(results_)) return 1;
     }
     for (int u = 0; u < n_; ++u) {
@@ -1388,13 +1427,65 @@ int Batch::results(EdlibAlignResult* out)
     return 0;
 }
 
+// Flat form of results(): one array per field instead of one malloc per unit (edlibAmdBatchResultsFlat).
+int Batch::resultsFlat(int* status, int* editDistance, int* numLocations, int* alphabetLength,
+                       long long* locOffsets, int** endLocations, int** startLocations,
+                       long long* alnOffsets, unsigned char** alignment)
+{
+    if (!haveResults_) { set_error("results() before a successful run()"); return 1; }
+    if (!readsCollected_) {
+        DeviceGuard guard(device_);
+        if (collectReads(results_)) return 1;
+    }
+    long long nloc = 0, naln = 0;
+    for (int u = 0; u < n_; ++u) {
+        const UnitResult& r = results_[u];
+        if (status) status[u] = r.status;
+        if (editDistance) editDistance[u] = r.editDistance;
+        if (numLocations) numLocations[u] = r.hasEnds ? (int)r.ends.size() : 0;
+        if (alphabetLength) alphabetLength[u] = r.alphabetLength;
+        if (locOffsets) locOffsets[u] = nloc;
+        if (alnOffsets) alnOffsets[u] = naln;
+        nloc += r.hasEnds ? (long long)r.ends.size() : 0;
+        naln += r.hasAlignment ? (long long)(r.opsView ? (size_t)r.opsViewLen : r.ops.size()) : 0;
+    }
+    if (locOffsets) locOffsets[n_] = nloc;
+    if (alnOffsets) alnOffsets[n_] = naln;
+    int* ends = endLocations ? static_cast<int*>(malloc(sizeof(int) * (size_t)std::max<long long>(nloc, 1))) : nullptr;
+    bool anyStarts = false;
+    for (int u = 0; u < n_ && !anyStarts; ++u) anyStarts = results_[u].hasStarts;
+    int* starts = (startLocations && anyStarts) ? static_cast<int*>(malloc(sizeof(int) * (size_t)std::max<long long>(nloc, 1))) : nullptr;
+    unsigned char* aln = alignment ? static_cast<unsigned char*>(malloc((size_t)std::max<long long>(naln, 1))) : nullptr;
+    if ((endLocations && !ends) || (alignment && !aln)) { free(ends); free(starts); free(aln); set_error("out of memory"); return 1; }
+    long long li = 0, ai = 0;
+    for (int u = 0; u < n_; ++u) {
+        const UnitResult& r = results_[u];
+        if (r.hasEnds) {
+            const size_t c = r.ends.size();
+            if (ends && c) memcpy(ends + li, r.ends.data(), c * sizeof(int));
+            if (starts) for (size_t i = 0; i < c; ++i) starts[li + i] = r.hasStarts ? r.starts[i] : -1;
+            li += (long long)c;
+        }
+        if (r.hasAlignment) {
+            const uint8_t* src = r.opsView ? r.opsView : r.ops.data();
+            const size_t len = r.opsView ? (size_t)r.opsViewLen : r.ops.size();
+            if (aln && len) memcpy(aln + ai, src, len);
+            ai += (long long)len;
+        }
+    }
+    if (endLocations) *endLocations = ends;
+    if (startLocations) *startLocations = starts;
+    if (alignment) *alignment = aln;
+    return 0;
+}
+
 // ----------------------------------------------------------------- one pair
 
 int align_one(const char* q, int qn, const char* t, int tn, EdlibAlignConfig cfg, EdlibAlignResult* out)
 {
     const long long qoff[2] = {0, qn}, toff[2] = {0, tn};
     Batch b;
-    if (b.init(q, qoff, 1, t, toff, 1, cfg, 0)) return 1;
+    if (b.init(q, qoff, 1, t, toff, 1, cfg, default_device())) return 1;
     if (b.run()) return 1;
     return b.results(out);
 }

@@ -70,6 +70,8 @@ public:
              EdlibAlignConfig cfg, int device);
     int run();
     int results(EdlibAlignResult* out);
+    int resultsFlat(int* status, int* editDistance, int* numLocations, int* alphabetLength, long long* locOffsets,
+                    int** endLocations, int** startLocations, long long* alnOffsets, unsigned char** alignment);
     EdlibAmdBatchStats stats{};
 
 private:
@@ -158,5 +160,6 @@ private:
 int align_one(const char* q, int qn, const char* t, int tn, EdlibAlignConfig cfg, EdlibAlignResult* out);
 
 int device_count();
+int default_device();
 
 }  // namespace edlib_amd

@@ -88,7 +88,9 @@ def illumina_reads(target, n, m=150, seed=12346, sub=0.01, ins=0.0005, dele=0.00
     `frac_random` is replaced by an unrelated uniform read.
 
     Returns dict(reads=[n,m] uint8, start=[n] int64, edits=[n] int32 (upper
-    bound on the planted edit count), random=[n] bool).  Generated in chunks
+    bound on the planted edit count), random=[n] bool, indels=[n] int32 (planted insertions +
+    deletions: a read with none and not `random` is its genome window with exactly `edits`
+    substitutions, so it ends at start + m - 1 with that many mismatches)).  Generated in chunks
     of `chunk` reads; the result does not depend on the chunk size.
     """
     target = np.asarray(target, dtype=np.uint8)
@@ -99,6 +101,7 @@ def illumina_reads(target, n, m=150, seed=12346, sub=0.01, ins=0.0005, dele=0.00
     is_random = rand_unit(seed, n, 4) < frac_random
     reads = np.empty((n, m), dtype=np.uint8)
     edits = np.empty(n, dtype=np.int32)
+    indels = np.zeros(n, dtype=np.int32)
     th = [int(round(v * (1 << 24))) for v in (sub, sub + ins, sub + ins + dele)]
     cols = np.arange(m + pad)[None, :]
     for a in range(0, n, chunk):
@@ -135,21 +138,39 @@ def illumina_reads(target, n, m=150, seed=12346, sub=0.01, ins=0.0005, dele=0.00
                               + 2 * (is_ins[indel_rows].sum(axis=1) + is_del[indel_rows].sum(axis=1)))
         reads[a:b] = rd
         edits[a:b] = ed
+        indels[a:b] = (is_ins | is_del).sum(axis=1)
     nr = int(is_random.sum())
     if nr:
         reads[is_random] = random_dna(seed, nr * m, 5).reshape(nr, m)
-    return {"reads": reads, "start": start, "edits": edits, "random": is_random}
+    return {"reads": reads, "start": start, "edits": edits, "random": is_random, "indels": indels}
 
 
-def mutated_pairs(n, length, seed, sub, ins, dele):
+def _pair(args):
+    i, length, seed, sub, ins, dele = args
+    t = random_dna(seed, length, stream=1000 + 2 * i)
+    q, _ = mutate(t, seed, sub, ins, dele, stream=1001 + 2 * i)
+    if len(q) == 0:
+        q = t[:1].copy()
+    return q, t
+
+
+def _pair_chunk(args):
+    lo, hi, length, seed, sub, ins, dele = args
+    return [_pair((i, length, seed, sub, ins, dele)) for i in range(lo, hi)]
+
+
+def mutated_pairs(n, length, seed, sub, ins, dele, workers=1, first=0):
     """n (query, target) pairs: target = `length` uniform bases, query = target
-    with edits.  Returns two lists of uint8 arrays."""
-    queries, targets = [], []
-    for i in range(n):
-        t = random_dna(seed, length, stream=1000 + 2 * i)
-        q, _ = mutate(t, seed, sub, ins, dele, stream=1001 + 2 * i)
-        if len(q) == 0:
-            q = t[:1].copy()
-        queries.append(q)
-        targets.append(t)
-    return queries, targets
+    with edits.  Returns two lists of uint8 arrays.
+    Pair i depends on (seed, first + i) only, so `workers` > 1 generates chunks in forked processes
+    with the same result."""
+    if workers > 1 and n >= 4 * workers:
+        import multiprocessing as mp
+        step = (n + 4 * workers - 1) // (4 * workers)
+        jobs = [(first + a, first + min(n, a + step), length, seed, sub, ins, dele) for a in range(0, n, step)]
+        with mp.get_context("fork").Pool(workers) as pool:
+            parts = pool.map(_pair_chunk, jobs)
+        pairs = [p for part in parts for p in part]
+    else:
+        pairs = _pair_chunk((first, first + n, length, seed, sub, ins, dele))
+    return [p[0] for p in pairs], [p[1] for p in pairs]

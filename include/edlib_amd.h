@@ -40,7 +40,7 @@ EDLIB_API const char* edlibAmdVersion(void);
  * Environment: EDLIB_AMD_DEVICES = "all" or a comma list of device ordinals
  * shards the units over several GPUs of the node (contiguous slices, target
  * replicated, one host thread + stream per device, no collective); default
- * is device 0.  All-or-nothing: if any shard fails every result is ERROR. */
+ * is EDLIB_AMD_DEVICE if set, else the calling thread's current HIP device.  All-or-nothing: if any shard fails every result is ERROR. */
 EDLIB_API int edlibAlignBatchSharedTarget(
     const char* const* queries, const int* queryLengths, int numQueries,
     const char* target, int targetLength,
@@ -79,6 +79,21 @@ EDLIB_API int edlibAmdBatchRun(EdlibAmdBatch* batch);
 /* Copy the results of the last Run to the host as EdlibAlignResult[numQueries]
  * (malloc'd arrays, caller frees each with edlibFreeAlignResult). */
 EDLIB_API int edlibAmdBatchResults(EdlibAmdBatch* batch, EdlibAlignResult* results);
+
+/* The same results as flat arrays: no per-unit malloc, one array per field (what a numpy / columnar caller
+ * wants).  status, editDistance, numLocations, alphabetLength: caller-provided int[numQueries];
+ * locOffsets, alnOffsets: caller-provided long long[numQueries + 1]; *endLocations, *startLocations
+ * (locOffsets[numQueries] ints; startLocations is NULL unless the task produced start locations) and
+ * *alignment (alnOffsets[numQueries] op bytes) are malloc'd, the caller free()s them.  Any pointer may be NULL. */
+EDLIB_API int edlibAmdBatchResultsFlat(EdlibAmdBatch* batch, int* status, int* editDistance, int* numLocations,
+                                       int* alphabetLength, long long* locOffsets, int** endLocations,
+                                       int** startLocations, long long* alnOffsets, unsigned char** alignment);
+
+/* edlibFreeAlignResult() over results[0..n) (one call instead of n for binding languages). */
+EDLIB_API void edlibAmdFreeResults(EdlibAlignResult* results, int n);
+
+/* Releases the process-wide cache of device / pinned blocks and idle streams the library keeps between calls. */
+EDLIB_API void edlibAmdTrim(void);
 
 typedef struct {
     double run_ms;          /* HIP-event time of the whole last Run on its stream           */

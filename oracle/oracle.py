@@ -145,3 +145,101 @@ def load_ref():
     if not os.path.exists(path):
         return None
     return _Ref(path)
+
+
+# ------------------------------------------------------------------ native thread pool over a batch
+
+class _RefPoolOut(C.Structure):     # ref_pool.cpp: struct RefPoolOut
+    _fields_ = [("n", C.c_int), ("threads", C.c_int), ("wall_seconds", C.c_double),
+                ("status", C.POINTER(C.c_int)), ("editDistance", C.POINTER(C.c_int)),
+                ("numLocations", C.POINTER(C.c_int)), ("alphabetLength", C.POINTER(C.c_int)),
+                ("alignmentLength", C.POINTER(C.c_int)),
+                ("hasEnds", C.POINTER(C.c_ubyte)), ("hasStarts", C.POINTER(C.c_ubyte)), ("hasAlignment", C.POINTER(C.c_ubyte)),
+                ("locOff", C.POINTER(C.c_longlong)), ("ends", C.POINTER(C.c_int)), ("starts", C.POINTER(C.c_int)),
+                ("alnOff", C.POINTER(C.c_longlong)), ("alignment", C.POINTER(C.c_ubyte)),
+                ("cigExtOff", C.POINTER(C.c_longlong)), ("cigStdOff", C.POINTER(C.c_longlong)),
+                ("cigExt", C.POINTER(C.c_char)), ("cigStd", C.POINTER(C.c_char)),
+                ("error", C.c_char * 256)]
+
+
+_pool_lib = None
+
+
+def _pool():
+    global _pool_lib
+    if _pool_lib is None:
+        path = os.path.join(HERE, "libref_pool.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.ref_pool_run.restype = C.POINTER(_RefPoolOut)
+        L.ref_pool_run.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int]
+        L.ref_pool_free.argtypes = [C.POINTER(_RefPoolOut)]
+        L.ref_pool_physical_cores.restype = C.c_int
+        _pool_lib = L
+    return _pool_lib
+
+
+def physical_cores():
+    return int(_pool().ref_pool_physical_cores())
+
+
+def checker_library():
+    """(path, kind) of the CPU implementation the pool should drive: the compiled reference where it
+    travelled ("reference"), else the C99 restatement ("port")."""
+    p = os.path.join(HERE, "_ref", "libedlib_ref.so")
+    if os.path.exists(p):
+        return p, "reference"
+    load_oracle()
+    return os.path.join(HERE, "liboracle_edlib.so"), "port"
+
+
+def pool_align(qpool, qoff, tpool, toff, shared, mode, task, k=-1, select=None, threads=0, eq_pairs=None,
+               want_cigar=False, libpath=None):
+    """Run edlibAlign over a packed batch on a native std::thread pool (ref_pool.cpp).
+
+    qpool / tpool: contiguous uint8 numpy arrays, qoff / toff: int64 offsets (toff has 2 entries when
+    `shared`).  `select`: optional int32 array of unit indices (the bounded sample of a big batch).
+    Returns a dict of flat numpy arrays (same layout as edlib_amd's flat results) plus wall_seconds / threads."""
+    import numpy as np
+    L = _pool()
+    if libpath is None:
+        libpath, _ = checker_library()
+    qpool = np.ascontiguousarray(qpool, dtype=np.uint8); tpool = np.ascontiguousarray(tpool, dtype=np.uint8)
+    qoff = np.ascontiguousarray(qoff, dtype=np.int64); toff = np.ascontiguousarray(toff, dtype=np.int64)
+    n = len(qoff) - 1
+    sel = None if select is None else np.ascontiguousarray(select, dtype=np.int32)
+    eqb = b"".join((a if isinstance(a, bytes) else a.encode("latin-1"))[:1] + (b if isinstance(b, bytes) else b.encode("latin-1"))[:1]
+                   for a, b in (eq_pairs or []))
+    p = L.ref_pool_run(libpath.encode(), threads, qpool.ctypes.data, qoff.ctypes.data, tpool.ctypes.data, toff.ctypes.data,
+                       1 if shared else 0, n, None if sel is None else sel.ctypes.data, 0 if sel is None else len(sel),
+                       k, MODES[mode] if isinstance(mode, str) else mode, TASKS[task] if isinstance(task, str) else task,
+                       eqb, len(eqb) // 2, 1 if want_cigar else 0)
+    if not p:
+        raise MemoryError("ref_pool_run")
+    o = p.contents
+    try:
+        if o.error:
+            raise RuntimeError("ref_pool: " + o.error.decode())
+        cnt = o.n
+
+        def arr(ptr, count, dtype):
+            if count == 0:
+                return np.zeros(0, dtype=dtype)
+            return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dtype, copy=True)
+        loc = arr(o.locOff, cnt + 1, np.int64); aln = arr(o.alnOff, cnt + 1, np.int64)
+        ce = arr(o.cigExtOff, cnt + 1, np.int64); cs = arr(o.cigStdOff, cnt + 1, np.int64)
+        out = {"n": cnt, "threads": o.threads, "wall_seconds": o.wall_seconds,
+               "status": arr(o.status, cnt, np.int32), "editDistance": arr(o.editDistance, cnt, np.int32),
+               "numLocations": arr(o.numLocations, cnt, np.int32), "alphabetLength": arr(o.alphabetLength, cnt, np.int32),
+               "alignmentLength": arr(o.alignmentLength, cnt, np.int32),
+               "hasEnds": arr(o.hasEnds, cnt, np.uint8), "hasStarts": arr(o.hasStarts, cnt, np.uint8),
+               "hasAlignment": arr(o.hasAlignment, cnt, np.uint8),
+               "locOff": loc, "ends": arr(o.ends, int(loc[-1]), np.int32), "starts": arr(o.starts, int(loc[-1]), np.int32),
+               "alnOff": aln, "alignment": arr(o.alignment, int(aln[-1]), np.uint8),
+               "cigExtOff": ce, "cigStdOff": cs,
+               "cigExt": C.string_at(o.cigExt, int(ce[-1])), "cigStd": C.string_at(o.cigStd, int(cs[-1]))}
+    finally:
+        L.ref_pool_free(p)
+    return out
