@@ -383,6 +383,7 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
         // the banded kernel reads whole dwords; on OUR stream: the null stream does not order with it
         EDLIB_AMD_HIP(hipMemsetAsync(d_tpk_.p, 0, d_tpk_.bytes(), stream_));
         EDLIB_AMD_HIP(d_wordSteps_.alloc(1));
+        EDLIB_AMD_HIP(d_trows_.alloc(((size_t)(T + 15) / 16 + 2) * 8));
     }
     {
         const char* env = getenv("EDLIB_AMD_BAND");
@@ -446,7 +447,7 @@ int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, i
                      const long long* posOff, const int* posCap, bool unbanded, unsigned long long* wordSteps)
 {
     ReadScanArgs a{};
-    a.peq = g.d_peq.p; a.tpk = d_tpk_.p; a.targetLength = tlen(0);
+    a.peq = g.d_peq.p; a.tpk = d_tpk_.p; a.trows = d_trows_.p; a.targetLength = tlen(0);
     a.qlen = g.d_qlen.p; a.kinit = d_kinit; a.slotmap = d_slotmap; a.nlanes = nlanes;
     a.numSegments = numSegments; a.segLen = segLen; a.warm = warm;
     a.segBest = segBest; a.segCnt = segCnt; a.segPos = segPos; a.cap = cap;
@@ -499,6 +500,7 @@ int Batch::runReads()
     stats.path |= 1;
     EDLIB_AMD_HIP(hipMemsetAsync(d_wordSteps_.p, 0, sizeof(unsigned long long), stream_));
     EDLIB_AMD_HIP(launch_pack_target_2bit(d_tpool_.p, d_tlut_.p, T, d_tpk_.p, stream_));
+    if (banded) EDLIB_AMD_HIP(launch_pack_target_rows(d_tpool_.p, d_tlut_.p, T, d_trows_.p, (int)d_trows_.n, stream_));
     for (auto& gp : groups_) {
         ReadGroup& g = *gp;
         EDLIB_AMD_HIP(launch_build_peq_reads(g.nwords, d_qpool_.p, d_qoff_.p, g.d_perm.p, g.nslots,

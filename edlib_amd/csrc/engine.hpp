@@ -105,7 +105,7 @@ private:
         std::vector<int> ovfSlots; std::vector<long long> ovfOff; DevBuf<int> d_ovfPool;
     };
     std::vector<std::unique_ptr<ReadGroup>> groups_;
-    DevBuf<uint32_t> d_tpk_;
+    DevBuf<uint32_t> d_tpk_, d_trows_;
     DevBuf<unsigned long long> d_wordSteps_;
     bool banded_ = false;        // HW groups use the Ukkonen-banded kernel with k-doubling
     int runReads();                                   // device work only; results stay in HBM

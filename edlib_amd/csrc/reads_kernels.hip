@@ -62,6 +62,31 @@ pack_target_2bit_kernel(const uint8_t* __restrict__ raw, const uint8_t* __restri
     tpk[w] = out;
 }
 
+// Expanded target for the banded kernel: 16 bits per column = LDS row offset of the column's Peq rows
+// (symbol << 8), so that one scalar instruction per column puts it into M0.  32 columns per thread.
+__global__ void __launch_bounds__(256)
+pack_target_rows_kernel(const uint8_t* __restrict__ raw, const uint8_t* __restrict__ lut, int T,
+                        u32* __restrict__ trows, int ndwords)
+{
+    __shared__ uint8_t s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;               // dword = 2 columns
+    if (w >= ndwords) return;
+    const int c = 2 * w;
+    const u32 a0 = c < T ? (u32)(s_lut[raw[c]] & 3) : 0u, a1 = c + 1 < T ? (u32)(s_lut[raw[c + 1]] & 3) : 0u;
+    trows[w] = (a0 << 8) | (a1 << 24);
+}
+
+hipError_t launch_pack_target_rows(const uint8_t* raw, const uint8_t* lut, int T, u32* trows, int ndwords,
+                                   hipStream_t stream)
+{
+    if (ndwords == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_target_rows_kernel, dim3((ndwords + 255) / 256), dim3(256), 0, stream,
+                       raw, lut, T, trows, ndwords);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_target_2bit(const uint8_t* raw, const uint8_t* lut, int T, u32* tpk,
                                    hipStream_t stream)
 {
@@ -390,56 +415,56 @@ __device__ __forceinline__ void column_step_eq1(const u32 eq0, u32 (&Pv)[NWD], u
     Mv[0] = ph & Xv;
 }
 
-// All Peq rows of the wave's 64 queries live in LDS as [wave][word][symbol][lane] (1 KB per word).  The row of
-// a column's symbol is picked by M0 = slice base | symbol << 8 and fetched with ds_read_addtid_b32 (address =
-// M0 + offset + 4*lane: no address VGPR, no VALU), word w at offset 1024*w, one column ahead of its use:
-// no symbol dispatch in the instruction stream and no Peq registers (4 x NWD VGPRs less than the
-// register-resident version, one more wave per SIMD at NWD = 5).  hipcc does not count asm loads, so the wait
-// is explicit and names the destinations (cdna_hip_programming.md §5.7).
-// J = position (0..3) of the column's symbol in the quad byte sym4.  The wave's slice is 1 KB-aligned, so the
-// row offset is OR-ed into M0 directly: s_lshl + s_and + s_or per column (scalar issue is not free here:
-// tools/narrow_ubench.hip, 6 SALU per column cost as much as the LDS fetch itself).  These SALU ops write
-// SCC: it is declared clobbered (without that hipcc kept a loop condition in SCC across the block and the
-// kernel never terminated).
-// The wait state that M0 needs before the LDS instruction is filled with the first half of the NEXT column's
-// row offset (off_ -> offNext, masked after the loads), so a column costs s_or + s_lshl + s_and and no s_nop.
-#define EDLIB_AMD_M0_ROW "s_or_b32 m0, %[o], %[base]\n\ts_lshl_b32 %[t], %[s4], %[sh]\n\t"
-#define EDLIB_AMD_M0_TAIL "\n\ts_and_b32 %[t], %[t], 0x300"
-#define EDLIB_AMD_M0_OPS [t] "=&s"(offNext) : [o] "s"(off), [s4] "s"(sym4), [sh] "n"(6 - 2 * J), [base] "s"(ldsBase) : "memory", "scc"
-// row offset of the quad's first column
-__device__ __forceinline__ u32 lds_row_offset0(const u32 sym4) { return (sym4 << 8) & 0x300u; }
+// All Peq rows of the wave's 64 queries live in LDS as [word][symbol][lane] (1 KB per word).  The kernel runs ONE
+// wave per workgroup, so its slice starts at LDS address 0 and the row of a column's (wave-uniform) symbol is
+// M0 = symbol << 8, fetched with ds_read_addtid_b32 (address = M0 + 1024 * word + 4 * lane: no address VGPR, no
+// VALU).  The target is read in the EXPANDED form the row fetch wants (pack_target_rows_kernel): 16 bits per
+// column holding that row offset, 16 columns per s_load_dwordx8, so a column costs ONE scalar instruction --
+// s_pack_ll_b32_b16 m0, pair, 0 (even column) or s_lshr_b32 m0, pair, 16 (odd column) -- where round 1 spent three
+// (shift, mask, or-in the slice base) plus the extraction of the quad's byte (tools/narrow2_ubench.hip: every
+// non-VALU instruction of the one-word column costs about a cycle of the 20 its ten VALU ops take).
+// s_lshr_b32 writes SCC: declared clobbered (hipcc keeps carries and loop conditions there; without it a
+// s_add_u32 / s_addc_u32 pair around the block computed a wild address).  M0 needs one wait state before an
+// add-TID LDS instruction: s_nop here, the column's first VALU op in the hand-scheduled one-word quad.
+#define EDLIB_AMD_M0_EVEN(P) "s_pack_ll_b32_b16 m0, " P ", 0\n\t"
+#define EDLIB_AMD_M0_ODD(P)  "s_lshr_b32 m0, " P ", 16\n\t"
+#define EDLIB_AMD_RD(N, OFF) "ds_read_addtid_b32 " N " offset:" #OFF "\n\t"
+
+// rows of ONE column (J = 0..3 of the quad held in the SGPR pair lo / hi), NA words
 template <int NA, int J>
-__device__ __forceinline__ void lds_rows_request(u32 (&n)[NA], const u32 off, u32& offNext, const u32 sym4, const u32 ldsBase)
+__device__ __forceinline__ void lds_rows_request(u32 (&n)[NA], const u32 lo, const u32 hi)
 {
     static_assert(NA >= 1 && NA <= 8, "band height");
-    if constexpr (NA == 1) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0" EDLIB_AMD_M0_TAIL
-                                        : "=v"(n[0]), EDLIB_AMD_M0_OPS);
-    if constexpr (NA == 2) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024" EDLIB_AMD_M0_TAIL
-                                        : "=v"(n[0]), "=v"(n[1]), EDLIB_AMD_M0_OPS);
-    if constexpr (NA == 3) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024\n\t"
-                                        "ds_read_addtid_b32 %2 offset:2048" EDLIB_AMD_M0_TAIL
-                                        : "=v"(n[0]), "=v"(n[1]), "=v"(n[2]), EDLIB_AMD_M0_OPS);
-    if constexpr (NA == 4) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024\n\t"
-                                        "ds_read_addtid_b32 %2 offset:2048\n\tds_read_addtid_b32 %3 offset:3072" EDLIB_AMD_M0_TAIL
-                                        : "=v"(n[0]), "=v"(n[1]), "=v"(n[2]), "=v"(n[3]), EDLIB_AMD_M0_OPS);
-    if constexpr (NA == 5) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024\n\t"
-                                        "ds_read_addtid_b32 %2 offset:2048\n\tds_read_addtid_b32 %3 offset:3072\n\t"
-                                        "ds_read_addtid_b32 %4 offset:4096" EDLIB_AMD_M0_TAIL
-                                        : "=v"(n[0]), "=v"(n[1]), "=v"(n[2]), "=v"(n[3]), "=v"(n[4]), EDLIB_AMD_M0_OPS);
-    if constexpr (NA == 6) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024\n\t"
-                                        "ds_read_addtid_b32 %2 offset:2048\n\tds_read_addtid_b32 %3 offset:3072\n\t"
-                                        "ds_read_addtid_b32 %4 offset:4096\n\tds_read_addtid_b32 %5 offset:5120" EDLIB_AMD_M0_TAIL
-                                        : "=v"(n[0]), "=v"(n[1]), "=v"(n[2]), "=v"(n[3]), "=v"(n[4]), "=v"(n[5]), EDLIB_AMD_M0_OPS);
-    if constexpr (NA == 7) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024\n\t"
-                                        "ds_read_addtid_b32 %2 offset:2048\n\tds_read_addtid_b32 %3 offset:3072\n\t"
-                                        "ds_read_addtid_b32 %4 offset:4096\n\tds_read_addtid_b32 %5 offset:5120\n\t"
-                                        "ds_read_addtid_b32 %6 offset:6144" EDLIB_AMD_M0_TAIL
-                                        : "=v"(n[0]), "=v"(n[1]), "=v"(n[2]), "=v"(n[3]), "=v"(n[4]), "=v"(n[5]), "=v"(n[6]), EDLIB_AMD_M0_OPS);
-    if constexpr (NA == 8) asm volatile(EDLIB_AMD_M0_ROW "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:1024\n\t"
-                                        "ds_read_addtid_b32 %2 offset:2048\n\tds_read_addtid_b32 %3 offset:3072\n\t"
-                                        "ds_read_addtid_b32 %4 offset:4096\n\tds_read_addtid_b32 %5 offset:5120\n\t"
-                                        "ds_read_addtid_b32 %6 offset:6144\n\tds_read_addtid_b32 %7 offset:7168" EDLIB_AMD_M0_TAIL
-                                        : "=v"(n[0]), "=v"(n[1]), "=v"(n[2]), "=v"(n[3]), "=v"(n[4]), "=v"(n[5]), "=v"(n[6]), "=v"(n[7]), EDLIB_AMD_M0_OPS);
+    const u32 pr = (J < 2) ? lo : hi;
+#define EDLIB_AMD_SET ((J & 1) ? EDLIB_AMD_M0_ODD("%[pr]") : EDLIB_AMD_M0_EVEN("%[pr]"))
+    if constexpr (NA == 1) { if constexpr (J & 1) asm volatile(EDLIB_AMD_M0_ODD("%[pr]") "s_nop 0\n\t" EDLIB_AMD_RD("%0", 0) : "=v"(n[0]) : [pr] "s"(pr) : "memory", "scc");
+                             else asm volatile(EDLIB_AMD_M0_EVEN("%[pr]") "s_nop 0\n\t" EDLIB_AMD_RD("%0", 0) : "=v"(n[0]) : [pr] "s"(pr) : "memory", "scc"); }
+#define EDLIB_AMD_ROWS_ASM(READS, OUTS)                                                                              \
+    { if constexpr (J & 1) asm volatile(EDLIB_AMD_M0_ODD("%[pr]") "s_nop 0\n\t" READS : OUTS : [pr] "s"(pr) : "memory", "scc");   \
+      else asm volatile(EDLIB_AMD_M0_EVEN("%[pr]") "s_nop 0\n\t" READS : OUTS : [pr] "s"(pr) : "memory", "scc"); }
+#define O1 "=v"(n[0])
+#define O2 O1, "=v"(n[1])
+#define O3 O2, "=v"(n[2])
+#define O4 O3, "=v"(n[3])
+#define O5 O4, "=v"(n[4])
+#define O6 O5, "=v"(n[5])
+#define O7 O6, "=v"(n[6])
+#define O8 O7, "=v"(n[7])
+#define R2 EDLIB_AMD_RD("%0", 0) EDLIB_AMD_RD("%1", 1024)
+#define R3 R2 EDLIB_AMD_RD("%2", 2048)
+#define R4 R3 EDLIB_AMD_RD("%3", 3072)
+#define R5 R4 EDLIB_AMD_RD("%4", 4096)
+#define R6 R5 EDLIB_AMD_RD("%5", 5120)
+#define R7 R6 EDLIB_AMD_RD("%6", 6144)
+#define R8 R7 EDLIB_AMD_RD("%7", 7168)
+    if constexpr (NA == 2) EDLIB_AMD_ROWS_ASM(R2, O2)
+    if constexpr (NA == 3) EDLIB_AMD_ROWS_ASM(R3, O3)
+    if constexpr (NA == 4) EDLIB_AMD_ROWS_ASM(R4, O4)
+    if constexpr (NA == 5) EDLIB_AMD_ROWS_ASM(R5, O5)
+    if constexpr (NA == 6) EDLIB_AMD_ROWS_ASM(R6, O6)
+    if constexpr (NA == 7) EDLIB_AMD_ROWS_ASM(R7, O7)
+    if constexpr (NA == 8) EDLIB_AMD_ROWS_ASM(R8, O8)
+#undef EDLIB_AMD_SET
 }
 template <int NA>
 __device__ __forceinline__ void lds_rows_wait(u32 (&n)[NA])
@@ -452,6 +477,52 @@ __device__ __forceinline__ void lds_rows_wait(u32 (&n)[NA])
     if constexpr (NA == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]), "+v"(n[4]), "+v"(n[5]));
     if constexpr (NA == 7) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]), "+v"(n[4]), "+v"(n[5]), "+v"(n[6]));
     if constexpr (NA == 8) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]), "+v"(n[4]), "+v"(n[5]), "+v"(n[6]), "+v"(n[7]));
+}
+
+// ---- the band of one word carries the rows of the NEXT quad across quads (requested while the current
+// quad computes, one s_waitcnt per quad).  word-0 rows of the quad in (lo, hi):
+__device__ __forceinline__ void quad_rows_request1(u32 (&n)[4], const u32 lo, const u32 hi)
+{
+    asm volatile(EDLIB_AMD_M0_EVEN("%[lo]") "s_nop 0\n\t" EDLIB_AMD_RD("%[n0]", 0)
+                 EDLIB_AMD_M0_ODD("%[lo]") "s_nop 0\n\t" EDLIB_AMD_RD("%[n1]", 0)
+                 EDLIB_AMD_M0_EVEN("%[hi]") "s_nop 0\n\t" EDLIB_AMD_RD("%[n2]", 0)
+                 EDLIB_AMD_M0_ODD("%[hi]") "s_nop 0\n\t" EDLIB_AMD_RD("%[n3]", 0)
+                 : [n0] "=&v"(n[0]), [n1] "=&v"(n[1]), [n2] "=&v"(n[2]), [n3] "=&v"(n[3])
+                 : [lo] "s"(lo), [hi] "s"(hi) : "memory", "scc");
+}
+__device__ __forceinline__ void quad_rows_wait1(u32 (&n)[4]) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3])); }
+
+// One column of the one-word band on row register C, with the request of row N of the NEXT quad folded in: MSET
+// writes M0, the v_and after it is the wait state an add-TID LDS instruction needs after an M0 write.  Ten VALU
+// ops, all full rate (column_step_eq1 in the compiler's hands gives the same ten; written out so that the four
+// requests sit where they cost nothing and the quad ends in ONE s_waitcnt).
+#define EDLIB_AMD_NB_COL(C, MSET, N)                                    \
+    MSET                                                                \
+    "v_and_b32 %[t], " C ", %[pv]\n\t"                                  \
+    EDLIB_AMD_RD(N, 0)                                                  \
+    "v_add_u32 %[t], %[t], %[pv]\n\t"                                   \
+    "v_bitop3_b32 %[x], %[t], " C ", %[pv] bitop3:0xde\n\t"             \
+    "v_bitop3_b32 %[p], %[mv], %[x], %[pv] bitop3:0xf1\n\t"             \
+    "v_and_b32 %[m], %[pv], %[x]\n\t"                                   \
+    "v_add_u32 %[p], %[p], %[p]\n\t"                                    \
+    "v_add_u32 %[m], %[m], %[m]\n\t"                                    \
+    "v_or_b32 %[x], " C ", %[mv]\n\t"                                   \
+    "v_bitop3_b32 %[pv], %[m], %[x], %[p] bitop3:0xf1\n\t"              \
+    "v_and_b32 %[mv], %[p], %[x]\n\t"
+__device__ __forceinline__ void quad_one_word(u32 (&c)[4], u32& Pv, u32& Mv, const u32 nlo, const u32 nhi)
+{
+    u32 n0, n1, n2, n3, t, x, p, m;
+    asm volatile(
+        EDLIB_AMD_NB_COL("%[c0]", EDLIB_AMD_M0_EVEN("%[lo]"), "%[n0]")
+        EDLIB_AMD_NB_COL("%[c1]", EDLIB_AMD_M0_ODD("%[lo]"), "%[n1]")
+        EDLIB_AMD_NB_COL("%[c2]", EDLIB_AMD_M0_EVEN("%[hi]"), "%[n2]")
+        EDLIB_AMD_NB_COL("%[c3]", EDLIB_AMD_M0_ODD("%[hi]"), "%[n3]")
+        "s_waitcnt lgkmcnt(0)"
+        : [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2), [n3] "=&v"(n3), [t] "=&v"(t), [x] "=&v"(x), [p] "=&v"(p), [m] "=&v"(m),
+          [pv] "+v"(Pv), [mv] "+v"(Mv)
+        : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [lo] "s"(nlo), [hi] "s"(nhi)
+        : "memory", "scc");
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
 
 template <int NA, int NWD>
@@ -496,42 +567,48 @@ struct HwTrack {            // per-lane tracking state of the banded kernel
     int* pos;
 };
 
-// Four columns (one byte of the packed target) with NA active words, then -- depending on NA and on the
-// position q of the quad in its dword -- the band checkpoint.  Returns the new number of active words.
+// Rows carried from quad to quad by the one-word band (the next quad's rows, already in registers); local to a run
+// of that band height (nothing of it is live at any other height).
+typedef u32 QuadRows[4];
+
+// Four columns (one SGPR pair of the expanded target: lo / hi) with NA active words, then -- depending on NA and
+// on the position Q of the quad in its 16-column block -- the band checkpoint.  nlo / nhi: the NEXT quad's pair
+// (the one-word band requests its rows while this quad computes).  Returns the new number of active words.
 //
 // Checkpoint intervals: a band of ONE word is re-examined every 4 columns, of two words every 8, of more
-// every 16 (at the end of the dword).  With an interval of c columns the band must grow when the score S of
-// its bottom row is <= k + c: rows differ by at most 1, so S > k + c - 1 puts the bottom c rows above k, and
-// a cell <= k descends at most one row per column (values never decrease along a diagonal), so nothing below
-// the band can reach k before the next checkpoint.  The short interval is what keeps the first pass of the
-// k-doubling on one word: against unrelated sequence the score 32 rows down hovers around 13, far above
-// k + 4 for k <= 8 but not above k + 16.
-template <int NA, int NWD>
-__device__ __forceinline__ int band_quad(const u32 sym4, const int q, const int colBase,
-                                         const int colEnd, const bool track, u32 (&Pv)[NWD], u32 (&Mv)[NWD],
-                                         int& e, int& flag, HwTrack& tr, const u32 sh, const int lastRows,
-                                         const u32 ldsBase)
+// every 16 (at the end of the block).  With an interval of c columns the band must grow when the computed score S
+// of its bottom row is <= k + c - 1: a cell <= k below the band at column j + d (d <= c) has its diagonal
+// predecessor <= k in the band's bottom row at column j + d - 1 (values never decrease along a diagonal), which is
+// then exact, and horizontal neighbours differ by at most 1, so S(j) <= k + d - 1 <= k + c - 1.  (Round 1 grew at
+// S <= k + c; the one unit matters: against unrelated sequence the score 32 rows down hovers around 13, and with
+// k = 6 a wave meets S <= 10 at 0.5 % of its checkpoints but S <= 9 at 0.06 %.)  A new word enters as "+1 per row"
+// like the reference's new block (edlib.cpp:605-608).
+template <int NA, int NWD, int Q>
+__device__ __forceinline__ int band_quad(const u32 lo, const u32 hi, const u32 nlo, const u32 nhi, QuadRows& qr,
+                                         const int colBase, const int colEnd, const bool track, u32 (&Pv)[NWD],
+                                         u32 (&Mv)[NWD], int& e, int& flag, HwTrack& tr, const u32 sh, const int lastRows)
 {
-    // straight-line code: the Peq rows of a column arrive from LDS while the previous column is computed.
-    // The first request of a quad is exposed; the other waves of the SIMD cover it (carrying it across quads
-    // costs registers, and with them occupancy; tools/narrow_ubench.hip: deeper prefetch buys nothing).
     int eh[4];
-    u32 nx[NA];
-    u32 o1, o2, o3, o4;
-    lds_rows_request<NA, 0>(nx, lds_row_offset0(sym4), o1, sym4, ldsBase);
+    if constexpr (NA == 1 && NWD > 1) {
+        quad_one_word(qr, Pv[0], Mv[0], nlo, nhi);                              // nothing tracked: the bottom row is outside
+    } else {
+        // straight-line code: the Peq rows of a column arrive from LDS while the previous column is computed.
+        // The first request of a quad is exposed; the other waves of the SIMD cover it.
+        u32 nx[NA];
+        lds_rows_request<NA, 0>(nx, lo, hi);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        lds_rows_wait<NA>(nx);
-        u32 eq[NA];
+        for (int j = 0; j < 4; ++j) {
+            lds_rows_wait<NA>(nx);
+            u32 eq[NA];
 #pragma unroll
-        for (int i = 0; i < NA; ++i) eq[i] = nx[i];
-        if (j == 0) lds_rows_request<NA, 1>(nx, o1, o2, sym4, ldsBase);
-        if (j == 1) lds_rows_request<NA, 2>(nx, o2, o3, sym4, ldsBase);
-        if (j == 2) lds_rows_request<NA, 3>(nx, o3, o4, sym4, ldsBase);
-        if constexpr (NA == 1 && NWD > 1) column_step_eq1<NWD>(eq[0], Pv, Mv);          // nothing tracked: the
-        else if constexpr (NA == 2 && NWD > 2) column_step_eq2<NWD>(eq[0], eq[1], Pv, Mv);   // bottom row is outside
-        else column_step_hw<NA, NWD>(eq, Pv, Mv, e, flag, sh);
-        eh[j] = e;
+            for (int i = 0; i < NA; ++i) eq[i] = nx[i];
+            if (j == 0) lds_rows_request<NA, 1>(nx, lo, hi);
+            if (j == 1) lds_rows_request<NA, 2>(nx, lo, hi);
+            if (j == 2) lds_rows_request<NA, 3>(nx, lo, hi);
+            if constexpr (NA == 2 && NWD > 2) column_step_eq2<NWD>(eq[0], eq[1], Pv, Mv);   // bottom row outside: nothing tracked
+            else column_step_hw<NA, NWD>(eq, Pv, Mv, e, flag, sh);
+            eh[j] = e;
+        }
     }
     if (NA == NWD) {
         if (track && __builtin_amdgcn_ballot_w64(flag < 0) != 0ull) {   // wave-uniform
@@ -555,9 +632,9 @@ __device__ __forceinline__ int band_quad(const u32 sym4, const int q, const int 
     // exceed k, which is all the rules use.  HW: the row above the band's top is all zeros.
     if constexpr (NA == 1) {
         if constexpr (NWD > 1) {
-            // S1 = popc(Pv) - popc(Mv) <= k + 4: second word.  Written so that the loop-invariant k + 4 rides
+            // S1 = popc(Pv) - popc(Mv) <= k + 3: second word.  Written so that the loop-invariant k + 3 rides
             // in the accumulator operand of v_bcnt: two v_bcnt and one v_cmp per quad
-            const int up = __popc(Pv[0]), dn = __popc(Mv[0]) + (tr.best + 4);
+            const int up = __popc(Pv[0]), dn = __popc(Mv[0]) + (tr.best + 3);
             if (__builtin_amdgcn_ballot_w64(up <= dn) != 0ull) {
                 Pv[1] = ~0u; Mv[1] = 0u;                                    // "+1 per row", edlib.cpp:605-608
                 if (NWD == 2) { e = (up - __popc(Mv[0])) + lastRows - tr.best - 1; flag = 0; }
@@ -566,11 +643,11 @@ __device__ __forceinline__ int band_quad(const u32 sym4, const int q, const int 
         }
         return 1;
     } else if constexpr (NA == 2) {
-        if (q & 1) {                                                        // every 8 columns
+        if (Q & 1) {                                                        // every 8 columns
             const int S1 = __popc(Pv[0]) - __popc(Mv[0]);
             const int S2 = S1 + __popc(Pv[1]) - __popc(Mv[1]);
             if constexpr (NWD > 2) {
-                if (__builtin_amdgcn_ballot_w64(S2 <= tr.best + 8) != 0ull) {
+                if (__builtin_amdgcn_ballot_w64(S2 <= tr.best + 7) != 0ull) {
                     Pv[2] = ~0u; Mv[2] = 0u;
                     if (NWD == 3) { e = S2 + lastRows - tr.best - 1; flag = 0; }
                     return 3;
@@ -588,13 +665,13 @@ __device__ __forceinline__ int band_quad(const u32 sym4, const int q, const int 
         }
         return 2;
     } else {
-        if (q == 3) {                                                       // end of the dword: every 16 columns
+        if (Q == 3) {                                                       // end of the block: every 16 columns
             int Sprev = 0;
 #pragma unroll
             for (int i = 0; i + 1 < NA; ++i) Sprev += __popc(Pv[i]) - __popc(Mv[i]);
             const int S = Sprev + __popc(Pv[NA - 1]) - __popc(Mv[NA - 1]);
             if constexpr (NA < NWD) {
-                if (__builtin_amdgcn_ballot_w64(S <= tr.best + 16) != 0ull) {
+                if (__builtin_amdgcn_ballot_w64(S <= tr.best + 15) != 0ull) {
                     Pv[NA < NWD ? NA : 0] = ~0u; Mv[NA < NWD ? NA : 0] = 0u;
                     if (NA + 1 == NWD) { e = S + lastRows - tr.best - 1; flag = 0; } // row m-1 is lastRows rows below
                     return NA + 1;
@@ -609,15 +686,15 @@ __device__ __forceinline__ int band_quad(const u32 sym4, const int q, const int 
     }
 }
 
+typedef u32 u32x8 __attribute__((ext_vector_type(8)));
+
 template <int NWD>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NWD <= 5 ? 8 : 1, 8)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NWD <= 5 ? 8 : 1, 8)))
 scan_reads_banded_kernel(const ReadScanArgs a)
 {
-    const int lane = threadIdx.x & 63;
-    const int rblk = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int seg = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int rblk = blockIdx.x;                                      // one wave per workgroup
     const int idx = rblk * 64 + lane;
-    if (rblk * 64 >= a.nlanes) return;
     const bool live = idx < a.nlanes;
     const int slot = live ? (a.slotmap ? a.slotmap[idx] : idx) : 0;
 
@@ -625,22 +702,21 @@ scan_reads_banded_kernel(const ReadScanArgs a)
     const int m = a.qlen[slot];
     const u32 sh = (u32)(m - 1) & 31u;                                // row m-1 inside the last word
     const int lastRows = m - 32 * (NWD - 1);                          // query rows in the last word
-    // the four Peq rows of the wave's queries: HBM -> LDS, [wave][word][symbol][lane] (1 KB-aligned slices)
-    __shared__ __attribute__((aligned(1024))) u32 s_eq[4][NWD][4][64];
-    const int wv = threadIdx.x >> 6;
+    // the four Peq rows of the wave's queries: HBM -> LDS, [word][symbol][lane].  The only LDS object of a
+    // one-wave workgroup: it sits at LDS address 0, which is what lets M0 be the bare row offset.
+    __shared__ __attribute__((aligned(1024))) u32 s_eq[NWD][4][64];
     {
         const size_t pb = (size_t)(slot >> 6) * 4 * NWD * 64 + (slot & 63);
 #pragma unroll
         for (int d = 0; d < NWD; ++d) {
 #pragma unroll
-            for (int sy = 0; sy < 4; ++sy) s_eq[wv][d][sy][lane] = a.peq[pb + (size_t)(sy * NWD + d) * 64];
+            for (int sy = 0; sy < 4; ++sy) s_eq[d][sy][lane] = a.peq[pb + (size_t)(sy * NWD + d) * 64];
             Pv[d] = ~0u;                                             // column -1: D[i][-1] = i+1
             Mv[d] = 0u;
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
-    const u32 ldsBase = __builtin_amdgcn_readfirstlane(
-        (u32)(size_t)(__attribute__((address_space(3))) u32*)&s_eq[wv][0][0][0]);
+    if ((u32)(size_t)(__attribute__((address_space(3))) u32*)&s_eq[0][0][0] != 0u) __builtin_trap();
     HwTrack tr;
     {
         const int k0 = a.kinit[slot];
@@ -649,7 +725,7 @@ scan_reads_banded_kernel(const ReadScanArgs a)
     tr.cnt = 0;
     {
         // lanes past nlanes (the tail of the last wave) own no record: they must not even read the tables
-        const long long item = (long long)idx * a.numSegments + seg;   // (lane, segment) record
+        const long long item = (long long)idx * a.numSegments + blockIdx.y;   // (lane, segment) record
         tr.cap = live ? (a.posCap ? a.posCap[item] : a.cap) : 0;
         tr.pos = a.segPos + (!live ? 0 : (a.posOff ? a.posOff[item] : item * a.cap));
     }
@@ -657,42 +733,64 @@ scan_reads_banded_kernel(const ReadScanArgs a)
     int flag = 0;
 
     const int T = a.targetLength;
-    const int c0 = seg * a.segLen;
+    const int c0 = blockIdx.y * a.segLen;
     int c1 = c0 + a.segLen; if (c1 > T) c1 = T;
     int cw = c0 - a.warm; if (cw < 0) cw = 0;
-    const int w0 = cw >> 4, wmain = c0 >> 4, wend = (c1 + 15) >> 4;
+    const int b0 = cw >> 4, bmain = c0 >> 4, bend = (c1 + 15) >> 4;   // blocks of 16 columns
+    // constant address space: the blocks are read with s_load_dwordx8 whatever the asm blocks clobber (a plain global
+    // pointer turns into vector loads behind the first "memory" clobber, and the rows' "s" operands into VGPRs)
+    typedef const u32x8 __attribute__((address_space(4))) * TargetBlocks;
+    const TargetBlocks tx = (TargetBlocks)(unsigned long long)a.trows;
     int nw = NWD;
     unsigned int bandWork = 0;                                        // sum of nw over the quads (wave-uniform)
-    // One inner loop per band height: a quad that leaves the height unchanged jumps straight back into the
-    // same code with every live value where it was (one switch around single quads made hipcc shuffle
-    // ~26 registers per quad between the cases).
-    int w = w0, q = 0;
-    // tw: the symbols of dword w that are still ahead, the quad's own in its low byte (the row requests mask
-    // what they need; every scalar instruction per quad counts, profiles/README.md: 0.54 SALU per VALU).
-    // (v_readfirstlane: the "s" asm operands below do not scalarise a uniform value that sits in a VGPR)
-    u32 tw = w0 < wend ? (u32)__builtin_amdgcn_readfirstlane(a.tpk[w0]) : 0u;
-    while (w < wend) {
+    // One inner loop per band height: a quad that leaves the height unchanged falls into the next quad of the same
+    // code with every live value where it was.  The 16 columns of a block are four unrolled quads of straight-line
+    // code; a run that starts in the middle of a block (the height changed there) first finishes that block quad
+    // by quad (an entry switch into the unrolled body made hipcc shuffle the rows and Pv / Mv between registers
+    // after every quad: 8 v_mov per 40 useful instructions).  cur / nxt: blocks b and b + 1 in SGPRs (the buffer
+    // is padded by two blocks); the load of block b + 2's predecessor is issued a whole block ahead of its use.
+    int b = b0, q = 0;
+    u32x8 cur = tx[b0], nxt = tx[b0 + 1];
+    while (b < bend) {
         switch (nw) {
-#define CASE(NA) case NA:                                                                                   \
-            if (NA <= NWD) {                                                                                \
-                do {                                                                                        \
-                    bandWork += (unsigned int)NA;                                                           \
-                    nw = band_quad<(NA <= NWD ? NA : NWD), NWD>(tw, q, w * 16 + q * 4, c1,                  \
-                             w >= wmain /* warm-up columns record nothing */, Pv, Mv, e, flag, \
-                             tr, sh, lastRows, ldsBase);                                                 \
-                    tw >>= 8;                                                                               \
-                    q = (q + 1) & 3;                                                                        \
-                    if (q == 0) { ++w; if (w < wend) tw = (u32)__builtin_amdgcn_readfirstlane(a.tpk[w]); }  \
-                } while (nw == NA && w < wend);                                                             \
-            }                                                                                               \
+#define QUAD(NA, Q)                                                                                             \
+            nw = band_quad<(NA <= NWD ? NA : NWD), NWD, Q>(cur[2 * Q], cur[2 * Q + 1],                          \
+                     Q < 3 ? cur[(2 * Q + 2) & 7] : nxt[0], Q < 3 ? cur[(2 * Q + 3) & 7] : nxt[1], qr,          \
+                     b * 16 + Q * 4, c1, b >= bmain /* warm-up columns record nothing */, Pv, Mv, e, flag, tr,  \
+                     sh, lastRows);
+#define ADVANCE { q = 0; ++b; cur = nxt; nxt = tx[b + 1]; }
+#define CASE(NA) case NA:                                                                                       \
+            if (NA <= NWD) {                                                                                    \
+                const int q0 = b * 4 + q;                                                                       \
+                QuadRows qr;                                                                                    \
+                /* the one-word band starts with the rows of its first quad in registers */                     \
+                if (NA == 1 && NWD > 1) {                                                                       \
+                    const u32 l = q == 0 ? cur[0] : q == 1 ? cur[2] : q == 2 ? cur[4] : cur[6];                 \
+                    const u32 h = q == 0 ? cur[1] : q == 1 ? cur[3] : q == 2 ? cur[5] : cur[7];                 \
+                    quad_rows_request1(qr, l, h); quad_rows_wait1(qr);                                          \
+                }                                                                                               \
+                /* head: the rest of a block entered in the middle (a quad always advances the position) */     \
+                if (q == 1) { QUAD(NA, 1) q = 2; }                                                              \
+                if (q == 2 && nw == NA) { QUAD(NA, 2) q = 3; }                                                  \
+                if (q == 3 && nw == NA) { QUAD(NA, 3) ADVANCE }                                                 \
+                /* steady state: whole blocks, four quads of straight-line code per trip */                     \
+                while (q == 0 && nw == NA && b < bend) {                                                        \
+                    QUAD(NA, 0) if (nw != NA) { q = 1; break; }                                                 \
+                    QUAD(NA, 1) if (nw != NA) { q = 2; break; }                                                 \
+                    QUAD(NA, 2) if (nw != NA) { q = 3; break; }                                                 \
+                    QUAD(NA, 3) ADVANCE                                                                         \
+                }                                                                                               \
+                bandWork += (unsigned int)NA * (unsigned int)(b * 4 + q - q0);                                  \
+            }                                                                                                   \
             break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
+#undef ADVANCE
+#undef QUAD
         }
     }
     if (live) {
-        // recomputed rather than kept in two VGPRs through the scan (the kernel sits at an occupancy edge)
-        const long long it = (long long)((blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63)) * a.numSegments + blockIdx.y;
+        const long long it = (long long)(blockIdx.x * 64 + threadIdx.x) * a.numSegments + blockIdx.y;
         a.segBest[it] = tr.best;
         a.segCnt[it] = tr.cnt;
     }
@@ -703,7 +801,7 @@ hipError_t launch_scan_reads_banded(int nwords, const ReadScanArgs& a, hipStream
 {
     if (a.nlanes == 0) return hipSuccess;
     const int nrblk = (a.nlanes + 63) / 64;
-    dim3 grid((nrblk + 3) / 4, a.numSegments), block(256);
+    dim3 grid(nrblk, a.numSegments), block(64);
     switch (nwords) {
 #define CASE(N) case N: hipLaunchKernelGGL((scan_reads_banded_kernel<N>), grid, block, 0, stream, a); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)

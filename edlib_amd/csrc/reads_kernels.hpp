@@ -12,7 +12,9 @@ constexpr int kLanes = 64;            // wave64, hard-coded (gfx950)
 // Everything the scan kernel needs; plain pointers into HBM.
 struct ReadScanArgs {
     const uint32_t* peq;      // [readBlock][4 symbols][NWD words][64 lanes]
-    const uint32_t* tpk;      // target, 2 bits / symbol, 16 symbols / dword, LSB first
+    const uint32_t* tpk;      // target, 2 bits / symbol, 16 symbols / dword, LSB first (scan_reads_kernel)
+    const uint32_t* trows;    // target, 16 bits / symbol = LDS row offset (symbol << 8), 16 columns per 32-byte block,
+                              // padded by two blocks (scan_reads_banded_kernel)
     int targetLength;
     const int* qlen;          // [slots] query length of the read in that slot (>= 1)
     const int* kinit;         // [slots] initial threshold: columns scoring <= kinit are candidates
@@ -39,6 +41,9 @@ hipError_t launch_scan_reads_banded(int nwords, const ReadScanArgs& a, hipStream
 
 hipError_t launch_pack_target_2bit(const uint8_t* raw, const uint8_t* lut, int targetLength,
                                    uint32_t* tpk, hipStream_t stream);
+// ndwords = 8 * (blocks of 16 columns, including the two blocks of padding): every dword is written
+hipError_t launch_pack_target_rows(const uint8_t* raw, const uint8_t* lut, int targetLength,
+                                   uint32_t* trows, int ndwords, hipStream_t stream);
 
 // Builds Peq for every slot (reference buildPeq, edlib.cpp:358-384, for the <=4 target symbols),
 // the per-slot query length and the number of query byte values absent from the target.

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <malloc.h>
 #include <string>
 #include <thread>
 #include <vector>
@@ -129,6 +130,15 @@ RefPoolOut* ref_pool_run(const char* libpath, int nthreads, const char* qpool, c
             impl.drop(r);
         }
     };
+    // The reference allocates (and frees) its transformed copy of the target in every call (edlib.cpp:1425-1430:
+    // 5 MB for config 2).  glibc serves a repeated request of exactly the size it last freed with a fresh mmap()
+    // each time (the dynamic threshold is set to that chunk's size and the test is >=), so N threads spend their
+    // time in page faults and TLB shootdowns instead of in edlibAlign.  A caller that cares pins the threshold;
+    // so does this pool (REF_POOL_MALLOPT=0 leaves glibc alone) -- the reference itself is untouched.
+    {
+        const char* env = getenv("REF_POOL_MALLOPT");
+        if (!(env && env[0] == '0')) { mallopt(M_MMAP_THRESHOLD, 32 << 20); mallopt(M_TRIM_THRESHOLD, 512 << 20); }
+    }
     const auto w0 = std::chrono::steady_clock::now();
     {
         std::vector<std::thread> th;
