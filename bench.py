@@ -148,7 +148,7 @@ def cpu_baseline_and_parity(w, flat, sample_target):
     from oracle import oracle as O
     c = CONFIGS[w["config"]]
     lib, kind = O.checker_library()
-    threads = os.cpu_count() or 1
+    threads, quota = O.cpu_quota()               # not os.cpu_count(): the box caps the container with a cgroup quota
     n = w["n"]
     want_cigar = c["task"] == "path"
 
@@ -158,10 +158,10 @@ def cpu_baseline_and_parity(w, flat, sample_target):
     if sample_target >= n:
         sel = np.arange(n, dtype=np.int32)
     else:
-        # calibrate on one unit per thread, then size the sample for ~25 s of wall time
-        cal = run(np.linspace(0, n - 1, min(n, threads)).astype(np.int32))
+        # calibrate on two units per thread, then let the sample take at most ~60 s of wall time
+        cal = run(np.linspace(0, n - 1, min(n, 2 * threads)).astype(np.int32))
         per_unit = max(cal["wall_seconds"], 1e-3) / max(1, cal["n"]) * min(cal["n"], threads)   # thread-seconds per unit
-        fit = int(25.0 * threads / per_unit)
+        fit = int(60.0 * threads / per_unit)
         cnt = max(min(2000, n), min(sample_target, fit))
         half = cnt // 2                                   # first half + evenly strided half
         sel = np.unique(np.concatenate([np.arange(half), np.linspace(0, n - 1, cnt - half).astype(np.int64)])).astype(np.int32)
@@ -199,11 +199,12 @@ def cpu_baseline_and_parity(w, flat, sample_target):
     gcups = cells / ref["wall_seconds"] / 1e9
     phys = O.physical_cores()
     base = {"value": round(gcups, 2), "unit": "GCUPS", "cores": ref["threads"], "kind": kind,
-            "physical_cores": phys, "per_thread": round(gcups / ref["threads"], 3),
-            "per_physical_core": round(gcups / max(1, min(phys or ref["threads"], ref["threads"])), 3),
+            "per_thread": round(gcups / ref["threads"], 3),
+            "host": {"logical_cpus": os.cpu_count(), "physical_cores": phys,
+                     "cgroup_cpu_quota": quota, "threads_used": ref["threads"]},
             "wall_seconds": round(ref["wall_seconds"], 2),
-            "sample": "%d of the batch's %d units (%s), native std::thread pool (oracle/ref_pool.cpp), %d threads, "
-                      "one edlibAlign() per unit" % (len(sel), n, "the whole batch" if len(sel) == n else
+            "sample": "%d of the batch's %d units (%s), native std::thread pool (oracle/ref_pool.cpp), %d threads "
+                      "(= the container's CPU quota), one edlibAlign() per unit, glibc mmap threshold pinned" % (len(sel), n, "the whole batch" if len(sel) == n else
                                                       "first half + evenly strided half", ref["threads"])}
     parity = {"checked": int(len(sel)), "bit_exact": int(len(sel) - bad.sum()),
               "fields": "status, editDistance, numLocations, endLocations, startLocations, alphabetLength" +

@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstring>
 #include <mutex>
@@ -218,15 +219,16 @@ static void build_tables(Tables& tab, const uint8_t* targets, long long totalTar
 
 // Number of distinct byte values in query (and, for non-shared batches, target):
 // the alphabetLength field (edlib.cpp:162, transformSequences :1417-1462).
-// One wave per unit, 256-bit presence set OR-reduced across lanes.
-__global__ void __launch_bounds__(64)
+// One workgroup per unit: aligned dword loads (four symbols each; the pools are padded), a 256-bit presence set per
+// thread in four 64-bit words, OR-reduced across the wave and then across the four waves through LDS.
+__global__ void __launch_bounds__(256)
 alphabet_count_kernel(const uint8_t* __restrict__ qpool, const long long* __restrict__ qoff,
                       const uint8_t* __restrict__ tpool, const long long* __restrict__ toff,
                       int shared, const uint32_t* __restrict__ basePresence,
                       const int* __restrict__ unitIdx, int* __restrict__ out)
 {
+    __shared__ unsigned long long s_set[4][4];
     const int u = unitIdx[blockIdx.x];
-    const int lane = threadIdx.x;
     unsigned long long s[4] = {0, 0, 0, 0};
     auto add = [&](uint32_t b) {
         const unsigned long long bit = 1ull << (b & 63);
@@ -234,18 +236,31 @@ alphabet_count_kernel(const uint8_t* __restrict__ qpool, const long long* __rest
         s[0] |= (w == 0) ? bit : 0ull; s[1] |= (w == 1) ? bit : 0ull;
         s[2] |= (w == 2) ? bit : 0ull; s[3] |= (w == 3) ? bit : 0ull;
     };
-    const long long q0 = qoff[u], q1 = qoff[u + 1];
-    for (long long i = q0 + lane; i < q1; i += 64) add(qpool[i]);
-    if (!shared) {
-        const long long t0 = toff[u], t1 = toff[u + 1];
-        for (long long i = t0 + lane; i < t1; i += 64) add(tpool[i]);
-    }
+    auto scan = [&](const uint8_t* pool, long long lo, long long hi) {
+        for (long long w = (lo >> 2) + threadIdx.x; (w << 2) < hi; w += blockDim.x) {
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(pool + (w << 2));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long long at = (w << 2) + k;
+                if (at >= lo && at < hi) add((v >> (8 * k)) & 0xffu);
+            }
+        }
+    };
+    scan(qpool, qoff[u], qoff[u + 1]);
+    if (!shared) scan(tpool, toff[u], toff[u + 1]);
     for (int off = 32; off > 0; off >>= 1)
         for (int k = 0; k < 4; ++k) s[k] |= __shfl_xor(s[k], off);
-    if (shared)
-        for (int k = 0; k < 4; ++k)
-            s[k] |= ((unsigned long long)basePresence[2 * k + 1] << 32) | basePresence[2 * k];
-    if (lane == 0) out[blockIdx.x] = __popcll(s[0]) + __popcll(s[1]) + __popcll(s[2]) + __popcll(s[3]);
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 4; ++k) s_set[threadIdx.x >> 6][k] = s[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int k = 0; k < 4; ++k) {
+            unsigned long long v = s_set[0][k] | s_set[1][k] | s_set[2][k] | s_set[3][k];
+            if (shared) v |= ((unsigned long long)basePresence[2 * k + 1] << 32) | basePresence[2 * k];
+            n += __popcll(v);
+        }
+        out[blockIdx.x] = n;
+    }
 }
 
 // overflow census of the reads path: how many slots need the exact second pass
@@ -897,7 +912,7 @@ int Batch::alphabetLengths(const std::vector<int>& units, std::vector<UnitResult
     DevBuf<int> d_idx, d_out;
     EDLIB_AMD_HIP(d_idx.alloc(units.size())); EDLIB_AMD_HIP(d_out.alloc(units.size()));
     EDLIB_AMD_HIP(hipMemcpyAsync(d_idx.p, units.data(), units.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
-    hipLaunchKernelGGL(alphabet_count_kernel, dim3((unsigned)units.size()), dim3(64), 0, stream_,
+    hipLaunchKernelGGL(alphabet_count_kernel, dim3((unsigned)units.size()), dim3(256), 0, stream_,
                        d_qpool_.p, d_qoff_.p, d_tpool_.p, d_toff_.p, shared_ ? 1 : 0, d_presence_.p,
                        d_idx.p, d_out.p);
     EDLIB_AMD_HIP(hipGetLastError());
@@ -925,21 +940,21 @@ int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& spli
     // Each piece scans inside the band of the WHOLE piece with k = its distance, stopped at the half's last
     // column -- exactly the reference's two calls, edlib.cpp:1252-1260 -- on the smallest lane ring that holds
     // that band (or all its blocks); pieces no ring holds take the unbanded strips.  Both dump their last column.
-    static const int rings[5] = {4, 16, 32, 64, 0};
+    static const int rings[kNumRings + 1] = {4, 8, 16, 21, 32, 64, 0};
     // (packing only pays with enough pieces to fill the chip: a handful of long pieces runs faster one per wave)
     const bool packed = np >= 256;
     auto ring_of = [&](const Piece& pc) {
         const bool off = getenv("EDLIB_AMD_NWBAND") && getenv("EDLIB_AMD_NWBAND")[0] == '0';
-        if (off) return 4;
-        if (!packed) return (pc.m > 64 * 64 && pc.score <= kMaxBandK) ? 3 : 4;
-        for (int g = 0; g < 4; ++g) if (pc.score <= ring_max_k(rings[g])) return g;
-        return (pc.m + 63) / 64 <= 64 ? 3 : 4;
+        if (off) return kNumRings;
+        if (!packed) return (pc.m > 64 * 64 && pc.score <= kMaxBandK) ? kNumRings - 1 : kNumRings;
+        for (int g = 0; g < kNumRings; ++g) if (pc.score <= ring_max_k(rings[g])) return g;
+        return (pc.m + 63) / 64 <= 64 ? kNumRings - 1 : kNumRings;
     };
     std::vector<size_t> order; order.reserve(np);
-    size_t groupCount[5] = {0, 0, 0, 0, 0};
+    size_t groupCount[kNumRings + 1] = {0};
     std::vector<int> groupOf(np);
     for (size_t p = 0; p < np; ++p) { groupOf[p] = ring_of(big[p]); ++groupCount[groupOf[p]]; }
-    for (int g = 0; g < 5; ++g) for (size_t p = 0; p < np; ++p) if (groupOf[p] == g) order.push_back(p);
+    for (int g = 0; g <= kNumRings; ++g) for (size_t p = 0; p < np; ++p) if (groupOf[p] == g) order.push_back(p);
     std::vector<PairDesc> descs(2 * np);
     std::vector<int> best(np);
     long long peqWords = 0, auxInts = 0, colBlocks = 0;
@@ -989,7 +1004,7 @@ int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& spli
     }
     a.colP = colP.p; a.colM = colM.p; a.colS = colS.p;
     size_t first = 0;
-    for (int g = 0; g < 5; ++g) {
+    for (int g = 0; g <= kNumRings; ++g) {
         if (!groupCount[g]) continue;
         a.descs = d_descs_.p + 2 * first; a.numUnits = (int)(2 * groupCount[g]);
         a.outScore = d_outScore_.p + 2 * first; a.outCount = d_outCount_.p + 2 * first; a.outLast = d_outLast_.p + 2 * first;
@@ -1074,16 +1089,16 @@ int Batch::solvePaths(const std::vector<Piece>& jobs, std::vector<OpsOut>& opsOu
     std::vector<const uint8_t*> leafPtr(units.size(), nullptr); std::vector<int> leafLen(units.size(), 0);
     {
         const bool bandOff = getenv("EDLIB_AMD_NWBAND") && getenv("EDLIB_AMD_NWBAND")[0] == '0';
-        static const int rings[5] = {4, 16, 32, 64, 0};
+        static const int rings[kNumRings + 1] = {4, 8, 16, 21, 32, 64, 0};
         std::vector<int> ringOfUnit(units.size(), 0);
         for (size_t u = 0; u < units.size(); ++u) {
             const int nb = (units[u].qlen + 63) / 64;
-            for (int g = 0; g < 4 && !bandOff; ++g)
+            for (int g = 0; g < kNumRings && !bandOff; ++g)
                 if (nb <= rings[g] || units[u].kinit <= ring_max_k(rings[g])) { ringOfUnit[u] = rings[g]; break; }
         }
-        size_t perRing[5] = {0, 0, 0, 0, 0};
-        for (size_t u = 0; u < units.size(); ++u) for (int g = 0; g < 5; ++g) if (ringOfUnit[u] == rings[g]) ++perRing[g];
-        for (int g = 0; g < 5; ++g) {
+        size_t perRing[kNumRings + 1] = {0};
+        for (size_t u = 0; u < units.size(); ++u) for (int g = 0; g <= kNumRings; ++g) if (ringOfUnit[u] == rings[g]) ++perRing[g];
+        for (int g = 0; g <= kNumRings; ++g) {
             if (!perRing[g]) continue;
             SolveOut so;
             if (perRing[g] == units.size()) {                       // the usual case: one kind of leaf
@@ -1174,45 +1189,55 @@ int Batch::solveSemiGlobal(int mode, bool wantPositions, const std::vector<UnitS
 
 // The reference finds the NW distance by doubling k from 64 until the banded scan succeeds
 // (edlib.cpp:197-217); any threshold >= the distance gives the same answer, so the levels here are the
-// ring sizes of scan_pairs_ring_kernel: K = 128 on 4-lane rings (16 units per wave), K = 896 on 16-lane
-// rings, K = 1920 on half waves, K = 3968 on whole waves, then the unbanded strips.  A unit whose blocks all fit a ring is exact on
-// it for any distance (threshold max(m, T)).  A failed level costs 1/16 or 1/4 of the next one, which is
-// pure waste when the whole batch is divergent, so larger batches first measure the divergence of 64
-// strided units on their 1 kb prefixes (one small launch) and every unit starts at the level that holds
-// its extrapolated distance.  The estimate only picks the starting level; results never depend on it.
+// ring sizes of scan_pairs_ring_kernel: K = 128 on 4-lane rings (16 units per wave), 384 on 8, 896 on 16, 1216 on 21
+// (three units per wave), 1920 on half waves, 3968 on whole waves, then the unbanded strips.  A unit whose blocks
+// all fit a ring is exact on it for any distance (threshold max(m, T)).  A failed level is pure waste when the whole
+// batch is divergent, so larger batches first measure the divergence of 64 strided units on their 1 kb prefixes
+// (one small launch) and every unit starts at the level that holds its extrapolated distance.  The estimate only picks the starting level; results never depend on it.
 int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<int>& score)
 {
     const size_t n = units.size();
     score.assign(n, -1);
     if (n == 0) return 0;
     const bool bandOff = getenv("EDLIB_AMD_NWBAND") && getenv("EDLIB_AMD_NWBAND")[0] == '0';
-    static const int ringOf[4] = {4, 16, 32, 64};
-    const int nl = 4;                                                   // ring levels; level nl = unbanded strips
+    static const int ringOf[kNumRings] = {4, 8, 16, 21, 32, 64};
+    const int nl = kNumRings;                                           // ring levels; level nl = unbanded strips
     const int kInf = 0x3fffffff;
     const int kcap = cfg_.k >= 0 ? cfg_.k : kInf;                       // answers above the caller's k are all alike
     auto blocks = [&](size_t i) { return (units[i].qlen + 63) / 64; };
 
-    double rate = 0.0;                                                  // edits per base, upper quartile of the sample
-    if (n >= 256 && !bandOff && !getenv("EDLIB_AMD_NOPROBE")) {
+    double rate = 0.0;                                                  // edits per base, median of the sample
+    size_t maxBlocks = 0;
+    for (size_t i = 0; i < n; ++i) maxBlocks = std::max<size_t>(maxBlocks, (size_t)blocks(i));
+    // (units of at most 16 blocks climb cheap levels -- the 16-lane ring holds them whole -- and skip the probe)
+    if (n >= 256 && maxBlocks > 16 && !bandOff && !getenv("EDLIB_AMD_NOPROBE")) {
+        // 64 strided units, the first 1 kb of the query against the first 1 kb + 128 of the target in PREFIX mode
+        // (the best end column is free: a global alignment of two equally cut prefixes would add the indel drift at
+        // the cut to the count, about one edit in a hundred bases at ONT-like rates)
         const int np = 64, cut = 1024;
         std::vector<UnitSpec> probe(np);
         for (int i = 0; i < np; ++i) {
             UnitSpec u = units[(size_t)((long long)i * n / np)];
-            u.qlen = std::min(u.qlen, cut); u.tlen = std::min(u.tlen, cut);
-            u.kinit = std::max(u.qlen, u.tlen);                         // 16 blocks at most: exact on a 16-lane ring
+            u.qlen = std::min(u.qlen, cut); u.tlen = std::min(u.tlen, cut + 128);
+            u.kinit = u.qlen;                                           // 16 blocks at most: the whole matrix on a 16-lane ring
             probe[i] = u;
         }
         SolveOut so;
-        if (solve(EDLIB_MODE_NW, false, false, probe, so, 16)) return 1;
+        if (solve(EDLIB_MODE_SHW, false, false, probe, so, 16)) return 1;
         std::vector<double> r(np);
-        for (int i = 0; i < np; ++i) r[i] = (double)so.score[i] / std::max(1, std::max(probe[i].qlen, probe[i].tlen));
+        for (int i = 0; i < np; ++i) r[i] = (double)std::max(so.score[i], 0) / std::max(1, probe[i].qlen);
         std::sort(r.begin(), r.end());
-        rate = r[(np * 3) / 4];
+        rate = r[np / 2];
     }
-    // first level of a unit: the smallest ring that holds all its blocks or its extrapolated distance
+    // First level of a unit: the smallest ring that holds all its blocks or its extrapolated distance.  The distance
+    // of a unit of length L at rate r scatters like a sum of L Bernoulli trials (sigma = sqrt(r L)).  A ring of G
+    // lanes costs G / 64 of a wave per unit, so trying the smaller ring first pays as long as fewer than a quarter
+    // to a half of the units fail on it and move up: the estimate is the mean plus half a sigma (10 kb pairs at
+    // 11.4 % sit under the 21-lane ring's 1216 -- three units per wave instead of two -- and the 1 % above it rerun).
     auto first_level = [&](size_t i) {
         const UnitSpec& u = units[i];
-        const double est = std::min<double>(kcap, 1.25 * rate * std::max(u.qlen, u.tlen) + std::abs(u.qlen - u.tlen) + 8);
+        const double mean = rate * std::min(u.qlen, u.tlen) + std::abs(u.qlen - u.tlen);
+        const double est = std::min<double>(kcap, mean + 0.5 * std::sqrt(mean) + 8);
         for (int l = 0; l < nl; ++l)
             if (blocks(i) <= ringOf[l] || est <= ring_max_k(ringOf[l])) return l;
         return est <= 2.0 * ring_max_k(64) ? nl - 1 : nl;               // far above every band: straight to the strips

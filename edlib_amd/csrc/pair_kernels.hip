@@ -290,46 +290,49 @@ hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStr
 // first/lastBlock bookkeeping converges to, edlib.cpp:744-830): a path of cost <= K only visits
 // diagonals d = j - i in [dmin, dmax] = [min(0,D) - p, max(0,D) + p], D = T - m, p = (K - |D|) / 2.
 // Block b therefore lives for columns [64b + dmin, 64b + 63 + dmax], and fewer than G consecutive
-// blocks are alive at a time when K <= ring_max_k(G).  A RING of G lanes (G = 4, 16, 32 or 64) therefore
-// covers a query of any length, and a wave carries 64 / G independent units:
+// blocks are alive at a time when K <= ring_max_k(G).  A RING of G lanes (G = 4, 8, 16, 21, 32 or 64)
+// therefore covers a query of any length, and a wave carries 64 / G independent units:
 //   * blocks are mapped to the ring's lanes round-robin (block b -> ring lane b % G).  When a lane's
 //     block leaves the band it re-arms for block b + G: state "+1 per row" below the upstream block's
 //     bottom score, exactly the reference's new block (edlib.cpp:803-808); cells outside the band only
 //     ever enter as such upper bounds, so values <= K stay exact (Ukkonen);
 //   * same anti-diagonal schedule as scan_pairs_kernel (block b updates column t - b at step t); the
-//     carry moves one lane up the ring per step in one DPP move (wave_ror:1 / row_ror:1 / quad_perm; the
-//     32-lane ring patches two lanes of a wave_ror with v_readlane / v_writelane; the last ring lane
-//     feeds the first); a block whose upstream is outside the band (or block 0)
-//     takes hin = +1 (edlib.cpp:779);
-//   * target symbols are staged in a 256-entry LDS ring per unit, filled 64 columns at a time; each
-//     lane reads the symbol of its next-but-one column and the Peq word of its next column while it
-//     computes the current one;
+//     carry moves one lane up the ring per step -- one DPP move for rings of 4, 16 and 64 lanes
+//     (quad_perm / row_ror / wave_ror), ds_bpermute_b32 for 8, 21 and 32 (any ring size works: 21 lanes
+//     = three units per wave is what 10 kb pairs at ONT-like divergence run on);
+//   * THE STEP IS BRANCH-LIGHT (round 2; round 1 spent 56 % of its instructions on glue).  Every lane runs
+//     the block update every step, whether its block is alive or not: a lane outside its block's life
+//     computes garbage on state that the next (re)arm overwrites.  What keeps that harmless:
+//       - the SENDER neutralises its carry: a lane that is not inside its block's life emits hout = +1,
+//         which is what a block takes from an upstream outside the band (edlib.cpp:779), so the receiver
+//         needs no "is my upstream alive" test;
+//       - the only per-step bookkeeping is one countdown per lane (steps to the lane's next event: its block
+//         starts, or its block has finished); the wave leaves the straight-line step only when some lane's
+//         countdown is at zero (about one step in eight at config 4's shape);
+//       - the NW score is decoded from the last block's final state (bottom score minus the vertical deltas
+//         below row m-1, like the reference does at edlib.cpp:914-917) instead of being followed per column;
+//   * target symbols sit in a 256-entry LDS ring per unit as the BYTE OFFSET of their Peq row (one v_add
+//     away from the address of the lane's Peq word), filled 64 columns at a time; each lane reads the
+//     offset of its next-but-one column and the Peq word of its next column while it computes the current one;
 //   * steps: T + numBlocks - 1 instead of (T + 63) per 64-block strip;
 //   * STORE: every block-step also writes (Pv, Mv, block score) at [ring lane][column] for
 //     traceback_kernel -- the reference's AlignmentData restricted to first..lastBlock (edlib.cpp:883-893).
 // A unit whose blocks all fit the ring (numBlocks <= G) may use any K: with K = max(m, T) the band is
 // the whole matrix.
-template <int G> __device__ __forceinline__ int ring_ror(const int v)
+template <int G> __device__ __forceinline__ int ring_ror(const int v, const int srcAddr)
 {
     // every lane has a source lane: no `old` operand to initialise (v_mov_b32_dpp ... bound_ctrl:1)
     if constexpr (G == 64) return __builtin_amdgcn_mov_dpp(v, 0x13C /*wave_ror:1*/, 0xf, 0xf, true);
-    else if constexpr (G == 32) {
-        // no DPP rotates 32 lanes: rotate the wave and hand lanes 0 and 32 their ring's last lane
-        int x = __builtin_amdgcn_mov_dpp(v, 0x13C, 0xf, 0xf, true);
-        const int lo = __builtin_amdgcn_readlane(v, 31), hi = __builtin_amdgcn_readlane(v, 63);
-        asm("v_writelane_b32 %0, %1, 0" : "+v"(x) : "s"(lo));
-        asm("v_writelane_b32 %0, %1, 32" : "+v"(x) : "s"(hi));
-        return x;
-    }
     else if constexpr (G == 16) return __builtin_amdgcn_mov_dpp(v, 0x121 /*row_ror:1*/, 0xf, 0xf, true);
-    else return __builtin_amdgcn_mov_dpp(v, 0x93 /*quad_perm:[3,0,1,2]*/, 0xf, 0xf, true);
+    else if constexpr (G == 4) return __builtin_amdgcn_mov_dpp(v, 0x93 /*quad_perm:[3,0,1,2]*/, 0xf, 0xf, true);
+    else return __builtin_amdgcn_ds_bpermute(srcAddr, v);              // srcAddr = 4 * (lane of the ring's previous lane)
 }
 
 // Ring layout of the column store: one row of T entries per ring lane, block b in row b % G (blocks b and
 // b + G are never alive in the same column).  A lane writes consecutive entries step after step, and the
 // traceback walking left through a block reads them back-to-back (4 columns per 128-byte line).
 __host__ __device__ static inline long long ring_index(int G, int T, int c, int b) {
-    return (long long)(b & (G - 1)) * T + c;
+    return (long long)(b % G) * T + c;
 }
 long long ring_store_entries(int G, int qlen, int tlen) {
     (void)qlen;
@@ -350,17 +353,19 @@ __global__ void __launch_bounds__(64)
 scan_pairs_ring_kernel(const PairScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u64 s_dyn[];      // Peq words, then the target rings
-    constexpr int U = 64 / G;                                         // units per wave
-    constexpr bool LDSPEQ = PEQ == 1;
+    constexpr int U = 64 / G;                                         // units per wave (lanes past U * G idle)
     const int lane = threadIdx.x;
-    const int rl = lane & (G - 1), uw = lane / G;                     // lane within the ring, ring within the wave
+    const int rl = lane % G, uwRaw = lane / G;                        // lane within the ring, ring within the wave
+    const bool inRing = uwRaw < U;
+    const int uw = inRing ? uwRaw : U - 1;                            // idle lanes alias the last ring's LDS (reads only)
+    const int srcAddr = 4 * (lane - rl + (rl == 0 ? G - 1 : rl - 1));
     const int peqWords = PEQ == 1 ? a.sigmaT * 64 : (PEQ == 2 ? U * a.peqFullStride : 0);
     u64* s_peq = s_dyn + (PEQ == 2 ? uw * a.peqFullStride : 0);
-    unsigned char* s_tgt = reinterpret_cast<unsigned char*>(s_dyn + peqWords) + uw * 256;
-    const int unit = blockIdx.x * U + uw;
-    const bool have = unit < a.numUnits;
+    unsigned short* s_tgt = reinterpret_cast<unsigned short*>(s_dyn + peqWords) + uw * 256;
+    const int unit = blockIdx.x * U + uwRaw;
+    const bool have = inRing && unit < a.numUnits;
     const PairDesc* dp = a.descs + (have ? unit : 0);
-    // a whole-wave ring keeps its descriptor in SGPRs (38 instead of 70 VGPRs: one more wave per SIMD)
+    // a whole-wave ring keeps its descriptor in SGPRs
     auto uni = [](int v) { return G == 64 ? __builtin_amdgcn_readfirstlane(v) : v; };
     auto uni64 = [&](long long v) {
         return G == 64 ? (long long)(((u64)(u32)uni((int)((u64)v >> 32)) << 32) | (u32)uni((int)(u32)(u64)v)) : v;
@@ -390,51 +395,55 @@ scan_pairs_ring_kernel(const PairScanArgs a)
     const int lastRows = m - 64 * (nb - 1);                           // query rows in the last block
     const int nbA = active ? nb : 0;                                  // idle rings own no block
 
-    // ---- target ring: columns [0, loaded) are in s_tgt[col & 255]
+    // ---- target ring: the Peq row offsets of columns [0, loaded) are in s_tgt[col & 255]
+    // symbol -> byte offset of its Peq row as seen from the lane's base address (PEQ 0: the symbol itself)
+    const int rowStride = PEQ == 2 ? a.peqRowStride : 0;
+    const int symScale = PEQ == 1 ? 512 : (PEQ == 2 ? 8 * rowStride : 1);
     int loaded = 0;
     auto refill = [&]() {                                             // 64 more columns per ring
         const long long toff = toff_(); const int tstep = tstep_();
         for (int i = rl; i < 64; i += G) {
             const int c = loaded + i;
-            s_tgt[c & 255] = (c < T) ? a.tlut[a.tpool[toff + (long long)c * tstep]] : 0;
+            s_tgt[c & 255] = (unsigned short)((c < T) ? a.tlut[a.tpool[toff + (long long)c * tstep]] * symScale : 0);
         }
         loaded += 64;
     };
-    for (int i = rl; i < 256; i += G) s_tgt[i] = 0;                   // never index Peq with an unwritten slot
+    if (inRing) for (int i = rl; i < 256; i += G) s_tgt[i] = 0;       // never index Peq with an unwritten slot
     if (active) { refill(); refill(); refill(); }                     // 192 columns ahead of column 0
     // rows padded to a.peqRowStride words (a multiple of 32 for long queries): a ring's lanes, which hold
     // consecutive blocks, then hit distinct bank pairs whatever symbols they look up
-    const int rowStride = PEQ == 2 ? a.peqRowStride : 0;
     if (PEQ == 2 && active) {
         const long long peqOff = peqOff_();
         for (int sy = 0; sy < a.sigmaT; ++sy)
             for (int i = rl; i < nb; i += G) s_peq[sy * rowStride + i] = a.peq[peqOff + (long long)sy * nb + i];
     }
-    auto peq_word = [&](int sym, int blk) -> u64 {
-        if (PEQ == 2) return s_peq[sym * rowStride + blk];
-        if (PEQ == 1) return s_peq[sym * 64 + lane];
-        return a.peq[peqOff_() + (long long)sym * nb + blk];
+    int b = rl;                                                       // current (or next) block of this lane
+    // Peq word of the column whose row offset is `off`: one add from the lane's base
+    const char* peqBase = reinterpret_cast<const char*>(s_peq) + (PEQ == 1 ? 8 * lane : 0);
+    auto peq_word = [&](const int off) -> u64 {
+        if (PEQ == 2) return *reinterpret_cast<const u64*>(peqBase + off + 8 * b);
+        if (PEQ == 1) return *reinterpret_cast<const u64*>(peqBase + off);
+        return a.peq[peqOff_() + (long long)off * nb + b];
     };
 
-    // ---- per-lane block bookkeeping.  Block b is updated at steps t with t - tstart in [0, span]; its
-    // upstream block delivers deltas up to step upLastT (edlib.cpp:779: +1 per column once it left the band)
-    int b = rl;                                                       // current (or next) block of this lane
+    // ---- per-lane block bookkeeping.  Block b is updated at steps tstart .. tstart + span
     auto first_col = [&](int blk) { const int c = 64 * blk + dmin; return c < 0 ? 0 : c; };
     auto last_col = [&](int blk) { const int c = 64 * blk + 63 + dmax; return c > T - 1 ? T - 1 : c; };
-    int tstart, span, upLastT;
-    u32 topPos;                                                       // hin bit at the top of a block with no upstream
-    auto arm = [&]() {
+    const int never = 0x3fffffff;
+    int ev, span = 0;                                                 // steps until this lane's next event; life of its block
+    auto arm = [&](const int t) {                                     // countdown to the start of block b
         const bool ok = b < nbA && first_col(b) <= last_col(b);       // blocks below the band never get a column
-        tstart = ok ? first_col(b) + b : 0x7fffffff;
+        const int tstart = ok ? first_col(b) + b : never;
         span = ok ? last_col(b) + b - tstart : 0;
-        upLastT = (b > 0) ? last_col(b - 1) + b : -1;
-        topPos = (MODE == 2 && b == 0) ? 0u : 1u;                     // row -1: +1 per column, 0 for HW (edlib.cpp:584)
+        ev = ok ? tstart - t : never;
     };
-    arm();
+    arm(0);
+    u32 actm = 0u;                                                    // all ones while the lane is inside its block's life
+    u32 xmask = (b == 0) ? 0u : ~0u, xfix = (b == 0) ? ((MODE == 2) ? 0u : 1u) : 0u;   // what block 0 takes instead of x
 
     Block64 B{~0u, ~0u, 0u, 0u};
-    int bscore = 0, sc = 0, carry = 0;
-    int nsteps = active ? T + nb - 1 : 0;
+    int bscore = 0, sc = 0, carry = 1;
+    int nsteps = active ? T + nb : 0;                                 // one step past the last block's last: its closing event
     if constexpr (G == 64) nsteps = __builtin_amdgcn_readfirstlane(nsteps);
     else {                                          // the wave runs for its longest unit
         int w = 0;
@@ -442,89 +451,110 @@ scan_pairs_ring_kernel(const PairScanArgs a)
         for (int u = 0; u < U; ++u) { const int v = __builtin_amdgcn_readlane(nsteps, u * G); w = v > w ? v : w; }
         nsteps = w;
     }
+    int cidx = 0;                                                     // column of the NEXT row-offset fetch (col + 2)
 
-    // One step.  eqCur / symCur: Peq word of this step's column and symbol of the next column (fetched by
-    // the previous step); eqNxt / symNxt are fetched here for the next step -- the caller swaps the two
-    // register sets every step instead of moving them.
-    auto step = [&](const int t, u64& eqCur, u64& eqNxt, int& symCur, int& symNxt) {
-        const int x = ring_ror<G>(carry);
-        const int dt = t - tstart;
-        // upstream's bottom score travels only when some lane starts a block at this step
-        const bool starting = (dt == 0);
-        int upScore = 0;
-        if (__builtin_amdgcn_ballot_w64(starting) != 0ull) upScore = ring_ror<G>(bscore);
-        const int col = t - b;
-        if (starting) {
-            // (re)arm: Peq column of the new block, fresh "+1 per row" state (edlib.cpp:759-763, 803-808)
-            if (LDSPEQ) {
+    // The rare part of a step: some lane's block has just finished (its last update was step t - 1) or starts now.
+    auto events = [&](const int t, const int x, u64& eqCur, int& offCur) {
+        const int upScore = ring_ror<G>(bscore, srcAddr);             // upstream's bottom score after step t - 1
+        if (ev == 0 && actm) {                                        // ---- closing block b
+            const int colLast = t - 1 - b;
+            if (colLast == T - 1) {                                   // it was alive at the stop column
+                if (b == nb - 1) {
+                    if (MODE == 0) {
+                        // D[m][T] from the block's bottom score and the vertical deltas below row m-1 (edlib.cpp:914-917)
+                        const u64 P = ((u64)B.p1 << 32) | B.p0, M = ((u64)B.m1 << 32) | B.m0;
+                        const u64 below = (sh == 63u) ? 0ull : (~0ull << (sh + 1));
+                        a.outScore[unit] = bscore - __popcll(P & below) + __popcll(M & below);
+                        a.outCount[unit] = 1; a.outLast[unit] = T - 1;
+                    } else {
+                        a.outScore[unit] = cnt > 0 ? best : -1; a.outCount[unit] = cnt; a.outLast[unit] = lastCol;
+                    }
+                }
+                if (dumpCol) {                                        // stop column of a Hirschberg half
+                    const long long co = G == 64 ? colOffU : dp->colOff;
+                    if (co >= 0) {
+                        a.colP[co + b] = ((u64)B.p1 << 32) | B.p0; a.colM[co + b] = ((u64)B.m1 << 32) | B.m0;
+                        a.colS[co + b] = bscore;
+                    }
+                }
+            }
+            actm = 0u;
+            b += G;
+            xmask = ~0u; xfix = 0u;
+            arm(t);                                                   // ev == 0 again when block b + G starts right now
+        }
+        if (ev == 0 && !actm) {                                       // ---- block b starts with this step
+            const int col = t - b;
+            if (PEQ == 1) {
                 const long long peqOff = peqOff_();
                 for (int sy = 0; sy < a.sigmaT; ++sy) s_peq[sy * 64 + lane] = a.peq[peqOff + (long long)sy * nb + b];
             }
-            B = Block64{~0u, ~0u, 0u, 0u};
-            const int hp0 = x & 1, hn0 = (x >> 1) & 1;                // upstream's delta at column `col`
-            const int above = (col == 0) ? 64 * b : (upScore - (hp0 - hn0));   // bottom of the block above, column col-1
+            B = Block64{~0u, ~0u, 0u, 0u};                            // "+1 per row" (edlib.cpp:759-763, 803-808)
+            // bottom of the block above at column col - 1: upstream's bottom after its step minus its delta at `col`
+            // (a sender outside its block's life extrapolates by +1 per column, the value its receivers assume)
+            const int above = (col == 0) ? 64 * b : upScore - ((x & 1) - ((x >> 1) & 1));
             bscore = above + 64;
-            if (b == nb - 1) sc = above + lastRows;
-            const int s0 = s_tgt[col & 255];
-            eqCur = peq_word(s0, b);
-            symCur = s_tgt[(col + 1) & 255];
+            if (MODE != 0 && b == nb - 1) sc = above + lastRows;
+            eqCur = peq_word(s_tgt[col & 255]);
+            offCur = s_tgt[(col + 1) & 255];
+            cidx = col + 2;
+            actm = ~0u;
+            ev = span + 1;                                            // closes at the top of the step after its last
         }
-        u32 hp = 0, hn = 0;
-        if ((u32)dt <= (u32)span) {
-            eqNxt = peq_word(symCur, b);
-            symNxt = s_tgt[(col + 2) & 255];
-            const bool fromUp = t <= upLastT;
-            const u32 hpos = fromUp ? ((u32)x & 1u) : topPos;
-            const u32 hneg = fromUp ? (((u32)x >> 1) & 1u) : 0u;
-            u32 ph0, ph1, mh0, mh1;
-            advance_block64(B, (u32)eqCur, (u32)(eqCur >> 32), hpos, hneg, ph0, ph1, mh0, mh1);
-            hp = ph1 >> 31; hn = mh1 >> 31;
-            bscore += (int)hp - (int)hn;
-            if (STORE) {
-                a.store[storeOff + (long long)rl * T + col] =
-                    StoreEntry{((u64)B.p1 << 32) | B.p0, ((u64)B.m1 << 32) | B.m0, bscore, {0, 0, 0}};
-            }
-            if (b == nb - 1) {
-                const u64 ph = ((u64)ph1 << 32) | ph0, mh = ((u64)mh1 << 32) | mh0;
-                sc += (int)((ph >> sh) & 1ull) - (int)((mh >> sh) & 1ull);
-                if (MODE == 0) {
-                    if (col == T - 1) { a.outScore[unit] = sc; a.outCount[unit] = 1; a.outLast[unit] = T - 1; }
-                } else {
+    };
+
+    // One step.  eqCur / offCur: Peq word of this step's column and row offset of the next column (fetched by
+    // the previous step); eqNxt / offNxt are fetched here for the next step -- the caller swaps the two
+    // register sets every step instead of moving them.
+    auto step = [&](const int t, u64& eqCur, u64& eqNxt, int& offCur, int& offNxt) {
+        const int x = ring_ror<G>(carry, srcAddr);
+        if (__builtin_amdgcn_ballot_w64(ev == 0) != 0ull) events(t, x, eqCur, offCur);
+        --ev;
+        eqNxt = peq_word(offCur);
+        offNxt = s_tgt[cidx & 255];
+        ++cidx;
+        u32 ph0, ph1, mh0, mh1;
+        // block 0 takes row -1 (+1 per column, 0 for HW: edlib.cpp:584, 779) whatever its ring neighbour sends (in a
+        // ring that holds all blocks of its unit the last block's lane feeds lane 0); every other block takes what
+        // arrives: its upstream's delta, or the +1 a sender outside its block's life emits
+        const u32 xx = __builtin_amdgcn_bitop3_b32((u32)x, xmask, xfix, 0xea /* (a & b) | c */);
+        advance_block64(B, (u32)eqCur, (u32)(eqCur >> 32), xx & 1u, xx >> 1, ph0, ph1, mh0, mh1);
+        const u32 hp = ph1 >> 31, hn = mh1 >> 31;
+        // carry and block score of a lane outside its block's life: +1 per step
+        carry = (int)__builtin_amdgcn_bitop3_b32(hp | (hn << 1), 1u, actm, 0xe4 /* c ? a : b */);
+        bscore += (int)__builtin_amdgcn_bitop3_b32(hp - hn, 1u, actm, 0xe4);
+        if (STORE || MODE != 0) {
+            if (actm) {
+                const int col = t - b;
+                if (STORE) {
+                    a.store[storeOff + (long long)rl * T + col] =
+                        StoreEntry{((u64)B.p1 << 32) | B.p0, ((u64)B.m1 << 32) | B.m0, bscore, {0, 0, 0}};
+                }
+                if (MODE != 0 && b == nb - 1) {
+                    const u64 ph = ((u64)ph1 << 32) | ph0, mh = ((u64)mh1 << 32) | mh0;
+                    sc += (int)((ph >> sh) & 1ull) - (int)((mh >> sh) & 1ull);
                     if (sc <= best) {                                 // edlib.cpp:658-673
                         if (sc < best) { best = sc; cnt = 0; }
                         if (cnt < dp->posCap) a.posPool[dp->posOff + cnt] = col;
                         ++cnt;
                         lastCol = col;
                     }
-                    if (col == T - 1) { a.outScore[unit] = cnt > 0 ? best : -1; a.outCount[unit] = cnt; a.outLast[unit] = lastCol; }
                 }
             }
-            if (dumpCol && col == T - 1) {                            // stop column of a Hirschberg half
-                const long long co = G == 64 ? colOffU : dp->colOff;
-                if (co >= 0) {
-                    a.colP[co + b] = ((u64)B.p1 << 32) | B.p0; a.colM[co + b] = ((u64)B.m1 << 32) | B.m0;
-                    a.colS[co + b] = bscore;
-                }
-            }
-        }
-        carry = (int)(hp | (hn << 1));
-        if (dt >= span && b < nbA) {                                  // block done: re-arm this lane for block b + G
-            b += G;
-            arm();
         }
     };
 
     u64 eqA = 0, eqB = 0;
-    int symA = 0, symB = 0;
-    for (int t = 0; t < nsteps; t += 2) {
+    int offA = 0, offB = 0;
+    for (int t = 0; t <= nsteps; t += 2) {
         if ((t & 63) == 0) {                                          // pace the ring by the largest column in use
             int bt = t - 63 - dmax; bt = bt <= 0 ? 0 : (bt + 64) / 65;
             if (t - T + 1 > bt) bt = t - T + 1;
             const int jmax = t - bt;
             while (active && loaded < T && loaded < jmax + 64 + 67) refill();
         }
-        step(t, eqA, eqB, symA, symB);
-        if (t + 1 < nsteps) step(t + 1, eqB, eqA, symB, symA);
+        step(t, eqA, eqB, offA, offB);
+        step(t + 1, eqB, eqA, offB, offA);
     }
 }
 
@@ -534,15 +564,16 @@ static hipError_t launch_scan_pairs_ring_t(const PairScanArgs& a, hipStream_t st
     constexpr int U = 64 / G;
     const dim3 grid((a.numUnits + U - 1) / U);
     const size_t full = (size_t)U * a.peqFullStride * sizeof(u64);
+    const size_t tgt = 512 * U;                                       // 256 row offsets (u16) per unit
     // the whole-Peq mode saves the refills of packed rings, but only pays while LDS does not cap the
-    // occupancy (measured: 10 KB per wave costs config 4 a third of its rate)
-    if (G < 64 && a.peqFullStride > 0 && full + 256 * U <= 8192) {
-        hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 2>), grid, dim3(64), full + 256 * U, stream, a);
+    // occupancy (measured: 10 KB per wave costs config 4 a third of its rate); row offsets are 16 bits
+    if (G < 64 && a.peqFullStride > 0 && full + tgt <= 8192 && 8LL * a.peqRowStride * a.sigmaT < 65536) {
+        hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 2>), grid, dim3(64), full + tgt, stream, a);
     } else if (a.sigmaT <= 32) {
-        const size_t lds = (size_t)a.sigmaT * 64 * sizeof(u64) + 256 * U;
+        const size_t lds = (size_t)a.sigmaT * 64 * sizeof(u64) + tgt;
         hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 1>), grid, dim3(64), lds, stream, a);
     } else {
-        hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 0>), grid, dim3(64), 256 * U, stream, a);
+        hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 0>), grid, dim3(64), tgt, stream, a);
     }
     return hipGetLastError();
 }
@@ -550,16 +581,20 @@ static hipError_t launch_scan_pairs_ring_t(const PairScanArgs& a, hipStream_t st
 hipError_t launch_scan_pairs_ring(int G, int mode, bool store, const PairScanArgs& a, hipStream_t stream)
 {
     if (a.numUnits == 0) return hipSuccess;
-    if (mode != 0 && (store || G >= 32)) return hipErrorInvalidValue;   // semi-global rings: 4 or 16 lanes, distance only
+    if (mode != 0 && (store || (G != 4 && G != 16))) return hipErrorInvalidValue;   // semi-global rings: 4 or 16 lanes, distance only
     switch (G * 8 + mode * 2 + (store ? 1 : 0)) {
         case 32: return launch_scan_pairs_ring_t<4, 0, false>(a, stream);
         case 33: return launch_scan_pairs_ring_t<4, 0, true>(a, stream);
         case 34: return launch_scan_pairs_ring_t<4, 1, false>(a, stream);
         case 36: return launch_scan_pairs_ring_t<4, 2, false>(a, stream);
+        case 64: return launch_scan_pairs_ring_t<8, 0, false>(a, stream);
+        case 65: return launch_scan_pairs_ring_t<8, 0, true>(a, stream);
         case 128: return launch_scan_pairs_ring_t<16, 0, false>(a, stream);
         case 129: return launch_scan_pairs_ring_t<16, 0, true>(a, stream);
         case 130: return launch_scan_pairs_ring_t<16, 1, false>(a, stream);
         case 132: return launch_scan_pairs_ring_t<16, 2, false>(a, stream);
+        case 168: return launch_scan_pairs_ring_t<21, 0, false>(a, stream);
+        case 169: return launch_scan_pairs_ring_t<21, 0, true>(a, stream);
         case 256: return launch_scan_pairs_ring_t<32, 0, false>(a, stream);
         case 257: return launch_scan_pairs_ring_t<32, 0, true>(a, stream);
         case 512: return launch_scan_pairs_ring_t<64, 0, false>(a, stream);

@@ -68,11 +68,12 @@ hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStr
 
 // NW with Ukkonen's diagonal band for threshold desc.kinit (reference myersCalcEditDistanceNW with a
 // fixed k, edlib.cpp:730-928): exact whenever the distance is <= kinit, otherwise some value > kinit.
-// ringLanes G in {4, 16, 32, 64}: the band must fit the ring (kinit <= ring_max_k(G), or numBlocks <= G and any
+// ringLanes G in {4, 8, 16, 21, 32, 64}: the band must fit the ring (kinit <= ring_max_k(G), or numBlocks <= G and any
 // kinit); a wave carries 64 / G units, whatever the query length (no strips).  Writes outScore and, when
 // colP is set, the (P, M, score) of the blocks alive at the last processed column (the caller pre-fills
 // the dump with "invalid").  store: also the column store in ring layout (ring_store_entries per unit).
 constexpr int ring_max_k(int G) { return 64 * G - 128; }
+constexpr int kNumRings = 6;           // ring sizes 4, 8, 16, 21, 32, 64 (units per wave: 16, 8, 4, 3, 2, 1)
 constexpr int kMaxBandK = ring_max_k(64);
 // mode 1 (SHW) / 2 (HW): packed rings only (ringLanes 4 or 16), every unit must have numBlocks <= ringLanes;
 // no band, kinit is the end-location threshold, outputs as launch_scan_pairs.

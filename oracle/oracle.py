@@ -185,6 +185,29 @@ def physical_cores():
     return int(_pool().ref_pool_physical_cores())
 
 
+def cpu_quota():
+    """CPUs this process may actually use: the cgroup CPU quota (cpu.max / cfs_quota_us) when there is one,
+    capped by the affinity mask.  The GPU boxes show 256 logical CPUs behind a 16-CPU quota: 256 threads then
+    run at 1/16 speed each and measure the throttle, not the reference."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if a != "max":
+            quota = float(a) / float(b)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def checker_library():
     """(path, kind) of the CPU implementation the pool should drive: the compiled reference where it
     travelled ("reference"), else the C99 restatement ("port")."""
