@@ -52,12 +52,16 @@ struct DevBuf {
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
+    bool owned = true;       // false: a view into another DevBuf's block (alias())
     ~DevBuf() { release(); }
-    void release() { if (p) { pool_free(p, granted); p = nullptr; n = 0; granted = 0; } }
+    void release() { if (p && owned) pool_free(p, granted); p = nullptr; n = 0; granted = 0; owned = true; }
+    // view of `count` elements inside a block somebody else owns (and outlives this view)
+    void alias(void* ptr, size_t count) { release(); p = static_cast<T*>(ptr); n = count; owned = false; }
     hipError_t alloc(size_t count) {
         release();
         if (count == 0) count = 1;
         n = count;
+        owned = true;
         return pool_alloc(reinterpret_cast<void**>(&p), count * sizeof(T), &granted);
     }
     // grow-only

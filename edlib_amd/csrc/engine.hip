@@ -181,6 +181,17 @@ int default_device() {
 
 // ------------------------------------------------------------------- tables
 
+// byte x byte equality matrix of EqualityDefinition (edlib.cpp:63-94); only built when there are additional
+// equalities (the kernels take "no matrix" as the identity)
+static void build_eq8(std::vector<uint8_t>& eq8, const EdlibEqualityPair* eqs, int neq) {
+    eq8.assign(256 * 256, 0);
+    for (int a = 0; a < 256; ++a) eq8[a * 256 + a] = 1;
+    for (int i = 0; i < neq; ++i) {
+        const int a = (uint8_t)eqs[i].first, b = (uint8_t)eqs[i].second;
+        eq8[a * 256 + b] = eq8[b * 256 + a] = 1;
+    }
+}
+
 static void build_tables(Tables& tab, const uint8_t* targets, long long totalTargetBytes,
                          const EdlibEqualityPair* eqs, int neq) {
     memset(tab.presence, 0, sizeof tab.presence);
@@ -201,17 +212,13 @@ static void build_tables(Tables& tab, const uint8_t* targets, long long totalTar
     // EqualityDefinition (edlib.cpp:63-94) on raw bytes.  The reference keeps a pair only
     // when both characters occur in that call's alphabet; a pair whose characters do not
     // occur can never be consulted, so the byte-level relation gives identical DP matrices.
-    tab.eq8.assign(256 * 256, 0);
-    for (int a = 0; a < 256; ++a) tab.eq8[a * 256 + a] = 1;
-    for (int i = 0; i < neq; ++i) {
-        const int a = (uint8_t)eqs[i].first, b = (uint8_t)eqs[i].second;
-        tab.eq8[a * 256 + b] = tab.eq8[b * 256 + a] = 1;
-    }
+    tab.eq8.clear();
+    if (neq > 0) build_eq8(tab.eq8, eqs, neq);
     for (int q = 0; q < 256; ++q) {
-        uint8_t mask = 0;
-        for (int s = 0; s < tab.sigmaT && s < 4; ++s)
-            if (tab.eq8[q * 256 + tab.idToByte[s]]) mask |= (uint8_t)(1u << s);
-        tab.eqtbl4[q] = mask;
+        uint16_t mask = 0;
+        for (int s = 0; s < tab.sigmaT && s < 16; ++s)
+            if (tab.eq8.empty() ? (q == tab.idToByte[s]) : (tab.eq8[q * 256 + tab.idToByte[s]] != 0)) mask |= (uint16_t)(1u << s);
+        tab.eqtbl[q] = mask;
     }
 }
 
@@ -326,30 +333,51 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
     EDLIB_AMD_HIP(pool_stream(&stream_));
     EDLIB_AMD_HIP(evRun0_.create()); EDLIB_AMD_HIP(evRun1_.create());
 
-    // resident inputs (pools are rebased to offset 0)
+    // resident inputs (pools are rebased to offset 0).  Offsets and the small tables -- and, for small batches,
+    // the sequences themselves -- go up as ONE block through pinned staging with one asynchronous copy: a call
+    // of edlibAlign() is a batch of one, and nine blocking hipMemcpy calls from pageable memory were most of
+    // what it cost.  Large pools are copied straight from the caller's memory.
     const long long qb = qoff_[0], tb = toff_[0];
     for (auto& v : qoff_) v -= qb;
     for (auto& v : toff_) v -= tb;
-    EDLIB_AMD_HIP(d_qpool_.alloc((size_t)qbytes + 16));
-    EDLIB_AMD_HIP(d_tpool_.alloc((size_t)tbytes + 16));
-    EDLIB_AMD_HIP(d_qoff_.alloc(qoff_.size()));
-    EDLIB_AMD_HIP(d_toff_.alloc(toff_.size()));
-    EDLIB_AMD_HIP(d_tlut_.alloc(256)); EDLIB_AMD_HIP(d_idToByte_.alloc(256));
-    EDLIB_AMD_HIP(d_eq8_.alloc(65536)); EDLIB_AMD_HIP(d_eqtbl4_.alloc(256));
-    EDLIB_AMD_HIP(d_presence_.alloc(8));
-    if (qbytes) EDLIB_AMD_HIP(hipMemcpy(d_qpool_.p, queries + qb, (size_t)qbytes, hipMemcpyHostToDevice));
-    if (tbytes) EDLIB_AMD_HIP(hipMemcpy(d_tpool_.p, targets + tb, (size_t)tbytes, hipMemcpyHostToDevice));
-    EDLIB_AMD_HIP(hipMemcpy(d_qoff_.p, qoff_.data(), qoff_.size() * sizeof(long long), hipMemcpyHostToDevice));
-    EDLIB_AMD_HIP(hipMemcpy(d_toff_.p, toff_.data(), toff_.size() * sizeof(long long), hipMemcpyHostToDevice));
-    EDLIB_AMD_HIP(hipMemcpy(d_tlut_.p, tab_.tlut, 256, hipMemcpyHostToDevice));
-    EDLIB_AMD_HIP(hipMemcpy(d_idToByte_.p, tab_.idToByte, 256, hipMemcpyHostToDevice));
-    EDLIB_AMD_HIP(hipMemcpy(d_eq8_.p, tab_.eq8.data(), 65536, hipMemcpyHostToDevice));
-    EDLIB_AMD_HIP(hipMemcpy(d_eqtbl4_.p, tab_.eqtbl4, 256, hipMemcpyHostToDevice));
-    EDLIB_AMD_HIP(hipMemcpy(d_presence_.p, tab_.presence, 32, hipMemcpyHostToDevice));
+    {
+        const bool inlinePools = qbytes + tbytes <= (1 << 20);
+        size_t at = 0;
+        auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 15) & ~(size_t)15; return o; };
+        const size_t oQoff = take(qoff_.size() * sizeof(long long)), oToff = take(toff_.size() * sizeof(long long));
+        const size_t oTlut = take(256), oId = take(256), oEq4 = take(512), oPres = take(32);
+        const size_t oQ = inlinePools ? take((size_t)qbytes + 16) : 0, oT = inlinePools ? take((size_t)tbytes + 16) : 0;
+        EDLIB_AMD_HIP(d_in_.alloc(at));
+        EDLIB_AMD_HIP(h_in_.alloc(at));
+        uint8_t* h = h_in_.p;
+        memcpy(h + oQoff, qoff_.data(), qoff_.size() * sizeof(long long));
+        memcpy(h + oToff, toff_.data(), toff_.size() * sizeof(long long));
+        memcpy(h + oTlut, tab_.tlut, 256); memcpy(h + oId, tab_.idToByte, 256);
+        memcpy(h + oEq4, tab_.eqtbl, 512); memcpy(h + oPres, tab_.presence, 32);
+        d_qoff_.alias(d_in_.p + oQoff, qoff_.size()); d_toff_.alias(d_in_.p + oToff, toff_.size());
+        d_tlut_.alias(d_in_.p + oTlut, 256); d_idToByte_.alias(d_in_.p + oId, 256);
+        d_eqtbl_.alias(d_in_.p + oEq4, 256); d_presence_.alias(d_in_.p + oPres, 8);
+        if (inlinePools) {
+            if (qbytes) memcpy(h + oQ, queries + qb, (size_t)qbytes);
+            if (tbytes) memcpy(h + oT, targets + tb, (size_t)tbytes);
+            memset(h + oQ + qbytes, 0, 16); memset(h + oT + tbytes, 0, 16);
+            d_qpool_.alias(d_in_.p + oQ, (size_t)qbytes + 16); d_tpool_.alias(d_in_.p + oT, (size_t)tbytes + 16);
+        } else {
+            EDLIB_AMD_HIP(d_qpool_.alloc((size_t)qbytes + 16));
+            EDLIB_AMD_HIP(d_tpool_.alloc((size_t)tbytes + 16));
+            if (qbytes) EDLIB_AMD_HIP(hipMemcpy(d_qpool_.p, queries + qb, (size_t)qbytes, hipMemcpyHostToDevice));
+            if (tbytes) EDLIB_AMD_HIP(hipMemcpy(d_tpool_.p, targets + tb, (size_t)tbytes, hipMemcpyHostToDevice));
+        }
+        EDLIB_AMD_HIP(hipMemcpyAsync(d_in_.p, h, at, hipMemcpyHostToDevice, stream_));
+    }
 
     // classification of the units for phase 1
     const int mode = (int)cfg_.mode;
-    const bool readsOk = shared_ && tab_.sigmaT <= 4 && tlen(0) > 0;
+    // reads-per-lane kernels: a shared target with at most 4 distinct bytes (every mode), or up to 16 in HW mode
+    // (the banded kernel keeps 8 or 16 Peq rows per word in LDS: genomes with N, soft-masked lower case, IUPAC codes)
+    const int modeIn = (int)cfg.mode;
+    const bool readsOk = shared_ && tlen(0) > 0 && (tab_.sigmaT <= 4 || (tab_.sigmaT <= 16 && modeIn == EDLIB_MODE_HW));
+    syms_ = tab_.sigmaT <= 4 ? 4 : (tab_.sigmaT <= 8 ? 8 : 16);
     std::vector<std::vector<int>> byWords(kMaxReadWords + 1);
     for (int u = 0; u < n; ++u) {
         const int m = qlen(u), T = tlen(u);
@@ -386,7 +414,7 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
         EDLIB_AMD_HIP(hipMemcpy(g->d_perm.p, g->perm.data(), ns * sizeof(int), hipMemcpyHostToDevice));
         EDLIB_AMD_HIP(g->d_qlen.alloc(ns)); EDLIB_AMD_HIP(g->d_kinit.alloc(ns));
         EDLIB_AMD_HIP(g->d_alphaExtra.alloc(ns));
-        EDLIB_AMD_HIP(g->d_peq.alloc(ns * 4 * w));
+        EDLIB_AMD_HIP(g->d_peq.alloc(ns * (size_t)syms_ * w));
         EDLIB_AMD_HIP(g->d_segBest.alloc(ns * S)); EDLIB_AMD_HIP(g->d_segCnt.alloc(ns * S));
         EDLIB_AMD_HIP(g->d_segPos.alloc(ns * S * 8));
         EDLIB_AMD_HIP(g->d_best.alloc(ns)); EDLIB_AMD_HIP(g->d_total.alloc(ns));
@@ -402,9 +430,17 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
     }
     {
         const char* env = getenv("EDLIB_AMD_BAND");
-        banded_ = (mode == EDLIB_MODE_HW) && !(env && env[0] == '0');
+        banded_ = (mode == EDLIB_MODE_HW) && (!(env && env[0] == '0') || syms_ > 4);   // more than 4 symbols: banded kernel only
     }
     return 0;
+}
+
+// the 64 KB equality matrix goes up only when a pair kernel needs it and there are additional equalities
+hipError_t Batch::uploadEq8() {
+    if (tab_.eq8.empty() || d_eq8_.p) return hipSuccess;
+    hipError_t e = d_eq8_.alloc(65536);
+    if (e != hipSuccess) return e;
+    return hipMemcpyAsync(d_eq8_.p, tab_.eq8.data(), 65536, hipMemcpyHostToDevice, stream_);
 }
 
 // ------------------------------------------------------------- scan timing
@@ -475,7 +511,7 @@ int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, i
                 g.nwords, mode, nlanes, numSegments, segLen, warm, cap, kcap, (const void*)d_slotmap, (const void*)posOff);
     }
     scanTimerStart();
-    if (banded_ && mode == EDLIB_MODE_HW && !unbanded) EDLIB_AMD_HIP(launch_scan_reads_banded(g.nwords, a, stream_));
+    if (banded_ && mode == EDLIB_MODE_HW && (!unbanded || syms_ > 4)) EDLIB_AMD_HIP(launch_scan_reads_banded(g.nwords, syms_, a, stream_));
     else {
         EDLIB_AMD_HIP(launch_scan_reads(g.nwords, mode, a, stream_));
         stats.word_steps += (long long)((nlanes + 63) / 64 * 64) * g.nwords *
@@ -514,12 +550,12 @@ int Batch::runReads()
     const int kNoCap = 0x3fffffff;
     stats.path |= 1;
     EDLIB_AMD_HIP(hipMemsetAsync(d_wordSteps_.p, 0, sizeof(unsigned long long), stream_));
-    EDLIB_AMD_HIP(launch_pack_target_2bit(d_tpool_.p, d_tlut_.p, T, d_tpk_.p, stream_));
+    if (syms_ == 4) EDLIB_AMD_HIP(launch_pack_target_2bit(d_tpool_.p, d_tlut_.p, T, d_tpk_.p, stream_));
     if (banded) EDLIB_AMD_HIP(launch_pack_target_rows(d_tpool_.p, d_tlut_.p, T, d_trows_.p, (int)d_trows_.n, stream_));
     for (auto& gp : groups_) {
         ReadGroup& g = *gp;
-        EDLIB_AMD_HIP(launch_build_peq_reads(g.nwords, d_qpool_.p, d_qoff_.p, g.d_perm.p, g.nslots,
-                                             d_eqtbl4_.p, d_presence_.p, cfg_.k, g.d_peq.p, g.d_qlen.p,
+        EDLIB_AMD_HIP(launch_build_peq_reads(g.nwords, syms_, d_qpool_.p, d_qoff_.p, g.d_perm.p, g.nslots,
+                                             d_eqtbl_.p, d_presence_.p, cfg_.k, g.d_peq.p, g.d_qlen.p,
                                              g.d_kinit.p, g.d_alphaExtra.p, stream_));
         // ---- pass 1: all slots; banded: threshold min(k, kFirst)
         int kFirst = kFirstMax;
@@ -613,7 +649,7 @@ int Batch::runReads()
                     EDLIB_AMD_HIP(hipMemcpyAsync(&ws, d_ws.p, sizeof ws, hipMemcpyDeviceToHost, stream_));
                     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
                     const double cols = (double)np2 * ((double)T + (double)(S3 - 1) * warm3);
-                    plain = (double)ws >= 0.85 * g.nwords * cols;
+                    plain = syms_ == 4 && (double)ws >= 0.85 * g.nwords * cols;
                     stats.word_steps += (long long)ws;
                 }
                 if (scanGroup(g, mode, d_map.p, (int)no, kNoCap, g.d_kinit.p, S2, segLen2, warm2,
@@ -796,7 +832,9 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     EDLIB_AMD_HIP(d_descs_.ensure(n));
     EDLIB_AMD_HIP(d_peq64_.ensure((size_t)peqWords));
     EDLIB_AMD_HIP(d_aux_.ensure((size_t)auxInts));
-    EDLIB_AMD_HIP(d_outScore_.ensure(n)); EDLIB_AMD_HIP(d_outCount_.ensure(n)); EDLIB_AMD_HIP(d_outLast_.ensure(n));
+    // score / count / last of the chunk side by side: one copy brings all three back
+    EDLIB_AMD_HIP(d_out3_.ensure(3 * n));
+    d_outScore_.alias(d_out3_.p, n); d_outCount_.alias(d_out3_.p + n, n); d_outLast_.alias(d_out3_.p + 2 * n, n);
     EDLIB_AMD_HIP(d_posPool_.ensure(n * kPosCap));
     if (wantPath) {
         EDLIB_AMD_HIP(d_store_.ensure((size_t)storeEntries));
@@ -805,6 +843,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         EDLIB_AMD_HIP(hipMemcpyAsync(d_opsOff_.p, opsOff.data(), (n + 1) * sizeof(long long), hipMemcpyHostToDevice, stream_));
     }
     EDLIB_AMD_HIP(hipMemcpyAsync(d_descs_.p, descs, n * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
+    EDLIB_AMD_HIP(uploadEq8());
     EDLIB_AMD_HIP(launch_build_peq_pairs(d_descs_.p, (int)n, d_qpool_.p, d_eq8_.p, d_idToByte_.p, tab_.sigmaT,
                                          d_peq64_.p, stream_));
     lap("chunk: descs+alloc");
@@ -829,11 +868,10 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         EDLIB_AMD_HIP(launch_traceback(tb, stream_));
     }
     if (lap.on) { EDLIB_AMD_HIP(hipStreamSynchronize(stream_)); lap("chunk: kernels"); }
-    std::vector<int> score(n), count(n), last(n), pool, opsLen;
+    std::vector<int> out3(3 * n), pool, opsLen;
+    const int* score = out3.data(); const int* count = score + n; const int* last = count + n;
     std::shared_ptr<PinBuf> ops;
-    EDLIB_AMD_HIP(hipMemcpyAsync(score.data(), d_outScore_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    EDLIB_AMD_HIP(hipMemcpyAsync(count.data(), d_outCount_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    EDLIB_AMD_HIP(hipMemcpyAsync(last.data(), d_outLast_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    EDLIB_AMD_HIP(hipMemcpyAsync(out3.data(), d_out3_.p, 3 * n * sizeof(int), hipMemcpyDeviceToHost, stream_));
     if (wantPositions) {
         pool.resize(n * kPosCap);
         EDLIB_AMD_HIP(hipMemcpyAsync(pool.data(), d_posPool_.p, n * kPosCap * sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -909,6 +947,25 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
 int Batch::alphabetLengths(const std::vector<int>& units, std::vector<UnitResult>& res)
 {
     if (units.empty()) return 0;
+    {   // a handful of short sequences (edlibAlign() on a pair): counting distinct bytes on the host costs less than
+        // a launch and a round trip; the sequences are still in the staging block of init()
+        long long total = 0;
+        for (int u : units) total += qlen(u) + (shared_ ? 0 : tlen(u));
+        if (h_in_.p && d_qpool_.p && !d_qpool_.owned && total <= 65536) {
+            const uint8_t* hq = h_in_.p + (d_qpool_.p - d_in_.p);
+            const uint8_t* ht = h_in_.p + (d_tpool_.p - d_in_.p);
+            for (int u : units) {
+                bool seen[256] = {false};
+                int cnt = 0;
+                auto add = [&](const uint8_t* p, long long len) { for (long long i = 0; i < len; ++i) if (!seen[p[i]]) { seen[p[i]] = true; ++cnt; } };
+                add(hq + qoff_[u], qlen(u));
+                if (!shared_) add(ht + toff_[u], tlen(u));
+                else for (int b = 0; b < 256; ++b) if ((tab_.presence[b >> 5] >> (b & 31)) & 1u) { if (!seen[b]) { seen[b] = true; ++cnt; } }
+                res[u].alphabetLength = cnt;
+            }
+            return 0;
+        }
+    }
     DevBuf<int> d_idx, d_out;
     EDLIB_AMD_HIP(d_idx.alloc(units.size())); EDLIB_AMD_HIP(d_out.alloc(units.size()));
     EDLIB_AMD_HIP(hipMemcpyAsync(d_idx.p, units.data(), units.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
@@ -986,10 +1043,12 @@ int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& spli
     EDLIB_AMD_HIP(hipMemsetAsync(colM.p, 0, (size_t)colBlocks * 8, stream_));
     EDLIB_AMD_HIP(hipMemsetAsync(colS.p, 0x3f, (size_t)colBlocks * 4, stream_));
     EDLIB_AMD_HIP(d_descs_.ensure(n)); EDLIB_AMD_HIP(d_peq64_.ensure((size_t)peqWords)); EDLIB_AMD_HIP(d_aux_.ensure((size_t)auxInts));
-    EDLIB_AMD_HIP(d_outScore_.ensure(n)); EDLIB_AMD_HIP(d_outCount_.ensure(n)); EDLIB_AMD_HIP(d_outLast_.ensure(n));
+    EDLIB_AMD_HIP(d_out3_.ensure(3 * n));
+    d_outScore_.alias(d_out3_.p, n); d_outCount_.alias(d_out3_.p + n, n); d_outLast_.alias(d_out3_.p + 2 * n, n);
     EDLIB_AMD_HIP(d_posPool_.ensure(1));
     EDLIB_AMD_HIP(hipMemcpyAsync(d_descs_.p, descs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
     EDLIB_AMD_HIP(hipMemcpyAsync(d_best.p, best.data(), np * sizeof(int), hipMemcpyHostToDevice, stream_));
+    EDLIB_AMD_HIP(uploadEq8());
     EDLIB_AMD_HIP(launch_build_peq_pairs(d_descs_.p, (int)n, d_qpool_.p, d_eq8_.p, d_idToByte_.p, tab_.sigmaT,
                                          d_peq64_.p, stream_));
     PairScanArgs a{};

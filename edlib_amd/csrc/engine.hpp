@@ -20,8 +20,8 @@ struct Tables {
     uint8_t idToByte[256];    // symbol id -> byte
     int sigmaT = 0;           // number of distinct target bytes
     uint32_t presence[8];     // bitset of the target bytes
-    uint8_t eqtbl4[256];      // query byte -> 4-bit set of target symbols it equals (sigmaT <= 4)
-    std::vector<uint8_t> eq8; // [256*256] eq8[q*256+t] = 1 if bytes q and t are equal
+    uint16_t eqtbl[256];      // query byte -> 16-bit set of the (first 16) target symbols it equals
+    std::vector<uint8_t> eq8; // [256*256] eq8[q*256+t] = 1 if bytes q and t are equal; EMPTY = identity
 };
 
 // A unit handed to the block-per-lane kernels (host mirror of PairDesc).
@@ -87,7 +87,11 @@ private:
     Event evRun0_, evRun1_, evA_, evB_;
 
     // ---- resident inputs
-    DevBuf<uint8_t> d_qpool_, d_tpool_, d_tlut_, d_idToByte_, d_eq8_, d_eqtbl4_;
+    DevBuf<uint8_t> d_in_;                       // offsets + small tables (+ small sequence pools) in one block
+    PinBuf h_in_;                                // its pinned staging (kept until the batch dies: the copy is asynchronous)
+    DevBuf<uint8_t> d_qpool_, d_tpool_, d_tlut_, d_idToByte_, d_eq8_;
+    DevBuf<uint16_t> d_eqtbl_;   // views into d_in_ unless large
+    hipError_t uploadEq8();
     DevBuf<uint32_t> d_presence_;
     DevBuf<long long> d_qoff_, d_toff_;
 
@@ -108,6 +112,7 @@ private:
     DevBuf<uint32_t> d_tpk_, d_trows_;
     DevBuf<unsigned long long> d_wordSteps_;
     bool banded_ = false;        // HW groups use the Ukkonen-banded kernel with k-doubling
+    int syms_ = 4;               // Peq rows per word of the reads kernels: target symbols rounded up to 4, 8 or 16
     int runReads();                                   // device work only; results stay in HBM
     int collectReads(std::vector<UnitResult>& res);   // D2H + result semantics (lazy for TASK_DISTANCE)
     bool readsCollected_ = true;
@@ -120,7 +125,7 @@ private:
     DevBuf<PairDesc> d_descs_;
     DevBuf<unsigned long long> d_peq64_;
     DevBuf<StoreEntry> d_store_;
-    DevBuf<int> d_aux_, d_outScore_, d_outCount_, d_outLast_, d_posPool_, d_opsLen_, d_alpha_;
+    DevBuf<int> d_aux_, d_out3_, d_outScore_, d_outCount_, d_outLast_, d_posPool_, d_opsLen_, d_alpha_;   // d_out{Score,Count,Last}_: views into d_out3_
     DevBuf<uint8_t> d_ops_;
     DevBuf<long long> d_opsOff_;
     // ring = 0: unbanded strips (any mode).  ring = 4 / 16 / 64: NW inside Ukkonen's band for threshold

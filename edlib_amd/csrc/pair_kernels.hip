@@ -77,7 +77,10 @@ build_peq_pairs_kernel(const PairDesc* __restrict__ descs, const uint8_t* __rest
         __syncthreads();
         {
             u32 mk = 0;
-            for (int sy = 0; sy < ns; ++sy) mk |= (u32)(eq8[threadIdx.x * 256 + idToByte[g0 + sy]] & 1) << sy;
+            for (int sy = 0; sy < ns; ++sy) {
+                const u32 tb = idToByte[g0 + sy];
+                mk |= (u32)(eq8 ? (eq8[threadIdx.x * 256 + tb] & 1) : (tb == threadIdx.x)) << sy;      // no matrix: identity
+            }
             s_mask[threadIdx.x] = mk;
         }
         __syncthreads();

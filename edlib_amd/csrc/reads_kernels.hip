@@ -74,7 +74,7 @@ pack_target_rows_kernel(const uint8_t* __restrict__ raw, const uint8_t* __restri
     const int w = blockIdx.x * blockDim.x + threadIdx.x;               // dword = 2 columns
     if (w >= ndwords) return;
     const int c = 2 * w;
-    const u32 a0 = c < T ? (u32)(s_lut[raw[c]] & 3) : 0u, a1 = c + 1 < T ? (u32)(s_lut[raw[c + 1]] & 3) : 0u;
+    const u32 a0 = c < T ? (u32)(s_lut[raw[c]] & 15) : 0u, a1 = c + 1 < T ? (u32)(s_lut[raw[c + 1]] & 15) : 0u;
     trows[w] = (a0 << 8) | (a1 << 24);
 }
 
@@ -99,66 +99,71 @@ hipError_t launch_pack_target_2bit(const uint8_t* raw, const uint8_t* lut, int T
 
 // ------------------------------------------------------------------ buildPeq
 
-// reference buildPeq (edlib.cpp:358-384) restricted to the (<= 4) symbols of the
+// reference buildPeq (edlib.cpp:358-384) restricted to the (<= 16) symbols of the
 // target: bit i of row s says "query[i] equals target symbol s".  eqtbl[byte] is
-// the 4-bit set of target symbols a query byte equals (identity plus
+// the 16-bit set of target symbols a query byte equals (identity plus
 // additionalEqualities, edlib.cpp:63-94).  Rows at or past the query end stay 0.
-// Output layout [readBlock][sym][word][lane]: a wave loads a row as one 256 B line.
+// Output layout [readBlock][sym (S = 4, 8 or 16)][word][lane]: a wave loads a row as one 256 B line.
+// Four symbols at a time (4 x NWD row registers); the query is re-read per group from L1.
 template <int NWD>
 __global__ void __launch_bounds__(256)
 build_peq_reads_kernel(const uint8_t* __restrict__ reads, const long long* __restrict__ qoff,
-                       const int* __restrict__ perm, int nslots,
-                       const uint8_t* __restrict__ eqtbl, const u32* __restrict__ tpres, int kcfg,
+                       const int* __restrict__ perm, int nslots, int S,
+                       const uint16_t* __restrict__ eqtbl, const u32* __restrict__ tpres, int kcfg,
                        u32* __restrict__ peq, int* __restrict__ qlen, int* __restrict__ kinit,
                        int* __restrict__ alphaExtra)
 {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= nslots) return;
     const int r = perm[slot];
-    u32 E[4][NWD];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int d = 0; d < NWD; ++d) E[s][d] = 0;
-    int m = 1, extra = 0;
-    if (r >= 0) {
-        const long long off = qoff[r];
-        m = (int)(qoff[r + 1] - off);
-        // distinct query bytes that do not occur in the target (for alphabetLength)
-        unsigned long long seen0 = ((unsigned long long)tpres[1] << 32) | tpres[0];
-        unsigned long long seen1 = ((unsigned long long)tpres[3] << 32) | tpres[2];
-        unsigned long long seen2 = ((unsigned long long)tpres[5] << 32) | tpres[4];
-        unsigned long long seen3 = ((unsigned long long)tpres[7] << 32) | tpres[6];
-#pragma unroll
-        for (int d = 0; d < NWD; ++d) {
-            u32 e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-            for (int j = 0; j < 32; ++j) {
-                const int i = d * 32 + j;
-                if (i >= m) break;
-                const u32 b = reads[off + i];
-                const u32 mask = eqtbl[b];
-                e0 |= (mask & 1u) << j;
-                e1 |= ((mask >> 1) & 1u) << j;
-                e2 |= ((mask >> 2) & 1u) << j;
-                e3 |= ((mask >> 3) & 1u) << j;
-                const unsigned long long bit = 1ull << (b & 63);
-                const u32 w = b >> 6;
-                unsigned long long cur = w == 0 ? seen0 : w == 1 ? seen1 : w == 2 ? seen2 : seen3;
-                if (!(cur & bit)) {
-                    ++extra;
-                    if (w == 0) seen0 |= bit; else if (w == 1) seen1 |= bit;
-                    else if (w == 2) seen2 |= bit; else seen3 |= bit;
-                }
-            }
-            E[0][d] = e0; E[1][d] = e1; E[2][d] = e2; E[3][d] = e3;
-        }
-    }
     const int blk = slot >> 6, lane = slot & 63;
+    int m = 1, extra = 0;
+    long long off = 0;
+    if (r >= 0) { off = qoff[r]; m = (int)(qoff[r + 1] - off); }
+    for (int g0 = 0; g0 < S; g0 += 4) {
+        u32 E[4][NWD];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int d = 0; d < NWD; ++d)
-            peq[((size_t)(blk * 4 + s) * NWD + d) * 64 + lane] = E[s][d];
+            for (int d = 0; d < NWD; ++d) E[s][d] = 0;
+        if (r >= 0) {
+            // distinct query bytes that do not occur in the target (for alphabetLength), first group only
+            unsigned long long seen0 = ((unsigned long long)tpres[1] << 32) | tpres[0];
+            unsigned long long seen1 = ((unsigned long long)tpres[3] << 32) | tpres[2];
+            unsigned long long seen2 = ((unsigned long long)tpres[5] << 32) | tpres[4];
+            unsigned long long seen3 = ((unsigned long long)tpres[7] << 32) | tpres[6];
+#pragma unroll
+            for (int d = 0; d < NWD; ++d) {
+                u32 e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+                for (int j = 0; j < 32; ++j) {
+                    const int i = d * 32 + j;
+                    if (i >= m) break;
+                    const u32 b = reads[off + i];
+                    const u32 mask = (u32)eqtbl[b] >> g0;
+                    e0 |= (mask & 1u) << j;
+                    e1 |= ((mask >> 1) & 1u) << j;
+                    e2 |= ((mask >> 2) & 1u) << j;
+                    e3 |= ((mask >> 3) & 1u) << j;
+                    if (g0 == 0) {
+                        const unsigned long long bit = 1ull << (b & 63);
+                        const u32 w = b >> 6;
+                        unsigned long long cur = w == 0 ? seen0 : w == 1 ? seen1 : w == 2 ? seen2 : seen3;
+                        if (!(cur & bit)) {
+                            ++extra;
+                            if (w == 0) seen0 |= bit; else if (w == 1) seen1 |= bit;
+                            else if (w == 2) seen2 |= bit; else seen3 |= bit;
+                        }
+                    }
+                }
+                E[0][d] = e0; E[1][d] = e1; E[2][d] = e2; E[3][d] = e3;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int d = 0; d < NWD; ++d)
+                peq[((size_t)(blk * S + g0 + s) * NWD + d) * 64 + lane] = E[s][d];
+    }
     qlen[slot] = m;
     // candidates are columns scoring <= min(k, m): HW clamps k to m (edlib.cpp:566-568) and
     // for SHW the best score never exceeds m either (the empty prefix costs m)
@@ -168,23 +173,24 @@ build_peq_reads_kernel(const uint8_t* __restrict__ reads, const long long* __res
 
 template <int NWD>
 static hipError_t launch_build_peq_t(const uint8_t* reads, const long long* qoff, const int* perm,
-                                     int nslots, const uint8_t* eqtbl, const u32* tpres, int kcfg,
+                                     int nslots, int S, const uint16_t* eqtbl, const u32* tpres, int kcfg,
                                      u32* peq, int* qlen, int* kinit, int* alphaExtra,
                                      hipStream_t stream)
 {
     hipLaunchKernelGGL(build_peq_reads_kernel<NWD>, dim3((nslots + 255) / 256), dim3(256), 0, stream,
-                       reads, qoff, perm, nslots, eqtbl, tpres, kcfg, peq, qlen, kinit, alphaExtra);
+                       reads, qoff, perm, nslots, S, eqtbl, tpres, kcfg, peq, qlen, kinit, alphaExtra);
     return hipGetLastError();
 }
 
-hipError_t launch_build_peq_reads(int nwords, const uint8_t* reads, const long long* qoff,
-                                  const int* perm, int nslots, const uint8_t* eqtbl,
+hipError_t launch_build_peq_reads(int nwords, int syms, const uint8_t* reads, const long long* qoff,
+                                  const int* perm, int nslots, const uint16_t* eqtbl,
                                   const u32* tpres, int kcfg, u32* peq, int* qlen, int* kinit,
                                   int* alphaExtra, hipStream_t stream)
 {
     if (nslots == 0) return hipSuccess;
+    if (syms != 4 && syms != 8 && syms != 16) return hipErrorInvalidValue;
     switch (nwords) {
-#define CASE(N) case N: return launch_build_peq_t<N>(reads, qoff, perm, nslots, eqtbl, tpres, kcfg, peq, qlen, kinit, alphaExtra, stream);
+#define CASE(N) case N: return launch_build_peq_t<N>(reads, qoff, perm, nslots, syms, eqtbl, tpres, kcfg, peq, qlen, kinit, alphaExtra, stream);
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
     }
@@ -429,9 +435,10 @@ __device__ __forceinline__ void column_step_eq1(const u32 eq0, u32 (&Pv)[NWD], u
 #define EDLIB_AMD_M0_EVEN(P) "s_pack_ll_b32_b16 m0, " P ", 0\n\t"
 #define EDLIB_AMD_M0_ODD(P)  "s_lshr_b32 m0, " P ", 16\n\t"
 #define EDLIB_AMD_RD(N, OFF) "ds_read_addtid_b32 " N " offset:" #OFF "\n\t"
+#define EDLIB_AMD_RDW(N, W) "ds_read_addtid_b32 " N " offset:%[w" #W "]\n\t"      /* word W of the row: offset W * S * 256 */
 
-// rows of ONE column (J = 0..3 of the quad held in the SGPR pair lo / hi), NA words
-template <int NA, int J>
+// rows of ONE column (J = 0..3 of the quad held in the SGPR pair lo / hi), NA words; S symbols per word (row stride 256 S)
+template <int NA, int J, int S>
 __device__ __forceinline__ void lds_rows_request(u32 (&n)[NA], const u32 lo, const u32 hi)
 {
     static_assert(NA >= 1 && NA <= 8, "band height");
@@ -439,9 +446,10 @@ __device__ __forceinline__ void lds_rows_request(u32 (&n)[NA], const u32 lo, con
 #define EDLIB_AMD_SET ((J & 1) ? EDLIB_AMD_M0_ODD("%[pr]") : EDLIB_AMD_M0_EVEN("%[pr]"))
     if constexpr (NA == 1) { if constexpr (J & 1) asm volatile(EDLIB_AMD_M0_ODD("%[pr]") "s_nop 0\n\t" EDLIB_AMD_RD("%0", 0) : "=v"(n[0]) : [pr] "s"(pr) : "memory", "scc");
                              else asm volatile(EDLIB_AMD_M0_EVEN("%[pr]") "s_nop 0\n\t" EDLIB_AMD_RD("%0", 0) : "=v"(n[0]) : [pr] "s"(pr) : "memory", "scc"); }
+#define EDLIB_AMD_WOFF [w1] "n"(S * 256), [w2] "n"(S * 512), [w3] "n"(S * 768), [w4] "n"(S * 1024), [w5] "n"(S * 1280), [w6] "n"(S * 1536), [w7] "n"(S * 1792)
 #define EDLIB_AMD_ROWS_ASM(READS, OUTS)                                                                              \
-    { if constexpr (J & 1) asm volatile(EDLIB_AMD_M0_ODD("%[pr]") "s_nop 0\n\t" READS : OUTS : [pr] "s"(pr) : "memory", "scc");   \
-      else asm volatile(EDLIB_AMD_M0_EVEN("%[pr]") "s_nop 0\n\t" READS : OUTS : [pr] "s"(pr) : "memory", "scc"); }
+    { if constexpr (J & 1) asm volatile(EDLIB_AMD_M0_ODD("%[pr]") "s_nop 0\n\t" READS : OUTS : [pr] "s"(pr), EDLIB_AMD_WOFF : "memory", "scc");   \
+      else asm volatile(EDLIB_AMD_M0_EVEN("%[pr]") "s_nop 0\n\t" READS : OUTS : [pr] "s"(pr), EDLIB_AMD_WOFF : "memory", "scc"); }
 #define O1 "=v"(n[0])
 #define O2 O1, "=v"(n[1])
 #define O3 O2, "=v"(n[2])
@@ -450,13 +458,13 @@ __device__ __forceinline__ void lds_rows_request(u32 (&n)[NA], const u32 lo, con
 #define O6 O5, "=v"(n[5])
 #define O7 O6, "=v"(n[6])
 #define O8 O7, "=v"(n[7])
-#define R2 EDLIB_AMD_RD("%0", 0) EDLIB_AMD_RD("%1", 1024)
-#define R3 R2 EDLIB_AMD_RD("%2", 2048)
-#define R4 R3 EDLIB_AMD_RD("%3", 3072)
-#define R5 R4 EDLIB_AMD_RD("%4", 4096)
-#define R6 R5 EDLIB_AMD_RD("%5", 5120)
-#define R7 R6 EDLIB_AMD_RD("%6", 6144)
-#define R8 R7 EDLIB_AMD_RD("%7", 7168)
+#define R2 EDLIB_AMD_RD("%0", 0) EDLIB_AMD_RDW("%1", 1)
+#define R3 R2 EDLIB_AMD_RDW("%2", 2)
+#define R4 R3 EDLIB_AMD_RDW("%3", 3)
+#define R5 R4 EDLIB_AMD_RDW("%4", 4)
+#define R6 R5 EDLIB_AMD_RDW("%5", 5)
+#define R7 R6 EDLIB_AMD_RDW("%6", 6)
+#define R8 R7 EDLIB_AMD_RDW("%7", 7)
     if constexpr (NA == 2) EDLIB_AMD_ROWS_ASM(R2, O2)
     if constexpr (NA == 3) EDLIB_AMD_ROWS_ASM(R3, O3)
     if constexpr (NA == 4) EDLIB_AMD_ROWS_ASM(R4, O4)
@@ -583,7 +591,7 @@ typedef u32 QuadRows[4];
 // S <= k + c; the one unit matters: against unrelated sequence the score 32 rows down hovers around 13, and with
 // k = 6 a wave meets S <= 10 at 0.5 % of its checkpoints but S <= 9 at 0.06 %.)  A new word enters as "+1 per row"
 // like the reference's new block (edlib.cpp:605-608).
-template <int NA, int NWD, int Q>
+template <int NA, int NWD, int Q, int S>
 __device__ __forceinline__ int band_quad(const u32 lo, const u32 hi, const u32 nlo, const u32 nhi, QuadRows& qr,
                                          const int colBase, const int colEnd, const bool track, u32 (&Pv)[NWD],
                                          u32 (&Mv)[NWD], int& e, int& flag, HwTrack& tr, const u32 sh, const int lastRows)
@@ -595,16 +603,16 @@ __device__ __forceinline__ int band_quad(const u32 lo, const u32 hi, const u32 n
         // straight-line code: the Peq rows of a column arrive from LDS while the previous column is computed.
         // The first request of a quad is exposed; the other waves of the SIMD cover it.
         u32 nx[NA];
-        lds_rows_request<NA, 0>(nx, lo, hi);
+        lds_rows_request<NA, 0, S>(nx, lo, hi);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             lds_rows_wait<NA>(nx);
             u32 eq[NA];
 #pragma unroll
             for (int i = 0; i < NA; ++i) eq[i] = nx[i];
-            if (j == 0) lds_rows_request<NA, 1>(nx, lo, hi);
-            if (j == 1) lds_rows_request<NA, 2>(nx, lo, hi);
-            if (j == 2) lds_rows_request<NA, 3>(nx, lo, hi);
+            if (j == 0) lds_rows_request<NA, 1, S>(nx, lo, hi);
+            if (j == 1) lds_rows_request<NA, 2, S>(nx, lo, hi);
+            if (j == 2) lds_rows_request<NA, 3, S>(nx, lo, hi);
             if constexpr (NA == 2 && NWD > 2) column_step_eq2<NWD>(eq[0], eq[1], Pv, Mv);   // bottom row outside: nothing tracked
             else column_step_hw<NA, NWD>(eq, Pv, Mv, e, flag, sh);
             eh[j] = e;
@@ -669,17 +677,17 @@ __device__ __forceinline__ int band_quad(const u32 lo, const u32 hi, const u32 n
             int Sprev = 0;
 #pragma unroll
             for (int i = 0; i + 1 < NA; ++i) Sprev += __popc(Pv[i]) - __popc(Mv[i]);
-            const int S = Sprev + __popc(Pv[NA - 1]) - __popc(Mv[NA - 1]);
+            const int Sb = Sprev + __popc(Pv[NA - 1]) - __popc(Mv[NA - 1]);
             if constexpr (NA < NWD) {
-                if (__builtin_amdgcn_ballot_w64(S <= tr.best + 15) != 0ull) {
+                if (__builtin_amdgcn_ballot_w64(Sb <= tr.best + 15) != 0ull) {
                     Pv[NA < NWD ? NA : 0] = ~0u; Mv[NA < NWD ? NA : 0] = 0u;
-                    if (NA + 1 == NWD) { e = S + lastRows - tr.best - 1; flag = 0; } // row m-1 is lastRows rows below
+                    if (NA + 1 == NWD) { e = Sb + lastRows - tr.best - 1; flag = 0; } // row m-1 is lastRows rows below
                     return NA + 1;
                 }
             }
             // drop the last word when (a) every cell of it exceeds k: a cell j rows below Sprev's row is
-            // >= max(Sprev - j, S - (32 - j)) >= (Sprev + S - 32) / 2, and (b) the new bottom 16 rows do too
-            const bool keep = (Sprev <= tr.best + 16) || (Sprev + S <= 2 * tr.best + 34);
+            // >= max(Sprev - j, Sb - (32 - j)) >= (Sprev + Sb - 32) / 2, and (b) the new bottom 16 rows do too
+            const bool keep = (Sprev <= tr.best + 16) || (Sprev + Sb <= 2 * tr.best + 34);
             if (__builtin_amdgcn_ballot_w64(keep) == 0ull) return NA - 1;
         }
         return NA;
@@ -688,8 +696,10 @@ __device__ __forceinline__ int band_quad(const u32 lo, const u32 hi, const u32 n
 
 typedef u32 u32x8 __attribute__((ext_vector_type(8)));
 
-template <int NWD>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NWD <= 5 ? 8 : 1, 8)))
+// S: Peq rows per word = target symbols rounded up to 4, 8 or 16 (a genome with N, soft-masked lower case, IUPAC
+// codes).  LDS per wave = NWD * S * 256 bytes: 8 waves per SIMD at S = 4 and up to 5 words, 4 at S = 8, 2 at S = 16.
+template <int NWD, int S>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((S == 4 && NWD <= 5) ? 8 : 1, 8)))
 scan_reads_banded_kernel(const ReadScanArgs a)
 {
     const int lane = threadIdx.x;
@@ -704,13 +714,13 @@ scan_reads_banded_kernel(const ReadScanArgs a)
     const int lastRows = m - 32 * (NWD - 1);                          // query rows in the last word
     // the four Peq rows of the wave's queries: HBM -> LDS, [word][symbol][lane].  The only LDS object of a
     // one-wave workgroup: it sits at LDS address 0, which is what lets M0 be the bare row offset.
-    __shared__ __attribute__((aligned(1024))) u32 s_eq[NWD][4][64];
+    __shared__ __attribute__((aligned(1024))) u32 s_eq[NWD][S][64];
     {
-        const size_t pb = (size_t)(slot >> 6) * 4 * NWD * 64 + (slot & 63);
+        const size_t pb = (size_t)(slot >> 6) * S * NWD * 64 + (slot & 63);
 #pragma unroll
         for (int d = 0; d < NWD; ++d) {
 #pragma unroll
-            for (int sy = 0; sy < 4; ++sy) s_eq[d][sy][lane] = a.peq[pb + (size_t)(sy * NWD + d) * 64];
+            for (int sy = 0; sy < S; ++sy) s_eq[d][sy][lane] = a.peq[pb + (size_t)(sy * NWD + d) * 64];
             Pv[d] = ~0u;                                             // column -1: D[i][-1] = i+1
             Mv[d] = 0u;
         }
@@ -754,7 +764,7 @@ scan_reads_banded_kernel(const ReadScanArgs a)
     while (b < bend) {
         switch (nw) {
 #define QUAD(NA, Q)                                                                                             \
-            nw = band_quad<(NA <= NWD ? NA : NWD), NWD, Q>(cur[2 * Q], cur[2 * Q + 1],                          \
+            nw = band_quad<(NA <= NWD ? NA : NWD), NWD, Q, S>(cur[2 * Q], cur[2 * Q + 1],                          \
                      Q < 3 ? cur[(2 * Q + 2) & 7] : nxt[0], Q < 3 ? cur[(2 * Q + 3) & 7] : nxt[1], qr,          \
                      b * 16 + Q * 4, c1, b >= bmain /* warm-up columns record nothing */, Pv, Mv, e, flag, tr,  \
                      sh, lastRows);
@@ -797,18 +807,29 @@ scan_reads_banded_kernel(const ReadScanArgs a)
     if (a.wordSteps && lane == 0) atomicAdd(a.wordSteps, (unsigned long long)bandWork * 4ull * 64ull);
 }
 
-hipError_t launch_scan_reads_banded(int nwords, const ReadScanArgs& a, hipStream_t stream)
+template <int S>
+static hipError_t launch_scan_reads_banded_s(int nwords, const ReadScanArgs& a, hipStream_t stream)
 {
-    if (a.nlanes == 0) return hipSuccess;
     const int nrblk = (a.nlanes + 63) / 64;
     dim3 grid(nrblk, a.numSegments), block(64);
     switch (nwords) {
-#define CASE(N) case N: hipLaunchKernelGGL((scan_reads_banded_kernel<N>), grid, block, 0, stream, a); break;
+#define CASE(N) case N: hipLaunchKernelGGL((scan_reads_banded_kernel<N, S>), grid, block, 0, stream, a); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+hipError_t launch_scan_reads_banded(int nwords, int syms, const ReadScanArgs& a, hipStream_t stream)
+{
+    if (a.nlanes == 0) return hipSuccess;
+    switch (syms) {
+        case 4: return launch_scan_reads_banded_s<4>(nwords, a, stream);
+        case 8: return launch_scan_reads_banded_s<8>(nwords, a, stream);
+        case 16: return launch_scan_reads_banded_s<16>(nwords, a, stream);
+    }
+    return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------- the merge

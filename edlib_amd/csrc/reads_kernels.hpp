@@ -11,7 +11,7 @@ constexpr int kLanes = 64;            // wave64, hard-coded (gfx950)
 
 // Everything the scan kernel needs; plain pointers into HBM.
 struct ReadScanArgs {
-    const uint32_t* peq;      // [readBlock][4 symbols][NWD words][64 lanes]
+    const uint32_t* peq;      // [readBlock][S symbols][NWD words][64 lanes], S = 4 (both kernels), 8 or 16 (banded kernel)
     const uint32_t* tpk;      // target, 2 bits / symbol, 16 symbols / dword, LSB first (scan_reads_kernel)
     const uint32_t* trows;    // target, 16 bits / symbol = LDS row offset (symbol << 8), 16 columns per 32-byte block,
                               // padded by two blocks (scan_reads_banded_kernel)
@@ -36,8 +36,9 @@ struct ReadScanArgs {
 // mode: 0 NW, 1 SHW, 2 HW (values of EdlibAlignMode).  Returns hipSuccess or the launch error.
 hipError_t launch_scan_reads(int nwords, int mode, const ReadScanArgs& a, hipStream_t stream);
 
-// HW only: Ukkonen-banded variant with k-doubling (see reads_kernels.hip); same Peq layout.
-hipError_t launch_scan_reads_banded(int nwords, const ReadScanArgs& a, hipStream_t stream);
+// HW only: Ukkonen-banded variant with k-doubling (see reads_kernels.hip); same Peq layout.  syms = Peq rows per word:
+// 4, 8 or 16 (target symbols rounded up); launch_scan_reads only knows 4.
+hipError_t launch_scan_reads_banded(int nwords, int syms, const ReadScanArgs& a, hipStream_t stream);
 
 hipError_t launch_pack_target_2bit(const uint8_t* raw, const uint8_t* lut, int targetLength,
                                    uint32_t* tpk, hipStream_t stream);
@@ -45,10 +46,11 @@ hipError_t launch_pack_target_2bit(const uint8_t* raw, const uint8_t* lut, int t
 hipError_t launch_pack_target_rows(const uint8_t* raw, const uint8_t* lut, int targetLength,
                                    uint32_t* trows, int ndwords, hipStream_t stream);
 
-// Builds Peq for every slot (reference buildPeq, edlib.cpp:358-384, for the <=4 target symbols),
+// Builds Peq for every slot (reference buildPeq, edlib.cpp:358-384, for the <= syms target symbols; eqtbl[byte] =
+// 16-bit set of the target symbols a query byte equals),
 // the per-slot query length and the number of query byte values absent from the target.
-hipError_t launch_build_peq_reads(int nwords, const uint8_t* reads, const long long* qoff,
-                                  const int* perm, int nslots, const uint8_t* eqtbl,
+hipError_t launch_build_peq_reads(int nwords, int syms, const uint8_t* reads, const long long* qoff,
+                                  const int* perm, int nslots, const uint16_t* eqtbl,
                                   const uint32_t* targetPresence /*8 dwords*/, int kcfg,
                                   uint32_t* peq, int* qlen, int* kinit, int* alphaExtra,
                                   hipStream_t stream);

@@ -174,3 +174,34 @@ def mutated_pairs(n, length, seed, sub, ins, dele, workers=1, first=0):
     else:
         pairs = _pair_chunk((first, first + n, length, seed, sub, ins, dele))
     return [p[0] for p in pairs], [p[1] for p in pairs]
+
+
+def masked_genome(seed, n, frac_n=0.01, frac_lower=0.1, iupac=False):
+    """uniform ACGT with runs of N (~50 long), soft-masked lower-case stretches (~200 long) and, with `iupac`,
+    scattered IUPAC codes: the alphabets real reference genomes have (5 to 16 distinct bytes)."""
+    g = random_dna(seed, n)
+    u = rand_unit(seed, n, 11)
+    nrun = np.zeros(n, dtype=bool); lrun = np.zeros(n, dtype=bool)
+    for start in np.nonzero(u < frac_n / 50.0)[0]:
+        nrun[start:start + 50] = True
+    for start in np.nonzero((u >= 0.5) & (u < 0.5 + frac_lower / 200.0))[0]:
+        lrun[start:start + 200] = True
+    g = g.copy()
+    g[lrun] = g[lrun] + 32                     # lower case
+    g[nrun] = ord("N")
+    if iupac:
+        codes = np.frombuffer(b"RYKMSW", dtype=np.uint8)
+        at = np.nonzero(rand_unit(seed, n, 12) < 0.002)[0]
+        g[at] = codes[(rand_u64(seed, len(at), 13) >> _U64(20)) % _U64(len(codes))]
+    return g
+
+
+def window_reads(target, n, m, seed, sub=0.01):
+    """n reads = m-byte windows of `target` (whatever bytes it holds) with substitutions by uniform ACGT."""
+    target = np.asarray(target, dtype=np.uint8)
+    start = (rand_u64(seed, n, 1) % _U64(len(target) - m + 1)).astype(np.int64)
+    reads = target[start[:, None] + np.arange(m)[None, :]].copy()
+    x = rand_u64(seed, n * m, 2).reshape(n, m)
+    hit = (x >> _U64(40)).astype(np.uint32) < int(round(sub * (1 << 24)))
+    reads[hit] = _ACGT[(x[hit] & _U64(3)).astype(np.int64)]
+    return reads, start
