@@ -495,11 +495,13 @@ static void finalize_global(UnitResult& r, int kcfg, int mode, int T, int score)
 // One scan launch over a group's slots (or a subset through d_slotmap), banded or not.
 int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, int kcap, const int* d_kinit,
                      int numSegments, int segLen, int warm, int* segBest, int* segCnt, int* segPos, int cap,
-                     const long long* posOff, const int* posCap, bool unbanded, unsigned long long* wordSteps)
+                     const long long* posOff, const int* posCap, bool unbanded, unsigned long long* wordSteps,
+                     const uint32_t* peqDense, const int* qlenDense)
 {
     ReadScanArgs a{};
-    a.peq = g.d_peq.p; a.tpk = d_tpk_.p; a.trows = d_trows_.p; a.targetLength = tlen(0);
-    a.qlen = g.d_qlen.p; a.kinit = d_kinit; a.slotmap = d_slotmap; a.nlanes = nlanes;
+    // peqDense / qlenDense (+ d_kinit): rows rebuilt for exactly the lanes of this launch, in lane order (pass 2)
+    a.peq = peqDense ? peqDense : g.d_peq.p; a.tpk = d_tpk_.p; a.trows = d_trows_.p; a.targetLength = tlen(0);
+    a.qlen = qlenDense ? qlenDense : g.d_qlen.p; a.kinit = d_kinit; a.slotmap = d_slotmap; a.nlanes = nlanes;
     a.numSegments = numSegments; a.segLen = segLen; a.warm = warm;
     a.segBest = segBest; a.segCnt = segCnt; a.segPos = segPos; a.cap = cap;
     a.posOff = posOff; a.posCap = posCap;
@@ -652,8 +654,21 @@ int Batch::runReads()
                     plain = syms_ == 4 && (double)ws >= 0.85 * g.nwords * cols;
                     stats.word_steps += (long long)ws;
                 }
-                if (scanGroup(g, mode, d_map.p, (int)no, kNoCap, g.d_kinit.p, S2, segLen2, warm2,
-                              d_sb.p, d_sc.p, d_sp.p, 8, nullptr, nullptr, plain)) return 1;
+                // The leftovers are scattered over the batch: through the slot map every lane of a wave would pull its
+                // rows from a different 256-byte line (16x the bytes, once per segment: 3 GB of fetch per 1M-read step
+                // in round 1).  Their rows are rebuilt in lane order instead -- the builder reads each query once.
+                const size_t no64 = (no + 63) / 64 * 64;
+                std::vector<int> perm2(no64, -1);
+                for (size_t i = 0; i < no; ++i) perm2[i] = g.perm[todo[i]];
+                DevBuf<int> d_perm2, d_qlen2, d_kinit2, d_extra2; DevBuf<uint32_t> d_peq2;
+                EDLIB_AMD_HIP(d_perm2.alloc(no64)); EDLIB_AMD_HIP(d_qlen2.alloc(no64)); EDLIB_AMD_HIP(d_kinit2.alloc(no64));
+                EDLIB_AMD_HIP(d_extra2.alloc(no64)); EDLIB_AMD_HIP(d_peq2.alloc(no64 * (size_t)syms_ * g.nwords));
+                EDLIB_AMD_HIP(hipMemcpyAsync(d_perm2.p, perm2.data(), no64 * sizeof(int), hipMemcpyHostToDevice, stream_));
+                EDLIB_AMD_HIP(launch_build_peq_reads(g.nwords, syms_, d_qpool_.p, d_qoff_.p, d_perm2.p, (int)no64,
+                                                     d_eqtbl_.p, d_presence_.p, cfg_.k, d_peq2.p, d_qlen2.p,
+                                                     d_kinit2.p, d_extra2.p, stream_));
+                if (scanGroup(g, mode, nullptr, (int)no, kNoCap, d_kinit2.p, S2, segLen2, warm2,
+                              d_sb.p, d_sc.p, d_sp.p, 8, nullptr, nullptr, plain, nullptr, d_peq2.p, d_qlen2.p)) return 1;
                 EDLIB_AMD_HIP(launch_merge_segments(d_sb.p, d_sc.p, d_sp.p, S2, 8, (int)no, d_map.p, 16,
                                                     g.d_best.p, g.d_total.p, g.d_pos.p, g.d_flags.p, stream_));
                 EDLIB_AMD_HIP(hipStreamSynchronize(stream_));            // temporaries die here

@@ -119,7 +119,8 @@ private:
     int scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, int kcap, const int* d_kinit,
                   int numSegments, int segLen, int warm, int* segBest, int* segCnt, int* segPos, int cap,
                   const long long* posOff, const int* posCap, bool unbanded = false,
-                  unsigned long long* wordSteps = nullptr);
+                  unsigned long long* wordSteps = nullptr, const uint32_t* peqDense = nullptr,
+                  const int* qlenDense = nullptr);
 
     // ---- block-per-lane path
     DevBuf<PairDesc> d_descs_;

@@ -104,7 +104,12 @@ hipError_t launch_pack_target_2bit(const uint8_t* raw, const uint8_t* lut, int T
 // the 16-bit set of target symbols a query byte equals (identity plus
 // additionalEqualities, edlib.cpp:63-94).  Rows at or past the query end stay 0.
 // Output layout [readBlock][sym (S = 4, 8 or 16)][word][lane]: a wave loads a row as one 256 B line.
-// Four symbols at a time (4 x NWD row registers); the query is re-read per group from L1.
+//
+// One wave builds the rows of its 64 reads COOPERATIVELY: for read j the lanes load 64 consecutive query bytes
+// (one coalesced line), look their symbol sets up, and a ballot per symbol IS the two 32-bit Peq words of those 64
+// rows, which lane j keeps.  (Round 1 gave every lane its own read and walked it byte
+// by byte: 64 different lines per load instruction, 8.9 GB of fetch per 1M reads against 150 MB of queries.)
+// Symbols are done four at a time (4 x NWD row registers); the query bytes are re-read per group from L1 / L2.
 template <int NWD>
 __global__ void __launch_bounds__(256)
 build_peq_reads_kernel(const uint8_t* __restrict__ reads, const long long* __restrict__ qoff,
@@ -113,57 +118,73 @@ build_peq_reads_kernel(const uint8_t* __restrict__ reads, const long long* __res
                        u32* __restrict__ peq, int* __restrict__ qlen, int* __restrict__ kinit,
                        int* __restrict__ alphaExtra)
 {
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= nslots) return;
-    const int r = perm[slot];
-    const int blk = slot >> 6, lane = slot & 63;
-    int m = 1, extra = 0;
-    long long off = 0;
+    __shared__ uint16_t s_eq[256];
+    s_eq[threadIdx.x] = eqtbl[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);               // read block of this wave
+    if (blk * 64 >= nslots) return;
+    const int slot = blk * 64 + lane;
+    const int r = slot < nslots ? perm[slot] : -1;
+    long long off = 0; int m = 1;
     if (r >= 0) { off = qoff[r]; m = (int)(qoff[r + 1] - off); }
+    int extra = 0;
     for (int g0 = 0; g0 < S; g0 += 4) {
         u32 E[4][NWD];
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int d = 0; d < NWD; ++d) E[s][d] = 0;
-        if (r >= 0) {
-            // distinct query bytes that do not occur in the target (for alphabetLength), first group only
-            unsigned long long seen0 = ((unsigned long long)tpres[1] << 32) | tpres[0];
-            unsigned long long seen1 = ((unsigned long long)tpres[3] << 32) | tpres[2];
-            unsigned long long seen2 = ((unsigned long long)tpres[5] << 32) | tpres[4];
-            unsigned long long seen3 = ((unsigned long long)tpres[7] << 32) | tpres[6];
+        for (int j = 0; j < 64; ++j) {                                 // read j of the wave (wave-uniform)
+            const int rj = __builtin_amdgcn_readlane(r, j);
+            if (rj < 0) continue;
+            const int mj = __builtin_amdgcn_readlane(m, j);
+            const long long offj = ((long long)__builtin_amdgcn_readlane((int)(off >> 32), j) << 32)
+                                 | (u32)__builtin_amdgcn_readlane((int)off, j);
+            // bytes of this read that do not occur in the target, counted once each (alphabetLength): wave-uniform
+            // 256-bit set, only touched when a lane holds such a byte (first symbol group only)
+            unsigned long long seen0 = 0, seen1 = 0, seen2 = 0, seen3 = 0;
+            int extraJ = 0;
+            const bool mine = lane == j;                               // the lane that keeps read j's rows
 #pragma unroll
-            for (int d = 0; d < NWD; ++d) {
-                u32 e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-                for (int j = 0; j < 32; ++j) {
-                    const int i = d * 32 + j;
-                    if (i >= m) break;
-                    const u32 b = reads[off + i];
-                    const u32 mask = (u32)eqtbl[b] >> g0;
-                    e0 |= (mask & 1u) << j;
-                    e1 |= ((mask >> 1) & 1u) << j;
-                    e2 |= ((mask >> 2) & 1u) << j;
-                    e3 |= ((mask >> 3) & 1u) << j;
-                    if (g0 == 0) {
-                        const unsigned long long bit = 1ull << (b & 63);
-                        const u32 w = b >> 6;
-                        unsigned long long cur = w == 0 ? seen0 : w == 1 ? seen1 : w == 2 ? seen2 : seen3;
-                        if (!(cur & bit)) {
-                            ++extra;
-                            if (w == 0) seen0 |= bit; else if (w == 1) seen1 |= bit;
-                            else if (w == 2) seen2 |= bit; else seen3 |= bit;
-                        }
+            for (int c = 0; c < (NWD + 1) / 2; ++c) {                  // 64 rows = two words per trip
+                const int i = 64 * c + lane;
+                const bool in = i < mj;
+                const u32 by = in ? reads[offj + i] : 0u;
+                const u32 mask = in ? ((u32)s_eq[by] >> g0) : 0u;
+                const unsigned long long b0 = __builtin_amdgcn_ballot_w64((mask & 1u) != 0), b1 = __builtin_amdgcn_ballot_w64((mask & 2u) != 0);
+                const unsigned long long b2 = __builtin_amdgcn_ballot_w64((mask & 4u) != 0), b3 = __builtin_amdgcn_ballot_w64((mask & 8u) != 0);
+                constexpr int w0 = 0;
+                const int d0 = 2 * c, d1 = (2 * c + 1 < NWD) ? 2 * c + 1 : w0;
+                E[0][d0] = (mine ? (u32)b0 : E[0][d0]); E[1][d0] = (mine ? (u32)b1 : E[1][d0]);
+                E[2][d0] = (mine ? (u32)b2 : E[2][d0]); E[3][d0] = (mine ? (u32)b3 : E[3][d0]);
+                if (2 * c + 1 < NWD) {
+                    E[0][d1] = (mine ? (u32)(b0 >> 32) : E[0][d1]); E[1][d1] = (mine ? (u32)(b1 >> 32) : E[1][d1]);
+                    E[2][d1] = (mine ? (u32)(b2 >> 32) : E[2][d1]); E[3][d1] = (mine ? (u32)(b3 >> 32) : E[3][d1]);
+                }
+                if (g0 == 0) {
+                    unsigned long long np = __builtin_amdgcn_ballot_w64(in && !((tpres[by >> 5] >> (by & 31)) & 1u));
+                    while (np) {                                       // rare: a query byte the target does not have
+                        const int l = __builtin_ctzll(np);
+                        const u32 v = (u32)__builtin_amdgcn_readlane((int)by, l);
+                        const unsigned long long bit = 1ull << (v & 63);
+                        unsigned long long& sw = (v >> 6) == 0 ? seen0 : (v >> 6) == 1 ? seen1 : (v >> 6) == 2 ? seen2 : seen3;
+                        if (!(sw & bit)) { sw |= bit; ++extraJ; }
+                        np &= ~__builtin_amdgcn_ballot_w64(in && by == v);
                     }
                 }
-                E[0][d] = e0; E[1][d] = e1; E[2][d] = e2; E[3][d] = e3;
             }
+            if (g0 == 0 && mine) extra = extraJ;
         }
+        if (slot < nslots) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int d = 0; d < NWD; ++d)
-                peq[((size_t)(blk * S + g0 + s) * NWD + d) * 64 + lane] = E[s][d];
+                for (int d = 0; d < NWD; ++d)
+                    peq[((size_t)(blk * S + g0 + s) * NWD + d) * 64 + lane] = E[s][d];
+        }
     }
+    if (slot >= nslots) return;
     qlen[slot] = m;
     // candidates are columns scoring <= min(k, m): HW clamps k to m (edlib.cpp:566-568) and
     // for SHW the best score never exceeds m either (the empty prefix costs m)

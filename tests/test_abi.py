@@ -88,3 +88,22 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in src.lower().replace("oracle-verified", ""), os.path.join(dirpath, f)
+
+
+def test_negative_lengths_are_errors_everywhere():
+    """edlibAlign() answers EDLIB_STATUS_ERROR for a negative length; the one-shot batch entry points must not turn
+    it into an empty sequence (decided before any device work, so this runs without a GPU)."""
+    import edlib_amd
+    L = edlib_amd.lib()
+    cfg = L.edlibDefaultAlignConfig()
+    r = L.edlibAlign(b"ACGT", -1, b"ACGT", 4, cfg)
+    assert r.status == 1 and r.editDistance == -1 and not r.endLocations
+    qs = (C.c_char_p * 2)(b"ACGT", b"AC")
+    res = (edlib_amd.AlignResult * 2)()
+    assert L.edlibAlignBatchSharedTarget(qs, (C.c_int * 2)(4, -2), 2, b"ACGTT", 5, cfg, res) == 1
+    assert "negative" in edlib_amd.last_error() and res[0].status == 1 and res[1].status == 1
+    ts = (C.c_char_p * 2)(b"ACGT", b"AC")
+    assert L.edlibAlignBatchPairs(qs, (C.c_int * 2)(4, 2), ts, (C.c_int * 2)(-4, 2), 2, cfg, res) == 1
+    assert L.edlibAlignBatchSharedTarget(qs, (C.c_int * 2)(4, 2), 2, b"ACGTT", -5, cfg, res) == 1
+    L.edlibAmdFreeResults(res, 2)               # nothing to free, must not crash
+    L.edlibAmdTrim()                            # empty cache, must not crash

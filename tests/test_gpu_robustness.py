@@ -160,3 +160,31 @@ def test_large_batch_takes_probe_and_leftover_paths(engine, ref, oracle):
     [t.join() for t in th]
     bad = [i for j, i in enumerate(idx) if not same(got[i], want[j])]
     assert not bad, (len(bad), bad[:5])
+
+
+def test_callers_device_and_env_device(engine, oracle, monkeypatch):
+    """no entry point leaves the calling thread on another HIP device than it found it (RAII guard), and
+    edlibAlign() takes EDLIB_AMD_DEVICE (an ordinal out of range falls back to the current device)"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")                     # the runtime libedlib.so itself is linked against
+
+    def current():
+        d = C.c_int(-1)
+        assert hip.hipGetDevice(C.byref(d)) == 0
+        return d.value
+    assert hip.hipSetDevice(0) == 0
+    q, t = b"ACGTTGCAAC", b"TTACGTAGCAACGG"
+    want = oracle.align(q, t, "HW", "path", -1)
+    for env in (None, "0", "63"):
+        if env is None:
+            monkeypatch.delenv("EDLIB_AMD_DEVICE", raising=False)
+        else:
+            monkeypatch.setenv("EDLIB_AMD_DEVICE", env)
+        got = engine.align_raw(q, t, "HW", "path", -1)
+        assert got == want
+        assert current() == 0
+    b = engine.SharedBatch([q, q], t, mode="HW", task="distance")
+    b.run(); b.results(); b.close()
+    assert current() == 0
+    engine.lib().edlibAmdTrim()
+    assert engine.align_raw(q, t, "HW", "path", -1) == want          # the cache refills after a trim
