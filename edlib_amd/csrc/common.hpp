@@ -101,10 +101,14 @@ struct DeviceGuard {
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
+// events are cached like streams (a batch of one pays for every hipEventCreate / hipEventDestroy it makes)
+hipError_t pool_event(hipEvent_t* e);
+void pool_event_release(hipEvent_t e);
+
 struct Event {
     hipEvent_t e = nullptr;
-    ~Event() { if (e) (void)hipEventDestroy(e); }
-    hipError_t create() { return e ? hipSuccess : hipEventCreate(&e); }
+    ~Event() { if (e) pool_event_release(e); }
+    hipError_t create() { return e ? hipSuccess : pool_event(&e); }
 };
 
 }  // namespace edlib_amd

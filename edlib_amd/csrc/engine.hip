@@ -42,6 +42,7 @@ struct Pool {
     static const int kMaxDev = 16;
     std::vector<void*> blocks[kMaxDev][48];     // [device][log2 size class]
     std::vector<hipStream_t> streams[kMaxDev];
+    std::vector<hipEvent_t> events[kMaxDev];
     size_t cachedBytes = 0;
     std::vector<void*> pinned[48];              // [log2 size class], host memory: device independent
     size_t cachedPinned = 0;
@@ -70,12 +71,15 @@ static bool pool_enabled() {
 void pool_trim() {
     Pool& P = pool();
     std::vector<std::pair<int, void*>> dev; std::vector<void*> pin; std::vector<std::pair<int, hipStream_t>> str;
+    std::vector<std::pair<int, hipEvent_t>> ev;
     {
         std::lock_guard<std::mutex> g(P.mu);
         for (int d = 0; d < Pool::kMaxDev; ++d) {
             for (auto& v : P.blocks[d]) { for (void* p : v) dev.push_back({d, p}); v.clear(); }
             for (hipStream_t s : P.streams[d]) str.push_back({d, s});
             P.streams[d].clear();
+            for (hipEvent_t e : P.events[d]) ev.push_back({d, e});
+            P.events[d].clear();
         }
         for (auto& v : P.pinned) { for (void* p : v) pin.push_back(p); v.clear(); }
         P.cachedBytes = 0; P.cachedPinned = 0;
@@ -83,6 +87,7 @@ void pool_trim() {
     for (auto& b : dev) (void)hipFree(b.second);
     for (void* p : pin) (void)hipHostFree(p);
     for (auto& s : str) { DeviceGuard g(s.first); (void)hipStreamDestroy(s.second); }
+    for (auto& e : ev) { DeviceGuard g(e.first); (void)hipEventDestroy(e.second); }
 }
 
 hipError_t pool_alloc(void** p, size_t bytes, size_t* granted) {
@@ -158,6 +163,27 @@ void pool_stream_release(hipStream_t s) {
         if (pool().streams[dev].size() < 16) { pool().streams[dev].push_back(s); return; }
     }
     (void)hipStreamDestroy(s);
+}
+
+hipError_t pool_event(hipEvent_t* e) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < Pool::kMaxDev && pool_enabled()) {
+        std::lock_guard<std::mutex> g(pool().mu);
+        auto& v = pool().events[dev];
+        if (!v.empty()) { *e = v.back(); v.pop_back(); return hipSuccess; }
+    }
+    return hipEventCreate(e);
+}
+
+void pool_event_release(hipEvent_t e) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < Pool::kMaxDev && pool_enabled()) {
+        std::lock_guard<std::mutex> g(pool().mu);
+        if (pool().events[dev].size() < 64) { pool().events[dev].push_back(e); return; }
+    }
+    (void)hipEventDestroy(e);
 }
 
 int device_count() {
@@ -282,8 +308,8 @@ count_flags_kernel(const int* __restrict__ flags, int n, int* __restrict__ count
 
 Batch::~Batch() {
     DeviceGuard guard(device_);
-    for (auto& p : scanEvents_) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (stream_) { (void)hipStreamSynchronize(stream_); pool_stream_release(stream_); }
+    for (auto& p : scanEvents_) { pool_event_release(p.first); pool_event_release(p.second); }
 }
 
 static int roundup(int x, int q) { return (x + q - 1) / q * q; }
@@ -413,12 +439,25 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
         EDLIB_AMD_HIP(g->d_perm.alloc(ns));
         EDLIB_AMD_HIP(hipMemcpy(g->d_perm.p, g->perm.data(), ns * sizeof(int), hipMemcpyHostToDevice));
         EDLIB_AMD_HIP(g->d_qlen.alloc(ns)); EDLIB_AMD_HIP(g->d_kinit.alloc(ns));
+        // Small groups (a call of edlibAlign() is one slot block): the merged per-slot results live in device-visible
+        // pinned host memory -- the merge / Peq / census kernels write them there, nothing is downloaded, and the
+        // host reads them after the one stream synchronisation a run needs anyway.
+        g->zeroCopy = ns <= 1024 && pool_enabled();
+        if (g->zeroCopy) {
+            EDLIB_AMD_HIP(g->hostOut.alloc((ns * 20 + ns + 1) * sizeof(int)));
+            int* h = reinterpret_cast<int*>(g->hostOut.p);
+            memset(h, 0, (ns * 20 + ns + 1) * sizeof(int));
+            g->d_best.alias(h, ns); g->d_total.alias(h + ns, ns); g->d_alphaExtra.alias(h + 2 * ns, ns);
+            g->d_flags.alias(h + 3 * ns, ns + 1); g->d_pos.alias(h + 4 * ns + 1, ns * 16);
+        } else
         EDLIB_AMD_HIP(g->d_alphaExtra.alloc(ns));
         EDLIB_AMD_HIP(g->d_peq.alloc(ns * (size_t)syms_ * w));
         EDLIB_AMD_HIP(g->d_segBest.alloc(ns * S)); EDLIB_AMD_HIP(g->d_segCnt.alloc(ns * S));
         EDLIB_AMD_HIP(g->d_segPos.alloc(ns * S * 8));
-        EDLIB_AMD_HIP(g->d_best.alloc(ns)); EDLIB_AMD_HIP(g->d_total.alloc(ns));
-        EDLIB_AMD_HIP(g->d_pos.alloc(ns * 16)); EDLIB_AMD_HIP(g->d_flags.alloc(ns + 1));
+        if (!g->zeroCopy) {
+            EDLIB_AMD_HIP(g->d_best.alloc(ns)); EDLIB_AMD_HIP(g->d_total.alloc(ns));
+            EDLIB_AMD_HIP(g->d_pos.alloc(ns * 16)); EDLIB_AMD_HIP(g->d_flags.alloc(ns + 1));
+        }
         groups_.push_back(std::move(g));
     }
     if (!groups_.empty()) {
@@ -448,7 +487,7 @@ hipError_t Batch::uploadEq8() {
 void Batch::scanTimerStart() {
     if (scanEventsUsed_ == scanEvents_.size()) {
         hipEvent_t a = nullptr, b = nullptr;
-        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        (void)pool_event(&a); (void)pool_event(&b);
         scanEvents_.push_back({a, b});
     }
     (void)hipEventRecord(scanEvents_[scanEventsUsed_].first, stream_);
@@ -611,8 +650,11 @@ int Batch::runReads()
         // ---- pass 2 (k-doubling): slots with nothing <= kFirst are rescanned with their full threshold
         if (twoPass) {
             std::vector<int> total(g.nslots);
-            EDLIB_AMD_HIP(hipMemcpyAsync(total.data(), g.d_total.p, (size_t)g.nslots * sizeof(int), hipMemcpyDeviceToHost, stream_));
-            EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+            if (g.zeroCopy) { EDLIB_AMD_HIP(hipStreamSynchronize(stream_)); memcpy(total.data(), g.d_total.p, (size_t)g.nslots * sizeof(int)); }
+            else {
+                EDLIB_AMD_HIP(hipMemcpyAsync(total.data(), g.d_total.p, (size_t)g.nslots * sizeof(int), hipMemcpyDeviceToHost, stream_));
+                EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+            }
             std::vector<int> todo;
             for (int s = 0; s < g.nslots; ++s) {
                 const int u = g.perm[s];
@@ -674,11 +716,13 @@ int Batch::runReads()
                 EDLIB_AMD_HIP(hipStreamSynchronize(stream_));            // temporaries die here
             }
         }
-        // census of slots whose end-location list did not fit
-        int* counter = g.d_flags.p + g.nslots;
-        EDLIB_AMD_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream_));
-        hipLaunchKernelGGL(count_flags_kernel, dim3((g.nslots + 255) / 256), dim3(256), 0, stream_,
-                           g.d_flags.p, g.nslots, counter);
+        // census of slots whose end-location list did not fit (small groups: counted on the host from the pinned flags)
+        if (!g.zeroCopy) {
+            int* counter = g.d_flags.p + g.nslots;
+            EDLIB_AMD_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream_));
+            hipLaunchKernelGGL(count_flags_kernel, dim3((g.nslots + 255) / 256), dim3(256), 0, stream_,
+                               g.d_flags.p, g.nslots, counter);
+        }
     }
     // exact second pass for the (rare) slots with more end locations than the first pass keeps.
     // Their best score b is already exact, so "score <= b" selects exactly the end locations:
@@ -690,12 +734,21 @@ int Batch::runReads()
         const size_t ns = (size_t)g.nslots;
         g.ovfSlots.clear(); g.ovfOff.assign(1, 0);
         int novf = 0;
-        EDLIB_AMD_HIP(hipMemcpyAsync(&novf, g.d_flags.p + g.nslots, sizeof(int), hipMemcpyDeviceToHost, stream_));
-        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+        if (g.zeroCopy) {
+            EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+            for (size_t s = 0; s < ns; ++s) novf += g.d_flags.p[s] != 0;
+        }
+        else {
+            EDLIB_AMD_HIP(hipMemcpyAsync(&novf, g.d_flags.p + g.nslots, sizeof(int), hipMemcpyDeviceToHost, stream_));
+            EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+        }
         if (novf <= 0 || mode == EDLIB_MODE_NW) continue;
         std::vector<int> flags(ns), total(ns);
-        EDLIB_AMD_HIP(hipMemcpyAsync(flags.data(), g.d_flags.p, ns * sizeof(int), hipMemcpyDeviceToHost, stream_));
-        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+        if (g.zeroCopy) memcpy(flags.data(), g.d_flags.p, ns * sizeof(int));
+        else {
+            EDLIB_AMD_HIP(hipMemcpyAsync(flags.data(), g.d_flags.p, ns * sizeof(int), hipMemcpyDeviceToHost, stream_));
+            EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+        }
         for (size_t s = 0; s < ns; ++s)
             if (flags[s] && g.perm[s] >= 0) g.ovfSlots.push_back((int)s);
         const size_t no = g.ovfSlots.size();
@@ -728,10 +781,10 @@ int Batch::runReads()
         EDLIB_AMD_HIP(hipStreamSynchronize(stream_));                    // temporaries die here
         stats.overflow_units += (int)no;
     }
-    if (banded) {
-        unsigned long long ws = 0;
-        EDLIB_AMD_HIP(hipMemcpy(&ws, d_wordSteps_.p, sizeof ws, hipMemcpyDeviceToHost));
-        stats.word_steps += (long long)ws;
+    if (banded) {            // read back with the run's final synchronisation (Batch::run)
+        EDLIB_AMD_HIP(h_wordSteps_.alloc(sizeof(unsigned long long)));
+        EDLIB_AMD_HIP(hipMemcpyAsync(h_wordSteps_.p, d_wordSteps_.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+        wordStepsPending_ = true;
     }
     return 0;
 }
@@ -745,10 +798,15 @@ int Batch::collectReads(std::vector<UnitResult>& res)
         ReadGroup& g = *gp;
         const size_t ns = (size_t)g.nslots;
         std::vector<int> best(ns), total(ns), extra(ns), pos(ns * 16), ovfPos((size_t)g.ovfOff.back());
+        if (g.zeroCopy) {                          // already on the host (run() synchronised the stream)
+            memcpy(best.data(), g.d_best.p, ns * sizeof(int)); memcpy(total.data(), g.d_total.p, ns * sizeof(int));
+            memcpy(extra.data(), g.d_alphaExtra.p, ns * sizeof(int)); memcpy(pos.data(), g.d_pos.p, ns * 16 * sizeof(int));
+        } else {
         EDLIB_AMD_HIP(hipMemcpyAsync(best.data(), g.d_best.p, ns * sizeof(int), hipMemcpyDeviceToHost, stream_));
         EDLIB_AMD_HIP(hipMemcpyAsync(total.data(), g.d_total.p, ns * sizeof(int), hipMemcpyDeviceToHost, stream_));
         EDLIB_AMD_HIP(hipMemcpyAsync(extra.data(), g.d_alphaExtra.p, ns * sizeof(int), hipMemcpyDeviceToHost, stream_));
         EDLIB_AMD_HIP(hipMemcpyAsync(pos.data(), g.d_pos.p, ns * 16 * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        }
         if (!ovfPos.empty())
             EDLIB_AMD_HIP(hipMemcpyAsync(ovfPos.data(), g.d_ovfPool.p, ovfPos.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
         EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
@@ -844,18 +902,49 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         // executed work: whole matrix, or one 64-block wave per column inside the band
         stats.word_steps += ring ? 2LL * ring * ((long long)s.tlen + nb - 1) : 2 * nb * (long long)s.tlen;
     }
-    EDLIB_AMD_HIP(d_descs_.ensure(n));
+    // A handful of units (edlibAlign() is one): the kernels write scores, positions and op strings straight into
+    // device-visible pinned host memory -- no download commands behind the launches, one stream synchronisation.
+    // (Descriptors still go up with a copy: the packed rings re-read them, and every read of host memory is a PCIe
+    // round trip.)  Larger chunks stage through HBM: a PCIe transaction per store does not scale.
+    const bool zeroCopy = n <= 16 && opsOff[n] <= (64 << 10) && pool_enabled();
+    PinBuf outPin;
+    int* hOut3 = nullptr; int* hPos = nullptr; int* hOpsLen = nullptr; long long* hOpsOff = nullptr;
+    std::shared_ptr<PinBuf> ops;
     EDLIB_AMD_HIP(d_peq64_.ensure((size_t)peqWords));
     EDLIB_AMD_HIP(d_aux_.ensure((size_t)auxInts));
-    // score / count / last of the chunk side by side: one copy brings all three back
-    EDLIB_AMD_HIP(d_out3_.ensure(3 * n));
+    if (zeroCopy) {
+        const size_t bytes = (3 * n + n * kPosCap + n) * sizeof(int) + (n + 1) * sizeof(long long);
+        EDLIB_AMD_HIP(outPin.alloc(bytes));
+        hOpsOff = reinterpret_cast<long long*>(outPin.p);
+        hOut3 = reinterpret_cast<int*>(hOpsOff + n + 1); hPos = hOut3 + 3 * n; hOpsLen = hPos + n * kPosCap;
+        memcpy(hOpsOff, opsOff.data(), (n + 1) * sizeof(long long));
+        EDLIB_AMD_HIP(d_descs_.ensure(n));
+        d_out3_.alias(hOut3, 3 * n); d_posPool_.alias(hPos, n * kPosCap);
+        d_opsLen_.alias(hOpsLen, n); d_opsOff_.alias(hOpsOff, n + 1);
+        if (wantPath && opsOff[n] > 0) {
+            ops = std::make_shared<PinBuf>();
+            EDLIB_AMD_HIP(ops->alloc((size_t)opsOff[n]));
+            d_ops_.alias(ops->p, (size_t)opsOff[n]);
+        }
+    } else {
+        if (!d_out3_.owned) d_out3_.release();
+        if (!d_posPool_.owned) d_posPool_.release();
+        if (!d_opsLen_.owned) d_opsLen_.release();
+        if (!d_opsOff_.owned) d_opsOff_.release();
+        if (!d_ops_.owned) d_ops_.release();
+        EDLIB_AMD_HIP(d_descs_.ensure(n));
+        // score / count / last of the chunk side by side: one copy brings all three back
+        EDLIB_AMD_HIP(d_out3_.ensure(3 * n));
+        EDLIB_AMD_HIP(d_posPool_.ensure(n * kPosCap));
+    }
     d_outScore_.alias(d_out3_.p, n); d_outCount_.alias(d_out3_.p + n, n); d_outLast_.alias(d_out3_.p + 2 * n, n);
-    EDLIB_AMD_HIP(d_posPool_.ensure(n * kPosCap));
     if (wantPath) {
         EDLIB_AMD_HIP(d_store_.ensure((size_t)storeEntries));
-        EDLIB_AMD_HIP(d_ops_.ensure((size_t)opsOff[n])); EDLIB_AMD_HIP(d_opsOff_.ensure(n + 1));
-        EDLIB_AMD_HIP(d_opsLen_.ensure(n));
-        EDLIB_AMD_HIP(hipMemcpyAsync(d_opsOff_.p, opsOff.data(), (n + 1) * sizeof(long long), hipMemcpyHostToDevice, stream_));
+        if (!zeroCopy) {
+            EDLIB_AMD_HIP(d_ops_.ensure((size_t)opsOff[n])); EDLIB_AMD_HIP(d_opsOff_.ensure(n + 1));
+            EDLIB_AMD_HIP(d_opsLen_.ensure(n));
+            EDLIB_AMD_HIP(hipMemcpyAsync(d_opsOff_.p, opsOff.data(), (n + 1) * sizeof(long long), hipMemcpyHostToDevice, stream_));
+        }
     }
     EDLIB_AMD_HIP(hipMemcpyAsync(d_descs_.p, descs, n * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
     EDLIB_AMD_HIP(uploadEq8());
@@ -885,13 +974,18 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     if (lap.on) { EDLIB_AMD_HIP(hipStreamSynchronize(stream_)); lap("chunk: kernels"); }
     std::vector<int> out3(3 * n), pool, opsLen;
     const int* score = out3.data(); const int* count = score + n; const int* last = count + n;
-    std::shared_ptr<PinBuf> ops;
-    EDLIB_AMD_HIP(hipMemcpyAsync(out3.data(), d_out3_.p, 3 * n * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    if (wantPositions) {
+    if (zeroCopy) {
+        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+        memcpy(out3.data(), hOut3, 3 * n * sizeof(int));
+        if (wantPositions) pool.assign(hPos, hPos + n * kPosCap);
+        if (wantPath) { opsLen.assign(hOpsLen, hOpsLen + n); if (ops) out.opsBufs.push_back(ops); }
+    }
+    if (!zeroCopy) EDLIB_AMD_HIP(hipMemcpyAsync(out3.data(), d_out3_.p, 3 * n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    if (wantPositions && !zeroCopy) {
         pool.resize(n * kPosCap);
         EDLIB_AMD_HIP(hipMemcpyAsync(pool.data(), d_posPool_.p, n * kPosCap * sizeof(int), hipMemcpyDeviceToHost, stream_));
     }
-    if (wantPath) {
+    if (wantPath && !zeroCopy) {
         opsLen.resize(n);
         EDLIB_AMD_HIP(hipMemcpyAsync(opsLen.data(), d_opsLen_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
         if (opsOff[n] > 0) {
@@ -956,6 +1050,10 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         }
     }
     lap("chunk: host gather");
+    if (zeroCopy) {          // the views into this chunk's pinned block die with it
+        d_out3_.release(); d_posPool_.release(); d_opsLen_.release(); d_opsOff_.release(); d_ops_.release();
+        d_outScore_.release(); d_outCount_.release(); d_outLast_.release();
+    }
     return 0;
 }
 
@@ -1317,7 +1415,14 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
         return est <= 2.0 * ring_max_k(64) ? nl - 1 : nl;               // far above every band: straight to the strips
     };
     std::vector<int> lvl(n);
-    for (size_t i = 0; i < n; ++i) lvl[i] = bandOff ? nl : first_level(i);
+    // A few units do not fill the chip at any ring size: a level then costs its ~T dependent steps on one wave
+    // whether it succeeds or not (a 10 kb pair: 1.7 ms per level), so units with more blocks than a ring holds
+    // go straight to whole-wave rings (K = 3968) instead of climbing.
+    const bool fewUnits = n <= 512 && rate == 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        lvl[i] = bandOff ? nl : first_level(i);
+        if (!bandOff && fewUnits && lvl[i] < nl - 1 && blocks(i) > ringOf[lvl[i]]) lvl[i] = nl - 1;
+    }
     for (int l = 0; l <= nl; ++l) {
         std::vector<UnitSpec> sel; std::vector<size_t> who;
         for (size_t i = 0; i < n; ++i) {
@@ -1470,6 +1575,7 @@ int Batch::run()
     float ms = 0;
     EDLIB_AMD_HIP(hipEventElapsedTime(&ms, evRun0_.e, evRun1_.e));
     stats.run_ms = ms;
+    if (wordStepsPending_) { stats.word_steps += (long long)*reinterpret_cast<unsigned long long*>(h_wordSteps_.p); wordStepsPending_ = false; }
     for (size_t i = 0; i < scanEventsUsed_; ++i) {
         float t = 0;
         EDLIB_AMD_HIP(hipEventElapsedTime(&t, scanEvents_[i].first, scanEvents_[i].second));
@@ -1585,10 +1691,19 @@ int Batch::resultsFlat(int* status, int* editDistance, int* numLocations, int* a
 int align_one(const char* q, int qn, const char* t, int tn, EdlibAlignConfig cfg, EdlibAlignResult* out)
 {
     const long long qoff[2] = {0, qn}, toff[2] = {0, tn};
-    Batch b;
-    if (b.init(q, qoff, 1, t, toff, 1, cfg, default_device())) return 1;
-    if (b.run()) return 1;
-    return b.results(out);
+    Lap lap;
+    int rc;
+    {
+        Batch b;
+        if (b.init(q, qoff, 1, t, toff, 1, cfg, default_device())) return 1;
+        lap("one: init");
+        if (b.run()) return 1;
+        lap("one: run");
+        rc = b.results(out);
+        lap("one: results");
+    }
+    lap("one: destroy");
+    return rc;
 }
 
 }  // namespace edlib_amd

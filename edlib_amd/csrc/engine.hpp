@@ -105,12 +105,14 @@ private:
         DevBuf<int> d_perm, d_qlen, d_kinit, d_alphaExtra, d_segBest, d_segCnt, d_segPos;
         DevBuf<int> d_best, d_total, d_pos, d_flags;
         DevBuf<uint32_t> d_peq;
+        bool zeroCopy = false; PinBuf hostOut;   // small groups: d_best / d_total / d_alphaExtra / d_flags / d_pos are views into pinned host memory
         // exact second pass of the last run: overflowing slots, their offsets into d_ovfPool
         std::vector<int> ovfSlots; std::vector<long long> ovfOff; DevBuf<int> d_ovfPool;
     };
     std::vector<std::unique_ptr<ReadGroup>> groups_;
     DevBuf<uint32_t> d_tpk_, d_trows_;
     DevBuf<unsigned long long> d_wordSteps_;
+    PinBuf h_wordSteps_; bool wordStepsPending_ = false;
     bool banded_ = false;        // HW groups use the Ukkonen-banded kernel with k-doubling
     int syms_ = 4;               // Peq rows per word of the reads kernels: target symbols rounded up to 4, 8 or 16
     int runReads();                                   // device work only; results stay in HBM

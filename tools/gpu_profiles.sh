@@ -47,9 +47,11 @@ if [ -z "$SKIP_PMC" ]; then
   pmc write_c2_1M "WRITE_SIZE" --steps 1 --warmup 0
   pmc sq1_c2_262k "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" --reads 262144 --steps 1 --warmup 0
   pmc sq2_c2_262k "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU" --reads 262144 --steps 1 --warmup 0
-  pmc fetch_c4 "FETCH_SIZE" --config 4 --steps 1 --warmup 0
-  pmc write_c4 "WRITE_SIZE" --config 4 --steps 1 --warmup 0
-  pmc sq1_c4 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH" --config 4 --steps 1 --warmup 0
-  pmc sq2_c4 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" --config 4 --steps 1 --warmup 0
+  # config 4 at 20,000 units: the counter passes serialise the dispatches and the full 100,000 ran into the timeout
+  pmc fetch_c4_20k "FETCH_SIZE" --config 4 --units 20000 --steps 1 --warmup 0
+  pmc write_c4_20k "WRITE_SIZE" --config 4 --units 20000 --steps 1 --warmup 0
+  pmc sq1_c4_20k "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH" --config 4 --units 20000 --steps 1 --warmup 0
+  pmc sq2_c4_20k "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" --config 4 --units 20000 --steps 1 --warmup 0
 fi
+( cd $ROOT && timeout 300 build/latency edlib_amd/libedlib.so > $OUT/${R}_latency_engine.json; timeout 300 build/latency oracle/_ref/libedlib_ref.so > $OUT/${R}_latency_reference.json; cat $OUT/${R}_latency_*.json; timeout 600 python tools/bench_wide.py > $OUT/${R}_wide_target.json; cat $OUT/${R}_wide_target.json )
 ls $OUT

@@ -1,27 +1,27 @@
 #!/usr/bin/env python3
-"""profiles/hbm_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
-HBM bytes per step of the scan kernel = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 summed over the scan
-launches of one step (MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reads exactly half of a wide
-coalesced stream -- confirmed here on pack_target_2bit_kernel: 2449 KB reported for a 5,000,000-byte
-16-B-per-lane read -- and WRITE_SIZE matched the known 1.25 MB / 24 MB stores of the pack and Peq
-kernels; the scan kernel's own loads are 4 B per lane and scalar, so the factor 2 is an upper bound)."""
-import csv, json, sys, collections
-
-def total(path, counter, kernel_substr):
-    acc = 0.0; n = 0
-    for row in csv.DictReader(open(path)):
-        if row["Counter_Name"] == counter and kernel_substr in row["Kernel_Name"]:
-            acc += float(row["Counter_Value"]); n += 1
-    return acc, n
-
-fetch_csv, write_csv, steps, reads, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-f, nf = total(fetch_csv, "FETCH_SIZE", "scan_reads")
-w, nw = total(write_csv, "WRITE_SIZE", "scan_reads")
-per_step = (2 * f + w) * 1024 / steps
-json.dump({"bytes_per_launch": int(per_step), "unit": "HBM bytes per step (all scan launches of one step)",
-           "fetch_size_kb_per_step": f / steps, "write_size_kb_per_step": w / steps,
-           "scan_launches_per_step": nf / steps, "reads": reads,
-           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes on `bench.py --reads %d --steps %d --warmup 0 "
-                     "--no-cpu-baseline`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE half-count correction)" % (reads, steps)},
-          open(out, "w"), indent=1)
-print(open(out).read())
+"""profiles/<R>_pmc_fetch_c2_1M.csv + <R>_pmc_write_c2_1M.csv (tools/gpu_profiles.sh) -> profiles/hbm_traffic.json,
+which bench.py copies into `roofline.traffic` TOGETHER WITH the commit the counters were taken at (it is a
+measurement of that commit, not of the timed run).  bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE on
+gfx950 reports half the bytes of a wide coalesced read (MI355X_MICROARCH.md §HBM; confirmed here on
+pack_target_2bit_kernel: 2458 KB reported for its 5,000,000-byte read)."""
+import csv, json, subprocess, sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
+out = {"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 0 "
+                 "--no-cpu-baseline --no-e2e` (tools/gpu_profiles.sh); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024", "configs": {}}
+for cfg, tag, units in (("2", "c2_1M", 1000000),):
+    items = {}
+    for ctr, fn in (("fetch_kb", "%s_pmc_fetch_%s.csv" % (R, tag)), ("write_kb", "%s_pmc_write_%s.csv" % (R, tag))):
+        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", fn))):
+            if "edlib_amd" not in r["Kernel_Name"]:
+                continue
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("edlib_amd::", "")
+            items.setdefault(k, {"fetch_kb": 0.0, "write_kb": 0.0, "dispatches": 0})
+            items[k][ctr] += float(r["Sum"]); items[k]["dispatches"] = int(r["Dispatches"])
+    total = sum(2 * v["fetch_kb"] + v["write_kb"] for v in items.values()) * 1024
+    for v in items.values():
+        v["bytes"] = int((2 * v["fetch_kb"] + v["write_kb"]) * 1024)
+    out["configs"][cfg] = {"units": units, "commit": commit, "bytes_per_step": int(total), "per_kernel": items}
+json.dump(out, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+print(json.dumps({k: v["bytes_per_step"] for k, v in out["configs"].items()}))
