@@ -22,6 +22,7 @@
 #include <cstdarg>
 #include <cstring>
 #include <mutex>
+#include <thread>
 
 namespace edlib_amd {
 
@@ -649,12 +650,14 @@ int Batch::runReads()
                                             g.d_flags.p, stream_));
         // ---- pass 2 (k-doubling): slots with nothing <= kFirst are rescanned with their full threshold
         if (twoPass) {
-            std::vector<int> total(g.nslots);
-            if (g.zeroCopy) { EDLIB_AMD_HIP(hipStreamSynchronize(stream_)); memcpy(total.data(), g.d_total.p, (size_t)g.nslots * sizeof(int)); }
-            else {
-                EDLIB_AMD_HIP(hipMemcpyAsync(total.data(), g.d_total.p, (size_t)g.nslots * sizeof(int), hipMemcpyDeviceToHost, stream_));
-                EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+            PinBuf totalPin;                               // pinned: the copy runs at link rate
+            const int* total = g.d_total.p;
+            if (!g.zeroCopy) {
+                EDLIB_AMD_HIP(totalPin.alloc((size_t)g.nslots * sizeof(int)));
+                EDLIB_AMD_HIP(hipMemcpyAsync(totalPin.p, g.d_total.p, (size_t)g.nslots * sizeof(int), hipMemcpyDeviceToHost, stream_));
+                total = reinterpret_cast<const int*>(totalPin.p);
             }
+            EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
             std::vector<int> todo;
             for (int s = 0; s < g.nslots; ++s) {
                 const int u = g.perm[s];
@@ -797,15 +800,22 @@ int Batch::collectReads(std::vector<UnitResult>& res)
     for (auto& gp : groups_) {
         ReadGroup& g = *gp;
         const size_t ns = (size_t)g.nslots;
-        std::vector<int> best(ns), total(ns), extra(ns), pos(ns * 16), ovfPos((size_t)g.ovfOff.back());
-        if (g.zeroCopy) {                          // already on the host (run() synchronised the stream)
-            memcpy(best.data(), g.d_best.p, ns * sizeof(int)); memcpy(total.data(), g.d_total.p, ns * sizeof(int));
-            memcpy(extra.data(), g.d_alphaExtra.p, ns * sizeof(int)); memcpy(pos.data(), g.d_pos.p, ns * 16 * sizeof(int));
+        // merged per-slot results: read in place when they already live in pinned host memory (small groups), else
+        // downloaded into pinned staging (a copy into pageable memory runs at a fraction of the link rate: 64 bytes
+        // per read were 20 ms per 1M reads)
+        std::vector<int> ovfPos((size_t)g.ovfOff.back());
+        PinBuf stage;
+        const int *best, *total, *extra, *pos;
+        if (g.zeroCopy) {                          // run() synchronised the stream
+            best = g.d_best.p; total = g.d_total.p; extra = g.d_alphaExtra.p; pos = g.d_pos.p;
         } else {
-        EDLIB_AMD_HIP(hipMemcpyAsync(best.data(), g.d_best.p, ns * sizeof(int), hipMemcpyDeviceToHost, stream_));
-        EDLIB_AMD_HIP(hipMemcpyAsync(total.data(), g.d_total.p, ns * sizeof(int), hipMemcpyDeviceToHost, stream_));
-        EDLIB_AMD_HIP(hipMemcpyAsync(extra.data(), g.d_alphaExtra.p, ns * sizeof(int), hipMemcpyDeviceToHost, stream_));
-        EDLIB_AMD_HIP(hipMemcpyAsync(pos.data(), g.d_pos.p, ns * 16 * sizeof(int), hipMemcpyDeviceToHost, stream_));
+            EDLIB_AMD_HIP(stage.alloc(ns * 19 * sizeof(int)));
+            int* h = reinterpret_cast<int*>(stage.p);
+            EDLIB_AMD_HIP(hipMemcpyAsync(h, g.d_best.p, ns * sizeof(int), hipMemcpyDeviceToHost, stream_));
+            EDLIB_AMD_HIP(hipMemcpyAsync(h + ns, g.d_total.p, ns * sizeof(int), hipMemcpyDeviceToHost, stream_));
+            EDLIB_AMD_HIP(hipMemcpyAsync(h + 2 * ns, g.d_alphaExtra.p, ns * sizeof(int), hipMemcpyDeviceToHost, stream_));
+            EDLIB_AMD_HIP(hipMemcpyAsync(h + 3 * ns, g.d_pos.p, ns * 16 * sizeof(int), hipMemcpyDeviceToHost, stream_));
+            best = h; total = h + ns; extra = h + 2 * ns; pos = h + 3 * ns;
         }
         if (!ovfPos.empty())
             EDLIB_AMD_HIP(hipMemcpyAsync(ovfPos.data(), g.d_ovfPool.p, ovfPos.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -822,7 +832,7 @@ int Batch::collectReads(std::vector<UnitResult>& res)
                     finalize_semiglobal(r, cfg_.k, m, best[s], ovfPos.data() + g.ovfOff[oi], g.ovfOff[oi + 1] - g.ovfOff[oi]);
                     ++oi;
                 } else {
-                    finalize_semiglobal(r, cfg_.k, m, best[s], pos.data() + s * 16, best[s] < 0 ? 0 : total[s]);
+                    finalize_semiglobal(r, cfg_.k, m, best[s], pos + s * 16, best[s] < 0 ? 0 : total[s]);
                 }
             } else {
                 finalize_global(r, cfg_.k, (int)cfg_.mode, T, best[s]);
@@ -1505,9 +1515,10 @@ int Batch::run()
         if (alphabetLengths(rest, res)) return 1;
     }
     lap("run: phase 1 (distance)");
-    std::vector<int> live;                     // non-empty units with a solution
-    for (int u = 0; u < n_; ++u)
-        if (qlen(u) > 0 && tlen(u) > 0 && res[u].editDistance >= 0) live.push_back(u);
+    std::vector<int> live;                     // non-empty units with a solution (only the later phases want them)
+    if (cfg_.task == EDLIB_TASK_LOC || cfg_.task == EDLIB_TASK_PATH)
+        for (int u = 0; u < n_; ++u)
+            if (qlen(u) > 0 && tlen(u) > 0 && res[u].editDistance >= 0) live.push_back(u);
 
     // ---- phase 2: start locations (edlib.cpp:228-272)
     if (cfg_.task == EDLIB_TASK_LOC || cfg_.task == EDLIB_TASK_PATH) {
@@ -1582,14 +1593,25 @@ int Batch::run()
         stats.scan_ms += t;
     }
     // algorithmic bytes: target + query + Peq + result header + end locations
-    stats.algo_bytes = 0;
-    for (int u = 0; u < n_; ++u) {
-        const long long m = qlen(u);
-        // (sigma+1) Peq rows; units still resident on the device are priced with sigma = |target alphabet|
-        // and one end location
-        const long long sigma = res[u].alphabetLength ? res[u].alphabetLength : tab_.sigmaT;
-        stats.algo_bytes += tlen(u) + m + 8LL * (sigma + 1) * ((m + 63) / 64) + 16
-                            + 4LL * std::max<long long>(1, (long long)res[u].ends.size());
+    if (!readsCollected_ && pairUnits_.empty() && emptyUnits_.empty()) {
+        // everything is still resident on the device (reads path, TASK_DISTANCE): every unit is priced with
+        // sigma = |target alphabet| and one end location -- a constant of the batch, summed once
+        if (algoBase_ < 0) {
+            algoBase_ = 0;
+            for (int u = 0; u < n_; ++u) {
+                const long long m = qlen(u);
+                algoBase_ += tlen(u) + m + 8LL * (tab_.sigmaT + 1) * ((m + 63) / 64) + 16 + 4;
+            }
+        }
+        stats.algo_bytes = algoBase_;
+    } else {
+        stats.algo_bytes = 0;
+        for (int u = 0; u < n_; ++u) {
+            const long long m = qlen(u);
+            const long long sigma = res[u].alphabetLength ? res[u].alphabetLength : tab_.sigmaT;
+            stats.algo_bytes += tlen(u) + m + 8LL * (sigma + 1) * ((m + 63) / 64) + 16
+                                + 4LL * std::max<long long>(1, (long long)res[u].ends.size());
+        }
     }
     results_.swap(res);
     haveResults_ = true;
@@ -1613,24 +1635,34 @@ int Batch::results(EdlibAlignResult* out)
         EDLIB_AMD_HIP(guard.status);
         if (collectReads(results_)) return 1;
     }
-    for (int u = 0; u < n_; ++u) {
-        const UnitResult& r = results_[u];
-        EdlibAlignResult& o = out[u];
-        o.status = r.status;
-        o.editDistance = r.editDistance;
-        o.endLocations = nullptr; o.startLocations = nullptr; o.numLocations = 0;
-        o.alignment = nullptr; o.alignmentLength = 0;
-        o.alphabetLength = r.alphabetLength;
-        if (r.hasEnds) { o.endLocations = malloc_ints(r.ends); o.numLocations = (int)r.ends.size(); }
-        if (r.hasStarts) o.startLocations = malloc_ints(r.starts);
-        if (r.hasAlignment) {
-            const uint8_t* src = r.opsView ? r.opsView : r.ops.data();
-            const size_t len = r.opsView ? (size_t)r.opsViewLen : r.ops.size();
-            o.alignment = static_cast<unsigned char*>(malloc(std::max<size_t>(len, 1)));
-            if (len) memcpy(o.alignment, src, len);
-            o.alignmentLength = (int)len;
+    auto marshal = [&](int lo, int hi) {
+        for (int u = lo; u < hi; ++u) {
+            const UnitResult& r = results_[u];
+            EdlibAlignResult& o = out[u];
+            o.status = r.status;
+            o.editDistance = r.editDistance;
+            o.endLocations = nullptr; o.startLocations = nullptr; o.numLocations = 0;
+            o.alignment = nullptr; o.alignmentLength = 0;
+            o.alphabetLength = r.alphabetLength;
+            if (r.hasEnds) { o.endLocations = malloc_ints(r.ends); o.numLocations = (int)r.ends.size(); }
+            if (r.hasStarts) o.startLocations = malloc_ints(r.starts);
+            if (r.hasAlignment) {
+                const uint8_t* src = r.opsView ? r.opsView : r.ops.data();
+                const size_t len = r.opsView ? (size_t)r.opsViewLen : r.ops.size();
+                o.alignment = static_cast<unsigned char*>(malloc(std::max<size_t>(len, 1)));
+                if (len) memcpy(o.alignment, src, len);
+                o.alignmentLength = (int)len;
+            }
         }
-    }
+    };
+    // one malloc per array is the reference's ownership contract (edlib.h:177-205); a million of them are worth a
+    // few threads (glibc arenas are per thread; free() of a block from any thread is fine)
+    if (n_ >= 65536) {
+        const int nthreads = 6;
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t) th.emplace_back(marshal, (int)((long long)n_ * t / nthreads), (int)((long long)n_ * (t + 1) / nthreads));
+        for (auto& x : th) x.join();
+    } else marshal(0, n_);
     return 0;
 }
 

@@ -162,6 +162,7 @@ private:
 
     std::vector<UnitResult> results_;
     bool haveResults_ = false;
+    long long algoBase_ = -1;     // algorithmic bytes of the batch while its results are still on the device
 };
 
 // single-pair convenience used by edlibAlign()
