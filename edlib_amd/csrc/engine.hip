@@ -520,7 +520,7 @@ static void finalize_semiglobal(UnitResult& r, int kcfg, int m, int best, const 
     r.editDistance = best;
     r.hasEnds = true;
     if (W > 0 && best == m) r.ends.push_back(-1);
-    r.ends.insert(r.ends.end(), pos, pos + npos);
+    r.ends.append(pos, (size_t)npos);
 }
 
 static void finalize_global(UnitResult& r, int kcfg, int mode, int T, int score) {
@@ -696,7 +696,7 @@ int Batch::runReads()
                     EDLIB_AMD_HIP(hipMemcpyAsync(&ws, d_ws.p, sizeof ws, hipMemcpyDeviceToHost, stream_));
                     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
                     const double cols = (double)np2 * ((double)T + (double)(S3 - 1) * warm3);
-                    plain = syms_ == 4 && (double)ws >= 0.85 * g.nwords * cols;
+                    plain = syms_ == 4 && (double)ws >= 0.85 * g.nwords * cols && !getenv("EDLIB_AMD_PASS2_BANDED");
                     stats.word_steps += (long long)ws;
                 }
                 // The leftovers are scattered over the batch: through the slot map every lane of a wave would pull its
@@ -1466,9 +1466,24 @@ int Batch::run()
     stats.cells = cells;
     scanEventsUsed_ = 0;
     haveResults_ = false;
+    opsKeep_.clear();            // (the previous run's views die with the reset of their records below)
+    // TASK_DISTANCE over reads-path units only: nothing is assembled on the host until results() asks for it, so
+    // the per-unit records (160 bytes each) are not even allocated in the timed run
+    const bool lazy = cfg_.task == EDLIB_TASK_DISTANCE && pairUnits_.empty() && emptyUnits_.empty() && !groups_.empty();
+    // the records of the run before last are recycled (no 160-byte-per-unit allocation + page faults per run)
+    std::vector<UnitResult>& res = work_;
+    if (lazy) res.clear();
+    else {
+        const size_t keep = std::min(res.size(), (size_t)n_);
+        res.resize((size_t)n_);
+        for (size_t u = 0; u < keep; ++u) {
+            UnitResult& r = res[u];
+            r.status = EDLIB_STATUS_OK; r.editDistance = -1; r.alphabetLength = 0;
+            r.hasEnds = r.hasStarts = r.hasAlignment = false;
+            r.ends.clear(); r.starts.clear(); r.ops.clear(); r.opsView = nullptr; r.opsViewLen = 0;
+        }
+    }
     results_.clear();            // views of the previous run die before their staging blocks
-    opsKeep_.clear();
-    std::vector<UnitResult> res(n_);
     const int mode = (int)cfg_.mode;
     const int scanMode = (mode == EDLIB_MODE_HW || mode == EDLIB_MODE_SHW) ? mode : EDLIB_MODE_NW;
     EDLIB_AMD_HIP(hipEventRecord(evRun0_.e, stream_));
@@ -1515,14 +1530,16 @@ int Batch::run()
         if (alphabetLengths(rest, res)) return 1;
     }
     lap("run: phase 1 (distance)");
-    std::vector<int> live;                     // non-empty units with a solution (only the later phases want them)
+    std::vector<int>& live = live_;            // non-empty units with a solution (only the later phases want them)
+    live.clear();
     if (cfg_.task == EDLIB_TASK_LOC || cfg_.task == EDLIB_TASK_PATH)
         for (int u = 0; u < n_; ++u)
             if (qlen(u) > 0 && tlen(u) > 0 && res[u].editDistance >= 0) live.push_back(u);
 
     // ---- phase 2: start locations (edlib.cpp:228-272)
     if (cfg_.task == EDLIB_TASK_LOC || cfg_.task == EDLIB_TASK_PATH) {
-        std::vector<UnitSpec> units; std::vector<std::pair<int, int>> where;
+        std::vector<UnitSpec>& units = startUnits_; std::vector<std::pair<int, int>>& where = startWhere_;   // capacity kept across runs
+        units.clear(); where.clear();
         units.reserve(live.size() + live.size() / 8); where.reserve(live.size() + live.size() / 8);
         for (int u : live) {
             UnitResult& r = res[u];
@@ -1621,7 +1638,7 @@ int Batch::run()
 
 // ------------------------------------------------------------ marshalling
 
-static int* malloc_ints(const std::vector<int>& v) {
+static int* malloc_ints(const LocList& v) {
     int* p = static_cast<int*>(malloc(sizeof(int) * std::max<size_t>(v.size(), 1)));
     if (p && !v.empty()) memcpy(p, v.data(), v.size() * sizeof(int));
     return p;
@@ -1633,6 +1650,7 @@ int Batch::results(EdlibAlignResult* out)
     if (!readsCollected_) {
         DeviceGuard guard(device_);
         EDLIB_AMD_HIP(guard.status);
+        if (results_.size() != (size_t)n_) results_.assign((size_t)n_, UnitResult{});
         if (collectReads(results_)) return 1;
     }
     auto marshal = [&](int lo, int hi) {
@@ -1674,6 +1692,7 @@ int Batch::resultsFlat(int* status, int* editDistance, int* numLocations, int* a
     if (!haveResults_) { set_error("results() before a successful run()"); return 1; }
     if (!readsCollected_) {
         DeviceGuard guard(device_);
+        if (results_.size() != (size_t)n_) results_.assign((size_t)n_, UnitResult{});
         if (collectReads(results_)) return 1;
     }
     long long nloc = 0, naln = 0;

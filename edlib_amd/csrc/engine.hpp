@@ -48,6 +48,47 @@ struct OpsOut {
     std::vector<uint8_t> own;
 };
 
+// Location lists of a unit: almost always one or two entries, so they live inside the result record (a
+// std::vector here was two malloc / free pairs per read: most of what LOC / PATH cost on a read batch).
+class LocList {
+public:
+    LocList() = default;
+    LocList(const LocList& o) { assign_range(o.data(), o.n_); }
+    LocList& operator=(const LocList& o) { if (this != &o) assign_range(o.data(), o.n_); return *this; }
+    LocList(LocList&& o) noexcept : n_(o.n_), big_(std::move(o.big_)) { for (int i = 0; i < kInline; ++i) in_[i] = o.in_[i]; o.n_ = 0; }
+    LocList& operator=(LocList&& o) noexcept {
+        n_ = o.n_; big_ = std::move(o.big_); for (int i = 0; i < kInline; ++i) in_[i] = o.in_[i]; o.n_ = 0; return *this;
+    }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    const int* data() const { return n_ <= (size_t)kInline ? in_ : big_.data(); }
+    int* data() { return n_ <= (size_t)kInline ? in_ : big_.data(); }
+    int operator[](size_t i) const { return data()[i]; }
+    int& operator[](size_t i) { return data()[i]; }
+    void clear() { n_ = 0; big_.clear(); }
+    void push_back(int v) { append(&v, 1); }
+    void append(const int* p, size_t c) {
+        const size_t nn = n_ + c;
+        if (nn <= (size_t)kInline) { for (size_t i = 0; i < c; ++i) in_[n_ + i] = p[i]; }
+        else {
+            if (n_ <= (size_t)kInline) big_.assign(in_, in_ + n_);
+            big_.insert(big_.end(), p, p + c);
+        }
+        n_ = nn;
+    }
+    void assign(size_t c, int v) {
+        clear();
+        if (c <= (size_t)kInline) { for (size_t i = 0; i < c; ++i) in_[i] = v; } else big_.assign(c, v);
+        n_ = c;
+    }
+private:
+    void assign_range(const int* p, size_t c) { clear(); append(p, c); }
+    static const int kInline = 4;
+    size_t n_ = 0;
+    int in_[kInline];
+    std::vector<int> big_;
+};
+
 // Per-unit result assembled on the host before it is marshalled into
 // EdlibAlignResult (malloc'd arrays) by results().
 struct UnitResult {
@@ -55,7 +96,7 @@ struct UnitResult {
     int editDistance = -1;
     int alphabetLength = 0;
     bool hasEnds = false, hasStarts = false, hasAlignment = false;
-    std::vector<int> ends, starts;
+    LocList ends, starts;
     std::vector<uint8_t> ops;                 // owned op string, or ...
     const uint8_t* opsView = nullptr;         // ... a view into a staging block the batch keeps alive
     int opsViewLen = 0;
@@ -160,7 +201,8 @@ private:
     std::vector<std::pair<hipEvent_t, hipEvent_t>> scanEvents_;
     size_t scanEventsUsed_ = 0;
 
-    std::vector<UnitResult> results_;
+    std::vector<UnitResult> results_, work_;     // last run's records / the next run's (ping-pong: no reallocation per run)
+    std::vector<UnitSpec> startUnits_; std::vector<std::pair<int, int>> startWhere_; std::vector<int> live_;
     bool haveResults_ = false;
     long long algoBase_ = -1;     // algorithmic bytes of the batch while its results are still on the device
 };
