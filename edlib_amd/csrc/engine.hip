@@ -900,7 +900,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         const long long nb = (s.qlen + 63) / 64;
         nbMax = std::max(nbMax, nb);
         d.qoff = s.qoff; d.toff = s.toff; d.qlen = s.qlen; d.tlen = s.tlen; d.qstep = s.qstep; d.tstep = s.tstep;
-        d.kinit = s.kinit;
+        d.kinit = s.kinit; d.skip = s.skip;
         d.peqOff = peqWords; peqWords += nb * tab_.sigmaT;
         d.auxOff = auxInts; if (nb > 64 && !ring) auxInts += s.tlen;
         d.storeOff = storeEntries;
@@ -1332,7 +1332,60 @@ int Batch::solvePaths(const std::vector<Piece>& jobs, std::vector<OpsOut>& opsOu
 
 // SHW / HW units of at most 4 (16) blocks share a wave 16 (4) at a time on the lane rings; longer ones take
 // the strips.  Same outputs as solve().
+// HW is shift-invariant (a scan that starts 2m-1 columns early from the fresh state reproduces the
+// exact bottom-row scores of its own columns), and a unit of kernel W is one wave's serial walk over its target: a
+// 1 kb query against a 5 Mb chromosome is 5M dependent steps (0.3 s) while 1023 SIMDs idle.  When a batch of HW units
+// does not fill the chip, every unit with a long target is cut into target segments (each a unit of its own with a
+// warm-up that records nothing: UnitSpec::skip) and the segments' answers are merged: minimum score, the end
+// locations of the segments that attain it in order, the last of them.  Results never depend on the cut.
 int Batch::solveSemiGlobal(int mode, bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out)
+{
+    const size_t n = units.size();
+    const bool off = getenv("EDLIB_AMD_HWSEG") && getenv("EDLIB_AMD_HWSEG")[0] == '0';
+    if (mode != EDLIB_MODE_HW || n == 0 || n >= 4096 || off) return solveSemiGlobalUnits(mode, wantPositions, units, out);
+    const long long smax = std::max<long long>(1, 8192 / (long long)n);
+    std::vector<UnitSpec> sub; std::vector<int> firstSeg(n + 1, 0); std::vector<int> base;   // base: first recorded column of a segment
+    bool any = false;
+    for (size_t i = 0; i < n; ++i) {
+        const UnitSpec& u = units[i];
+        const long long segMin = std::max<long long>(4096, 8LL * u.qlen);
+        const long long S = std::max<long long>(1, std::min<long long>(smax, u.tlen / segMin));
+        const long long segLen = (u.tlen + S - 1) / S;
+        for (long long sg = 0; sg < S; ++sg) {
+            const long long c0 = sg * segLen, c1 = std::min<long long>(u.tlen, c0 + segLen);
+            if (c0 >= c1) break;
+            const long long cw = std::max<long long>(0, c0 - (2LL * u.qlen - 1));
+            UnitSpec v = u;
+            v.toff = u.toff + cw * u.tstep; v.tlen = (int)(c1 - cw); v.skip = (int)(c0 - cw);
+            sub.push_back(v); base.push_back((int)cw);
+        }
+        firstSeg[i + 1] = (int)sub.size();
+        any = any || firstSeg[i + 1] - firstSeg[i] > 1;
+    }
+    if (!any) return solveSemiGlobalUnits(mode, wantPositions, units, out);
+    SolveOut so;
+    if (solveSemiGlobalUnits(mode, wantPositions, sub, so)) return 1;
+    out.score.assign(n, -1); out.count.assign(n, 0); out.last.assign(n, -1);
+    out.posStart.assign(n + 1, 0); out.posFlat.clear();
+    out.opsPtr.assign(n, nullptr); out.opsLen.assign(n, 0); out.opsBufs.clear();
+    for (size_t i = 0; i < n; ++i) {
+        int best = -1;
+        for (int q = firstSeg[i]; q < firstSeg[i + 1]; ++q)
+            if (so.score[q] >= 0 && (best < 0 || so.score[q] < best)) best = so.score[q];
+        out.score[i] = best;
+        if (best >= 0)
+            for (int q = firstSeg[i]; q < firstSeg[i + 1]; ++q) {
+                if (so.score[q] != best) continue;
+                out.count[i] += so.count[q];
+                out.last[i] = so.last[q] + base[q];
+                for (long long k = so.posStart[q]; k < so.posStart[q + 1]; ++k) out.posFlat.push_back(so.posFlat[k] + base[q]);
+            }
+        out.posStart[i + 1] = (long long)out.posFlat.size();
+    }
+    return 0;
+}
+
+int Batch::solveSemiGlobalUnits(int mode, bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out)
 {
     const size_t n = units.size();
     const bool ringsOff = getenv("EDLIB_AMD_NWBAND") && getenv("EDLIB_AMD_NWBAND")[0] == '0';

@@ -29,6 +29,7 @@ struct UnitSpec {
     long long qoff; int qlen; int qstep;
     long long toff; int tlen; int tstep;
     int kinit;
+    int skip = 0;      // HW target segments: leading warm-up columns whose scores are not recorded
 };
 
 struct SolveOut {
@@ -184,6 +185,7 @@ private:
     int solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<int>& score);
     // SHW / HW units: short queries packed on 4- and 16-lane rings, the rest on the strips
     int solveSemiGlobal(int mode, bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out);
+    int solveSemiGlobalUnits(int mode, bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out);
     int alphabetLengths(const std::vector<int>& units, std::vector<UnitResult>& res);
     // linear-space paths (reference obtainAlignmentHirschberg, edlib.cpp:1231-1396)
     struct Piece { long long qoff; int m; long long toff; int T; int score; };

@@ -232,7 +232,7 @@ scan_pairs_kernel(const PairScanArgs a)
                     if (tracker) {
                         const u64 ph = ((u64)ph1 << 32) | ph0, mh = ((u64)mh1 << 32) | mh0;
                         sc += (int)((ph >> sh) & 1ull) - (int)((mh >> sh) & 1ull);
-                        if (MODE != 0 && sc <= best) {                   // edlib.cpp:658-673
+                        if (MODE != 0 && sc <= best && col >= d.skip) {  // edlib.cpp:658-673
                             if (sc < best) { best = sc; cnt = 0; }
                             if (cnt < d.posCap) pos[cnt] = col;
                             ++cnt;
@@ -536,7 +536,7 @@ scan_pairs_ring_kernel(const PairScanArgs a)
                 if (MODE != 0 && b == nb - 1) {
                     const u64 ph = ((u64)ph1 << 32) | ph0, mh = ((u64)mh1 << 32) | mh0;
                     sc += (int)((ph >> sh) & 1ull) - (int)((mh >> sh) & 1ull);
-                    if (sc <= best) {                                 // edlib.cpp:658-673
+                    if (sc <= best && col >= dp->skip) {              // edlib.cpp:658-673
                         if (sc < best) { best = sc; cnt = 0; }
                         if (cnt < dp->posCap) a.posPool[dp->posOff + cnt] = col;
                         ++cnt;

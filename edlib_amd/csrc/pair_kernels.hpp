@@ -27,6 +27,7 @@ struct PairDesc {
     long long colOff;    // first block of this unit's last-column dump (Hirschberg), or -1
     int bandT;           // banded NW kernel: target length that defines the band when the scan stops early
                          // at column tlen-1 (Hirschberg halves, edlib.cpp:1252-1260); 0 = tlen
+    int skip;            // SHW / HW tracking: columns before this one are warm-up and record nothing (HW target segments)
     int ring;            // layout of this unit's column store: 0 = strips (scan_pairs_kernel), else the ring
                          // size G of scan_pairs_ring_kernel (band of threshold kinit)
 };

@@ -219,3 +219,30 @@ def test_switches_do_not_change_results(engine):
         finally:
             del os.environ[var]
         assert got == base, var
+
+
+@pytest.mark.parametrize("m", [300, 700, 1100, 1500, 5000])
+def test_hw_long_queries_are_cut_into_target_segments(engine, oracle, m):
+    """a handful of HW units with long targets: kernel W cuts every target into segments (each a unit with a warm-up
+    of 2m-1 columns that records nothing) and merges them; scores, ALL end locations (several equal copies planted,
+    some straddling cuts), start locations and paths must be what one uncut scan gives (reference edlib.cpp:550-704)"""
+    import numpy as np
+    from edlib_amd import synth
+    T = 260_000
+    t = synth.random_dna(600 + m, T)
+    q0 = t[1000:1000 + m].copy()
+    # plant exact copies of the same stretch at several places (cut positions are multiples of T / S: cover a few)
+    for at in (40_000, 65_000 - m // 2, 129_990, 200_000, T - m):
+        t[at:at + m] = q0
+    q, _ = synth.mutate(q0, 601 + m, 0.02, 0.005, 0.005)
+    qs = [q, q0, synth.random_dna(602 + m, m)]             # edited copy, exact copy, unrelated
+    for task in ("distance", "locations", "path"):
+        got = engine.align_batch(qs, t, mode="HW", task=task, raw=True)
+        for i, qq in enumerate(qs):
+            want = oracle.align(qq.tobytes(), t.tobytes(), "HW", task, -1)
+            if want["status"] == 2:                         # Hirschberg regime not restated by the C oracle
+                continue
+            for f in ("editDistance", "endLocations", "startLocations", "numLocations", "alignment", "alphabetLength"):
+                assert got[i][f] == want[f], (m, task, i, f)
+    one = engine.align_raw(q.tobytes(), t.tobytes(), "HW", "locations", 40)
+    assert one == oracle.align(q.tobytes(), t.tobytes(), "HW", "locations", 40)
