@@ -246,3 +246,51 @@ def test_hw_long_queries_are_cut_into_target_segments(engine, oracle, m):
                 assert got[i][f] == want[f], (m, task, i, f)
     one = engine.align_raw(q.tobytes(), t.tobytes(), "HW", "locations", 40)
     assert one == oracle.align(q.tobytes(), t.tobytes(), "HW", "locations", 40)
+
+
+def test_round2_ring_sizes_8_and_21(engine, ref, oracle):
+    """The rings added in round 2 (8 lanes: K = 384, 21 lanes: K = 1216, both carried by ds_bpermute): distances
+    just below / at / above their limits, block counts right at 8 and 21 blocks, batches of >= 256 long units that
+    take the prefix probe and start on the 21-lane ring with a tail that climbs to 32, fixed k, and paths whose
+    storing scan lands on those rings (ring store row = block % 21)."""
+    rng = random.Random(4110 + SEED_SHIFT)
+    impl = _impl(ref, oracle)
+    qs, ts = [], []
+    for n, edits in ((7000, 370), (7000, 384), (7000, 385), (7000, 400), (12000, 1190), (12000, 1216), (12000, 1217), (12000, 1260)):
+        for _ in range(3):
+            q, t = _pair_with_edits(rng, n, edits, indel_frac=0.2)
+            qs.append(q); ts.append(t)
+    _check(engine, impl, qs, ts, "NW", "distance", -1, "8 / 21 thresholds")
+    for k in (383, 384, 385, 1215, 1216, 1217):
+        _check(engine, impl, qs, ts, "NW", "distance", k, "8 / 21 thresholds fixed k")
+    # block counts at the ring sizes, similar / divergent / unrelated
+    qs, ts = [], []
+    for m in (449, 511, 512, 513, 1280, 1343, 1344, 1345, 1408):
+        for rate in (0.01, 0.2):
+            t = synth.random_dna(rng.randrange(1 << 30), m + rng.randrange(-20, 21))
+            q, _ = synth.mutate(t, rng.randrange(1 << 30), rate, rate / 3, rate / 3)
+            q = q[:m] if len(q) >= m else np.concatenate([q, synth.random_dna(rng.randrange(1 << 30), m - len(q))])
+            qs.append(q.tobytes()); ts.append(t.tobytes())
+        qs.append(synth.random_dna(rng.randrange(1 << 30), m).tobytes()); ts.append(synth.random_dna(rng.randrange(1 << 30), m // 3 + 1).tobytes())
+    _check(engine, impl, qs, ts, "NW", "distance", -1, "8 / 21 blocks")
+    _check(engine, impl, [q for q in qs if len(q) < 1100], [t for q, t in zip(qs, ts) if len(q) < 1100], "NW", "path", -1, "8 / 21 blocks paths")
+    # paths of 3 kb pairs at distance ~250 (storing scan on 8-lane rings) and ~1000 (21-lane rings): Hirschberg regime
+    # (3000 x 3000 needs 20 * 47 * 3000 bytes > 1 MiB), so the leaves of the levels use the new rings too
+    qs, ts = [], []
+    for edits in (250, 330, 1000, 1150):
+        for _ in range(2):
+            q, t = _pair_with_edits(rng, 3000 if edits < 500 else 9000, edits, indel_frac=0.3)
+            qs.append(q); ts.append(t)
+    if ref is not None:
+        _check(engine, ref, qs, ts, "NW", "path", -1, "8 / 21 paths (Hirschberg)")
+    # >= 256 long units: probe, first level 21 lanes, a tail above 1216
+    qs, ts = [], []
+    for i in range(300):
+        t = synth.random_dna(rng.randrange(1 << 30), 10000)
+        rate = 0.038 if i % 10 else 0.046
+        q, _ = synth.mutate(t, rng.randrange(1 << 30), rate, rate, rate)
+        qs.append(q.tobytes()); ts.append(t.tobytes())
+    got = engine.align_pairs(qs, ts, mode="NW", task="distance", k=-1, raw=True)
+    for i in range(0, 300, 3):
+        want = impl.align(qs[i], ts[i], "NW", "distance", -1)
+        assert all(got[i][f] == want[f] for f in FIELDS), (i, got[i], want)
