@@ -12,7 +12,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Iin
 SRCS := $(CSRC)/reads_kernels.hip $(CSRC)/pair_kernels.hip $(CSRC)/engine.hip $(CSRC)/api.hip
 OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 
-all: edlib_amd/libedlib.so build/edlib-aligner-batch
+all: edlib_amd/libedlib.so build/edlib-aligner-batch build/latency
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hpp) include/edlib.h include/edlib_amd.h
 	@mkdir -p $(OBJDIR)
@@ -25,6 +25,11 @@ edlib_amd/libedlib.so: $(OBJS)
 build/edlib-aligner-batch: apps/aligner_batch.cpp edlib_amd/libedlib.so include/edlib.h include/edlib_amd.h
 	@mkdir -p build
 	g++ -O2 -std=c++14 -Iinclude apps/aligner_batch.cpp -Ledlib_amd -l:libedlib.so -Wl,-rpath,'$$ORIGIN/../edlib_amd' -o $@
+
+# microseconds per edlibAlign() call for any library with the edlib C ABI
+build/latency: tools/latency.cpp
+	@mkdir -p build
+	g++ -O2 -std=c++14 tools/latency.cpp -ldl -o $@
 
 oracle:
 	$(MAKE) -C oracle all
