@@ -6,9 +6,12 @@
 //
 //   * one wave64 = 64 queries ("slots") x one segment of the target; every
 //     lane owns one query, so the target symbol of a column is WAVE-UNIFORM:
-//     it comes from the 2-bit packed target as a scalar and picks which of the
-//     lane's four Peq rows feeds the column -- by M0 for an LDS read in the banded
-//     kernel, by a scalar 4-way branch over register rows in the plain one.  No
+//     it comes from the packed target as a scalar and picks which of the lane's
+//     Peq rows feeds the column -- in the banded kernel the target is stored as
+//     the LDS row offset itself (16 bits per column, s_load_dwordx8) and goes
+//     into M0 with one scalar instruction for a ds_read_addtid_b32 (4, 8 or 16
+//     rows per word: targets of up to 16 symbols); in the plain kernel a scalar
+//     4-way branch over register rows (2-bit packed target, four symbols).  No
 //     cross-lane traffic and no divergence in the DP itself.
 //   * the query column lives in VGPRs as NWD 32-bit words (Pv, Mv) instead of
 //     the reference's 64-bit blocks: 150 rows need 5 words (160 rows) rather
@@ -29,7 +32,8 @@
 //                                       k-doubling whose band is the whole query, and with EDLIB_AMD_BAND=0).
 //                                       All outputs are functions of the full DP matrix, so no band is
 //                                       needed for correctness and the kernel never branches on data.
-//   scan_reads_banded_kernel<NWD>       HW: Ukkonen band per wave + k-doubling (the bench kernel, §3b).
+//   scan_reads_banded_kernel<NWD, S>    HW: Ukkonen band per wave + k-doubling (the bench kernel, §3b); one wave per
+//                                       workgroup, S = 4 / 8 / 16 Peq rows per word.
 #include "reads_kernels.hpp"
 
 namespace edlib_amd {
@@ -386,14 +390,13 @@ hipError_t launch_scan_reads(int nwords, int mode, const ReadScanArgs& a, hipStr
 // Ukkonen band + k-doubling of the reference (edlib.cpp:197-217, 562, 602-630) re-expressed per WAVE:
 //   * the wave computes only the first `nw` words of the column (nw is wave-uniform, 1..NWD); rows
 //     below are known to exceed every lane's threshold k = best-so-far (<= min(kinit, kcap));
-//   * nw is re-evaluated once per packed target dword (16 columns) from the exact score S of the
-//     last active word's bottom row (popcounts of Pv/Mv: with HW's zero row -1, D[r] = sum of the
-//     vertical deltas above r).  A cell changes by at most 1 per column, so
-//        S >  k+16        -> no row below becomes <= k within the next 16 columns (no growth needed)
-//        S <= k+16 (any lane) -> take one more word, entering as "+1 per row" like the reference's
+//   * nw is re-evaluated from the computed score S of the band's bottom row (popcounts of Pv/Mv: with HW's zero
+//     row -1, D[r] = sum of the vertical deltas above r) every c = 4 columns at one word, 8 at two, 16 above
+//     (band_quad has the rules and why they are sound):
+//        S <= k + c - 1 (any lane) -> take one more word, entering as "+1 per row" like the reference's
 //                               new block (edlib.cpp:605-608: P = ~0, M = 0)
-//        all lanes: every cell of the last word and the 16 rows above it exceed k -> drop the word
-//                               (edlib.cpp:610-612; bound from both neighbouring word scores)
+//        all lanes: every cell of the last word and the rows the next interval needs above it exceed k -> drop
+//                               the word (edlib.cpp:610-612; bounds from the word's boundary scores)
 //   * the bottom query row (bit (m-1)%32 of the last word) is only in the band while nw == NWD, so
 //     its score is only followed then; e = score - best - 1 is tracked instead of score, its sign bit is
 //     OR-ed into `flag`, and once per 4 columns a WAVE-UNIFORM test (ballot) enters the rare path,
@@ -464,7 +467,6 @@ __device__ __forceinline__ void lds_rows_request(u32 (&n)[NA], const u32 lo, con
 {
     static_assert(NA >= 1 && NA <= 8, "band height");
     const u32 pr = (J < 2) ? lo : hi;
-#define EDLIB_AMD_SET ((J & 1) ? EDLIB_AMD_M0_ODD("%[pr]") : EDLIB_AMD_M0_EVEN("%[pr]"))
     if constexpr (NA == 1) { if constexpr (J & 1) asm volatile(EDLIB_AMD_M0_ODD("%[pr]") "s_nop 0\n\t" EDLIB_AMD_RD("%0", 0) : "=v"(n[0]) : [pr] "s"(pr) : "memory", "scc");
                              else asm volatile(EDLIB_AMD_M0_EVEN("%[pr]") "s_nop 0\n\t" EDLIB_AMD_RD("%0", 0) : "=v"(n[0]) : [pr] "s"(pr) : "memory", "scc"); }
 #define EDLIB_AMD_WOFF [w1] "n"(S * 256), [w2] "n"(S * 512), [w3] "n"(S * 768), [w4] "n"(S * 1024), [w5] "n"(S * 1280), [w6] "n"(S * 1536), [w7] "n"(S * 1792)
@@ -493,7 +495,6 @@ __device__ __forceinline__ void lds_rows_request(u32 (&n)[NA], const u32 lo, con
     if constexpr (NA == 6) EDLIB_AMD_ROWS_ASM(R6, O6)
     if constexpr (NA == 7) EDLIB_AMD_ROWS_ASM(R7, O7)
     if constexpr (NA == 8) EDLIB_AMD_ROWS_ASM(R8, O8)
-#undef EDLIB_AMD_SET
 }
 template <int NA>
 __device__ __forceinline__ void lds_rows_wait(u32 (&n)[NA])
