@@ -426,8 +426,10 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
         std::copy(byWords[w].begin(), byWords[w].end(), g->perm.begin());
         const int nrblk = g->nslots / 64;
         if (mode == EDLIB_MODE_HW) {
-            // enough waves to fill 256 CUs x 4 SIMDs several times over, segments >= 4096 columns
-            long long S = (65536 + nrblk - 1) / nrblk;
+            // enough waves to fill 256 CUs x 4 SIMDs x 8 slots many times over, segments >= 4096 columns
+            // ~16 waves per resident slot: the launch ends on a thin tail (65,536 -> 131,072 waves: +1 % at 1M reads)
+            static const long long wantWaves = getenv("EDLIB_AMD_WAVES") ? atoll(getenv("EDLIB_AMD_WAVES")) : 131072;
+            long long S = (wantWaves + nrblk - 1) / nrblk;
             const long long maxS = std::min(65535, std::max(1, T / 4096));     // gridDim.y limit
             S = std::max(1LL, std::min(S, maxS));
             g->segLen = roundup((int)((T + S - 1) / S), 16);
