@@ -1522,6 +1522,7 @@ int Batch::run()
     scanEventsUsed_ = 0;
     haveResults_ = false;
     opsKeep_.clear();            // (the previous run's views die with the reset of their records below)
+    opsOwned_.clear();
     // TASK_DISTANCE over reads-path units only: nothing is assembled on the host until results() asks for it, so
     // the per-unit records (160 bytes each) are not even allocated in the timed run
     const bool lazy = cfg_.task == EDLIB_TASK_DISTANCE && pairUnits_.empty() && emptyUnits_.empty() && !groups_.empty();
@@ -1535,7 +1536,7 @@ int Batch::run()
             UnitResult& r = res[u];
             r.status = EDLIB_STATUS_OK; r.editDistance = -1; r.alphabetLength = 0;
             r.hasEnds = r.hasStarts = r.hasAlignment = false;
-            r.ends.clear(); r.starts.clear(); r.ops.clear(); r.opsView = nullptr; r.opsViewLen = 0;
+            r.ends.clear(); r.starts.clear(); r.opsView = nullptr; r.opsViewLen = 0;
         }
     }
     results_.clear();            // views of the previous run die before their staging blocks
@@ -1635,7 +1636,10 @@ int Batch::run()
             const int m = qlen(u);
             const int s = r.starts[0], e = r.ends[0];
             const int len = e - s + 1;
-            if (len <= 0) { r.ops.assign(m, EDLIB_EDOP_INSERT); r.hasAlignment = true; continue; }   // :1168-1175
+            if (len <= 0) {                                                                         // :1168-1175
+                opsOwned_.emplace_back((size_t)m, (uint8_t)EDLIB_EDOP_INSERT);
+                r.opsView = opsOwned_.back().data(); r.opsViewLen = m; r.hasAlignment = true; continue;
+            }
             jobs.push_back(Piece{qoff_[u], m, tbase(u) + s, len, r.editDistance});
             where.push_back(u);
         }
@@ -1646,8 +1650,10 @@ int Batch::run()
             for (size_t i = 0; i < jobs.size(); ++i) {
                 UnitResult& r = res[where[i]];
                 if (st[i] != EDLIB_STATUS_OK) { r.status = EDLIB_STATUS_ERROR; continue; }
-                if (!ops[i].own.empty()) r.ops.swap(ops[i].own);
-                else { r.opsView = ops[i].p; r.opsViewLen = ops[i].len; }
+                if (!ops[i].own.empty()) {
+                    opsOwned_.emplace_back(std::move(ops[i].own));
+                    r.opsView = opsOwned_.back().data(); r.opsViewLen = (int)opsOwned_.back().size();
+                } else { r.opsView = ops[i].p; r.opsViewLen = ops[i].len; }
                 r.hasAlignment = true;
             }
         }
@@ -1720,8 +1726,8 @@ int Batch::results(EdlibAlignResult* out)
             if (r.hasEnds) { o.endLocations = malloc_ints(r.ends); o.numLocations = (int)r.ends.size(); }
             if (r.hasStarts) o.startLocations = malloc_ints(r.starts);
             if (r.hasAlignment) {
-                const uint8_t* src = r.opsView ? r.opsView : r.ops.data();
-                const size_t len = r.opsView ? (size_t)r.opsViewLen : r.ops.size();
+                const uint8_t* src = r.opsView;
+                const size_t len = (size_t)r.opsViewLen;
                 o.alignment = static_cast<unsigned char*>(malloc(std::max<size_t>(len, 1)));
                 if (len) memcpy(o.alignment, src, len);
                 o.alignmentLength = (int)len;
@@ -1760,7 +1766,7 @@ int Batch::resultsFlat(int* status, int* editDistance, int* numLocations, int* a
         if (locOffsets) locOffsets[u] = nloc;
         if (alnOffsets) alnOffsets[u] = naln;
         nloc += r.hasEnds ? (long long)r.ends.size() : 0;
-        naln += r.hasAlignment ? (long long)(r.opsView ? (size_t)r.opsViewLen : r.ops.size()) : 0;
+        naln += r.hasAlignment ? (long long)r.opsViewLen : 0;
     }
     if (locOffsets) locOffsets[n_] = nloc;
     if (alnOffsets) alnOffsets[n_] = naln;
@@ -1780,8 +1786,8 @@ int Batch::resultsFlat(int* status, int* editDistance, int* numLocations, int* a
             li += (long long)c;
         }
         if (r.hasAlignment) {
-            const uint8_t* src = r.opsView ? r.opsView : r.ops.data();
-            const size_t len = r.opsView ? (size_t)r.opsViewLen : r.ops.size();
+            const uint8_t* src = r.opsView;
+            const size_t len = (size_t)r.opsViewLen;
             if (aln && len) memcpy(aln + ai, src, len);
             ai += (long long)len;
         }

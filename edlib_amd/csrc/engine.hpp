@@ -7,6 +7,7 @@
 #include "pair_kernels.hpp"
 #include "reads_kernels.hpp"
 
+#include <deque>
 #include <memory>
 #include <vector>
 
@@ -50,44 +51,48 @@ struct OpsOut {
 };
 
 // Location lists of a unit: almost always one or two entries, so they live inside the result record (a
-// std::vector here was two malloc / free pairs per read: most of what LOC / PATH cost on a read batch).
+// std::vector here was two malloc / free pairs per read: most of what LOC / PATH cost on a read batch); longer
+// lists move to the heap.  24 bytes: the host side of LOC / PATH is bound by walking these records.
 class LocList {
 public:
     LocList() = default;
-    LocList(const LocList& o) { assign_range(o.data(), o.n_); }
-    LocList& operator=(const LocList& o) { if (this != &o) assign_range(o.data(), o.n_); return *this; }
-    LocList(LocList&& o) noexcept : n_(o.n_), big_(std::move(o.big_)) { for (int i = 0; i < kInline; ++i) in_[i] = o.in_[i]; o.n_ = 0; }
+    ~LocList() { delete big_; }
+    LocList(const LocList& o) { append(o.data(), o.n_); }
+    LocList& operator=(const LocList& o) { if (this != &o) { clear(); append(o.data(), o.n_); } return *this; }
+    LocList(LocList&& o) noexcept : n_(o.n_), big_(o.big_) { in_[0] = o.in_[0]; in_[1] = o.in_[1]; o.n_ = 0; o.big_ = nullptr; }
     LocList& operator=(LocList&& o) noexcept {
-        n_ = o.n_; big_ = std::move(o.big_); for (int i = 0; i < kInline; ++i) in_[i] = o.in_[i]; o.n_ = 0; return *this;
+        if (this != &o) { delete big_; n_ = o.n_; big_ = o.big_; in_[0] = o.in_[0]; in_[1] = o.in_[1]; o.n_ = 0; o.big_ = nullptr; }
+        return *this;
     }
     size_t size() const { return n_; }
     bool empty() const { return n_ == 0; }
-    const int* data() const { return n_ <= (size_t)kInline ? in_ : big_.data(); }
-    int* data() { return n_ <= (size_t)kInline ? in_ : big_.data(); }
+    const int* data() const { return n_ <= kInline ? in_ : big_->data(); }
+    int* data() { return n_ <= kInline ? in_ : big_->data(); }
     int operator[](size_t i) const { return data()[i]; }
     int& operator[](size_t i) { return data()[i]; }
-    void clear() { n_ = 0; big_.clear(); }
+    void clear() { n_ = 0; }                              // keeps the heap block (records are recycled across runs)
     void push_back(int v) { append(&v, 1); }
     void append(const int* p, size_t c) {
         const size_t nn = n_ + c;
-        if (nn <= (size_t)kInline) { for (size_t i = 0; i < c; ++i) in_[n_ + i] = p[i]; }
+        if (nn <= kInline) { for (size_t i = 0; i < c; ++i) in_[n_ + i] = p[i]; }
         else {
-            if (n_ <= (size_t)kInline) big_.assign(in_, in_ + n_);
-            big_.insert(big_.end(), p, p + c);
+            if (!big_) big_ = new std::vector<int>();
+            if (n_ <= kInline) big_->assign(in_, in_ + n_);
+            big_->insert(big_->end(), p, p + c);
         }
-        n_ = nn;
+        n_ = (uint32_t)nn;
     }
     void assign(size_t c, int v) {
-        clear();
-        if (c <= (size_t)kInline) { for (size_t i = 0; i < c; ++i) in_[i] = v; } else big_.assign(c, v);
-        n_ = c;
+        n_ = 0;
+        if (c <= kInline) { for (size_t i = 0; i < c; ++i) in_[i] = v; }
+        else { if (!big_) big_ = new std::vector<int>(); big_->assign(c, v); }
+        n_ = (uint32_t)c;
     }
 private:
-    void assign_range(const int* p, size_t c) { clear(); append(p, c); }
-    static const int kInline = 4;
-    size_t n_ = 0;
+    static const uint32_t kInline = 2;
+    uint32_t n_ = 0;
     int in_[kInline];
-    std::vector<int> big_;
+    std::vector<int>* big_ = nullptr;
 };
 
 // Per-unit result assembled on the host before it is marshalled into
@@ -98,8 +103,7 @@ struct UnitResult {
     int alphabetLength = 0;
     bool hasEnds = false, hasStarts = false, hasAlignment = false;
     LocList ends, starts;
-    std::vector<uint8_t> ops;                 // owned op string, or ...
-    const uint8_t* opsView = nullptr;         // ... a view into a staging block the batch keeps alive
+    const uint8_t* opsView = nullptr;         // op string: a view into a staging block (or an owned string) the batch keeps alive
     int opsViewLen = 0;
 };
 
@@ -193,6 +197,7 @@ private:
                         std::vector<int>& leftScore, std::vector<int>& rightScore);
     int solvePaths(const std::vector<Piece>& jobs, std::vector<OpsOut>& opsOut, std::vector<int>& status);
     std::vector<std::shared_ptr<PinBuf>> opsKeep_;      // staging blocks the last run's op views point into
+    std::deque<std::vector<uint8_t>> opsOwned_;         // op strings assembled on the host (Hirschberg pieces, empty windows)
 
     int qlen(int u) const { return (int)(qoff_[u + 1] - qoff_[u]); }
     long long tbase(int u) const { return shared_ ? toff_[0] : toff_[u]; }
