@@ -555,7 +555,16 @@ int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, i
                 g.nwords, mode, nlanes, numSegments, segLen, warm, cap, kcap, (const void*)d_slotmap, (const void*)posOff);
     }
     scanTimerStart();
-    if (banded_ && mode == EDLIB_MODE_HW && (!unbanded || syms_ > 4)) EDLIB_AMD_HIP(launch_scan_reads_banded(g.nwords, syms_, a, stream_));
+    // full-height HW scans (pass 2 over unrelated reads): 0 = scan_reads_kernel (register-resident rows, 4 symbols only:
+    // 288 ms per 1M-read step), 1 = scan_reads_full_kernel (LDS rows picked by M0, any symbol count: 314 ms),
+    // 2 = the banded kernel at full height (325 ms).  Default: 0 for four symbols, 1 above.
+    static const int pass2Kernel = getenv("EDLIB_AMD_PASS2") ? atoi(getenv("EDLIB_AMD_PASS2")) : 0;
+    const bool fullHeight = banded_ && mode == EDLIB_MODE_HW && unbanded && (pass2Kernel == 1 || syms_ > 4) && pass2Kernel != 2;
+    if (fullHeight) {
+        EDLIB_AMD_HIP(launch_scan_reads_full(g.nwords, syms_, a, stream_));
+        stats.word_steps += (long long)((nlanes + 63) / 64 * 64) * g.nwords *
+                            ((long long)a.targetLength + (long long)(numSegments - 1) * warm);
+    } else if (banded_ && mode == EDLIB_MODE_HW && (!unbanded || syms_ > 4)) EDLIB_AMD_HIP(launch_scan_reads_banded(g.nwords, syms_, a, stream_));
     else {
         EDLIB_AMD_HIP(launch_scan_reads(g.nwords, mode, a, stream_));
         stats.word_steps += (long long)((nlanes + 63) / 64 * 64) * g.nwords *
@@ -698,7 +707,7 @@ int Batch::runReads()
                     EDLIB_AMD_HIP(hipMemcpyAsync(&ws, d_ws.p, sizeof ws, hipMemcpyDeviceToHost, stream_));
                     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
                     const double cols = (double)np2 * ((double)T + (double)(S3 - 1) * warm3);
-                    plain = syms_ == 4 && (double)ws >= 0.85 * g.nwords * cols && !getenv("EDLIB_AMD_PASS2_BANDED");
+                    plain = (double)ws >= 0.85 * g.nwords * cols && !getenv("EDLIB_AMD_PASS2_BANDED");
                     stats.word_steps += (long long)ws;
                 }
                 // The leftovers are scattered over the batch: through the slot map every lane of a wave would pull its

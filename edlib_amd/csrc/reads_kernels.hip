@@ -613,7 +613,7 @@ typedef u32 QuadRows[4];
 // S <= k + c; the one unit matters: against unrelated sequence the score 32 rows down hovers around 13, and with
 // k = 6 a wave meets S <= 10 at 0.5 % of its checkpoints but S <= 9 at 0.06 %.)  A new word enters as "+1 per row"
 // like the reference's new block (edlib.cpp:605-608).
-template <int NA, int NWD, int Q, int S>
+template <int NA, int NWD, int Q, int S, bool CHECK = true>
 __device__ __forceinline__ int band_quad(const u32 lo, const u32 hi, const u32 nlo, const u32 nhi, QuadRows& qr,
                                          const int colBase, const int colEnd, const bool track, u32 (&Pv)[NWD],
                                          u32 (&Mv)[NWD], int& e, int& flag, HwTrack& tr, const u32 sh, const int lastRows)
@@ -660,7 +660,8 @@ __device__ __forceinline__ int band_quad(const u32 lo, const u32 hi, const u32 n
     }
     // ---- band checkpoints.  Scores are computed values: exact when <= k, otherwise upper bounds that still
     // exceed k, which is all the rules use.  HW: the row above the band's top is all zeros.
-    if constexpr (NA == 1) {
+    if constexpr (!CHECK) return NA;                                        // scan_reads_full_kernel: the band is the query
+    else if constexpr (NA == 1) {
         if constexpr (NWD > 1) {
             // S1 = popc(Pv) - popc(Mv) <= k + 3: second word.  Written so that the loop-invariant k + 3 rides
             // in the accumulator operand of v_bcnt: two v_bcnt and one v_cmp per quad
@@ -827,6 +828,92 @@ scan_reads_banded_kernel(const ReadScanArgs a)
         a.segCnt[it] = tr.cnt;
     }
     if (a.wordSteps && lane == 0) atomicAdd(a.wordSteps, (unsigned long long)bandWork * 4ull * 64ull);
+}
+
+// Every row of every column, HW mode, with the banded kernel's data path (Peq rows in LDS picked by M0, the target as
+// row offsets through s_load_dwordx8, one wave per workgroup) but no band bookkeeping at all: what the leftovers of the
+// k-doubling run on when a sample shows that their band is the whole query (unrelated reads).  Against
+// scan_reads_kernel (register-resident rows, a scalar 4-way branch per column) it has no symbol dispatch and takes 4, 8 or
+// 16 symbols; against scan_reads_banded_kernel at full height it has no checkpoints and a third of the code.
+template <int NWD, int S>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((S == 4 && NWD <= 5) ? 7 : 1, 8)))
+scan_reads_full_kernel(const ReadScanArgs a)
+{
+    const int lane = threadIdx.x;
+    const int idx = blockIdx.x * 64 + lane;
+    const bool live = idx < a.nlanes;
+    const int slot = live ? (a.slotmap ? a.slotmap[idx] : idx) : 0;
+    u32 Pv[NWD], Mv[NWD];
+    const int m = a.qlen[slot];
+    const u32 sh = (u32)(m - 1) & 31u;
+    const int lastRows = m - 32 * (NWD - 1);
+    __shared__ __attribute__((aligned(1024))) u32 s_eq[NWD][S][64];
+    {
+        const size_t pb = (size_t)(slot >> 6) * S * NWD * 64 + (slot & 63);
+#pragma unroll
+        for (int d = 0; d < NWD; ++d) {
+#pragma unroll
+            for (int sy = 0; sy < S; ++sy) s_eq[d][sy][lane] = a.peq[pb + (size_t)(sy * NWD + d) * 64];
+            Pv[d] = ~0u; Mv[d] = 0u;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    if ((u32)(size_t)(__attribute__((address_space(3))) u32*)&s_eq[0][0][0] != 0u) __builtin_trap();
+    HwTrack tr;
+    tr.best = a.kinit[slot];
+    tr.cnt = 0;
+    {
+        const long long item = (long long)idx * a.numSegments + blockIdx.y;
+        tr.cap = live ? (a.posCap ? a.posCap[item] : a.cap) : 0;
+        tr.pos = a.segPos + (!live ? 0 : (a.posOff ? a.posOff[item] : item * a.cap));
+    }
+    int e = m - tr.best - 1, flag = 0;
+    const int T = a.targetLength;
+    const int c0 = blockIdx.y * a.segLen;
+    int c1 = c0 + a.segLen; if (c1 > T) c1 = T;
+    int cw = c0 - a.warm; if (cw < 0) cw = 0;
+    const int b0 = cw >> 4, bmain = c0 >> 4, bend = (c1 + 15) >> 4;
+    typedef const u32x8 __attribute__((address_space(4))) * TargetBlocks;
+    const TargetBlocks tx = (TargetBlocks)(unsigned long long)a.trows;
+    u32x8 cur = tx[b0];
+    QuadRows qr;
+    for (int b = b0; b < bend; ++b) {
+        const u32x8 nxt = tx[b + 1];
+#define QUADF(Q) (void)band_quad<NWD, NWD, Q, S, false>(cur[2 * Q], cur[2 * Q + 1], 0u, 0u, qr, b * 16 + Q * 4, c1, b >= bmain, \
+                                                       Pv, Mv, e, flag, tr, sh, lastRows);
+        QUADF(0) QUADF(1) QUADF(2) QUADF(3)
+#undef QUADF
+        cur = nxt;
+    }
+    if (live) {
+        const long long it = (long long)idx * a.numSegments + blockIdx.y;
+        a.segBest[it] = tr.best;
+        a.segCnt[it] = tr.cnt;
+    }
+}
+
+template <int S>
+static hipError_t launch_scan_reads_full_s(int nwords, const ReadScanArgs& a, hipStream_t stream)
+{
+    dim3 grid((a.nlanes + 63) / 64, a.numSegments), block(64);
+    switch (nwords) {
+#define CASE(N) case N: hipLaunchKernelGGL((scan_reads_full_kernel<N, S>), grid, block, 0, stream, a); break;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_reads_full(int nwords, int syms, const ReadScanArgs& a, hipStream_t stream)
+{
+    if (a.nlanes == 0) return hipSuccess;
+    switch (syms) {
+        case 4: return launch_scan_reads_full_s<4>(nwords, a, stream);
+        case 8: return launch_scan_reads_full_s<8>(nwords, a, stream);
+        case 16: return launch_scan_reads_full_s<16>(nwords, a, stream);
+    }
+    return hipErrorInvalidValue;
 }
 
 template <int S>

@@ -40,6 +40,9 @@ hipError_t launch_scan_reads(int nwords, int mode, const ReadScanArgs& a, hipStr
 // 4, 8 or 16 (target symbols rounded up); launch_scan_reads only knows 4.
 hipError_t launch_scan_reads_banded(int nwords, int syms, const ReadScanArgs& a, hipStream_t stream);
 
+// HW only, no band: every row of every column with the banded kernel's data path (syms = 4, 8 or 16)
+hipError_t launch_scan_reads_full(int nwords, int syms, const ReadScanArgs& a, hipStream_t stream);
+
 hipError_t launch_pack_target_2bit(const uint8_t* raw, const uint8_t* lut, int targetLength,
                                    uint32_t* tpk, hipStream_t stream);
 // ndwords = 8 * (blocks of 16 columns, including the two blocks of padding): every dword is written
