@@ -63,6 +63,15 @@ def test_fixed_k_and_large_batch_through_both_passes(engine):
     _check(engine, reads[:3000], target, "distance", k=2)
 
 
+def test_many_unrelated_reads_take_the_full_height_kernel(engine):
+    """>= 4096 leftovers whose band is the whole query: pass 2 runs on scan_reads_full_kernel (LDS rows, 8 / 16 symbols)"""
+    for seed, kw in ((51, dict(frac_lower=0.0)), (52, dict())):          # 5 symbols (8 rows) and 9 symbols (16 rows)
+        target = synth.masked_genome(seed, 30_000, **kw)
+        reads, _ = synth.window_reads(target, 24000, 50, seed=seed + 10, sub=0.02)
+        reads[::4] = synth.random_dna(seed + 20, len(reads[::4]) * 50).reshape(-1, 50)    # 6000 unrelated reads
+        _check(engine, reads, target, "distance")
+
+
 def test_seventeen_symbols_fall_back_to_pairs(engine):
     t = np.frombuffer(bytes(range(65, 82)) * 200, dtype=np.uint8)                  # 17 distinct bytes
     reads, _ = synth.window_reads(t, 64, 40, seed=50, sub=0.05)
