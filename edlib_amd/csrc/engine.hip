@@ -405,11 +405,18 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
     const int modeIn = (int)cfg.mode;
     const bool readsOk = shared_ && tlen(0) > 0 && (tab_.sigmaT <= 4 || (tab_.sigmaT <= 16 && modeIn == EDLIB_MODE_HW));
     syms_ = tab_.sigmaT <= 4 ? 4 : (tab_.sigmaT <= 8 ? 8 : 16);
-    std::vector<std::vector<int>> byWords(kMaxReadWords + 1);
+    {
+        const char* env = getenv("EDLIB_AMD_BAND");
+        banded_ = (mode == EDLIB_MODE_HW) && (!(env && env[0] == '0') || syms_ > 4);   // more than 4 symbols: banded kernel only
+    }
+    // reads of 257..512 bases: banded / full-height HW kernels only, up to 8 target symbols (EDLIB_AMD_LONGREADS=0: pair path)
+    static const bool longReads = !(getenv("EDLIB_AMD_LONGREADS") && getenv("EDLIB_AMD_LONGREADS")[0] == '0');
+    const int maxReadLen = 32 * ((banded_ && modeIn == EDLIB_MODE_HW && syms_ <= 8 && longReads) ? kMaxLongReadWords : kMaxReadWords);
+    std::vector<std::vector<int>> byWords(kMaxLongReadWords + 1);
     for (int u = 0; u < n; ++u) {
         const int m = qlen(u), T = tlen(u);
         if (m == 0 || T == 0) emptyUnits_.push_back(u);
-        else if (readsOk && m <= 32 * kMaxReadWords) { readUnits_.push_back(u); byWords[(m + 31) / 32].push_back(u); }
+        else if (readsOk && m <= maxReadLen) { readUnits_.push_back(u); byWords[read_group_words(m)].push_back(u); }
         else pairUnits_.push_back(u);
     }
     stats.cells = 0;
@@ -417,7 +424,7 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
 
     // reads-per-lane groups: one per query word count, slots padded to whole waves
     const int T = shared_ ? tlen(0) : 0;
-    for (int w = 1; w <= kMaxReadWords; ++w) {
+    for (int w = 1; w <= kMaxLongReadWords; ++w) {
         if (byWords[w].empty()) continue;
         std::unique_ptr<ReadGroup> g(new ReadGroup);
         g->nwords = w;
@@ -469,10 +476,6 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
         EDLIB_AMD_HIP(hipMemsetAsync(d_tpk_.p, 0, d_tpk_.bytes(), stream_));
         EDLIB_AMD_HIP(d_wordSteps_.alloc(1));
         EDLIB_AMD_HIP(d_trows_.alloc(((size_t)(T + 15) / 16 + 2) * 8));
-    }
-    {
-        const char* env = getenv("EDLIB_AMD_BAND");
-        banded_ = (mode == EDLIB_MODE_HW) && (!(env && env[0] == '0') || syms_ > 4);   // more than 4 symbols: banded kernel only
     }
     return 0;
 }
@@ -559,12 +562,13 @@ int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, i
     // 288 ms per 1M-read step), 1 = scan_reads_full_kernel (LDS rows picked by M0, any symbol count: 314 ms),
     // 2 = the banded kernel at full height (325 ms).  Default: 0 for four symbols, 1 above.
     static const int pass2Kernel = getenv("EDLIB_AMD_PASS2") ? atoi(getenv("EDLIB_AMD_PASS2")) : 0;
-    const bool fullHeight = banded_ && mode == EDLIB_MODE_HW && unbanded && (pass2Kernel == 1 || syms_ > 4) && pass2Kernel != 2;
+    const bool longGroup = g.nwords > kMaxReadWords;                  // no plain kernel for 12 / 16 words
+    const bool fullHeight = banded_ && mode == EDLIB_MODE_HW && unbanded && (pass2Kernel == 1 || syms_ > 4 || longGroup) && pass2Kernel != 2;
     if (fullHeight) {
         EDLIB_AMD_HIP(launch_scan_reads_full(g.nwords, syms_, a, stream_));
         stats.word_steps += (long long)((nlanes + 63) / 64 * 64) * g.nwords *
                             ((long long)a.targetLength + (long long)(numSegments - 1) * warm);
-    } else if (banded_ && mode == EDLIB_MODE_HW && (!unbanded || syms_ > 4)) EDLIB_AMD_HIP(launch_scan_reads_banded(g.nwords, syms_, a, stream_));
+    } else if (banded_ && mode == EDLIB_MODE_HW && (!unbanded || syms_ > 4 || longGroup)) EDLIB_AMD_HIP(launch_scan_reads_banded(g.nwords, syms_, a, stream_));
     else {
         EDLIB_AMD_HIP(launch_scan_reads(g.nwords, mode, a, stream_));
         stats.word_steps += (long long)((nlanes + 63) / 64 * 64) * g.nwords *

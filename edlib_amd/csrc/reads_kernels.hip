@@ -216,7 +216,7 @@ hipError_t launch_build_peq_reads(int nwords, int syms, const uint8_t* reads, co
     if (syms != 4 && syms != 8 && syms != 16) return hipErrorInvalidValue;
     switch (nwords) {
 #define CASE(N) case N: return launch_build_peq_t<N>(reads, qoff, perm, nslots, syms, eqtbl, tpres, kcfg, peq, qlen, kinit, alphaExtra, stream);
-        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(12) CASE(16)
 #undef CASE
     }
     return hipErrorInvalidValue;
@@ -461,52 +461,70 @@ __device__ __forceinline__ void column_step_eq1(const u32 eq0, u32 (&Pv)[NWD], u
 #define EDLIB_AMD_RD(N, OFF) "ds_read_addtid_b32 " N " offset:" #OFF "\n\t"
 #define EDLIB_AMD_RDW(N, W) "ds_read_addtid_b32 " N " offset:%[w" #W "]\n\t"      /* word W of the row: offset W * S * 256 */
 
-// rows of ONE column (J = 0..3 of the quad held in the SGPR pair lo / hi), NA words; S symbols per word (row stride 256 S)
-template <int NA, int J, int S>
-__device__ __forceinline__ void lds_rows_request(u32 (&n)[NA], const u32 lo, const u32 hi)
+// rows of ONE column (J = 0..3 of the quad held in the SGPR pair lo / hi), NA words; S symbols per word (row stride 256 S).
+// Up to eight words per asm statement (operand count); heights 12 and 16 take two, each writing M0 itself (nothing
+// tells the compiler that M0 is live between two statements).
+template <int NA, int W0, int CNT, int J, int S>
+__device__ __forceinline__ void lds_rows_chunk(u32 (&n)[NA], const u32 pr)
 {
-    static_assert(NA >= 1 && NA <= 8, "band height");
-    const u32 pr = (J < 2) ? lo : hi;
-    if constexpr (NA == 1) { if constexpr (J & 1) asm volatile(EDLIB_AMD_M0_ODD("%[pr]") "s_nop 0\n\t" EDLIB_AMD_RD("%0", 0) : "=v"(n[0]) : [pr] "s"(pr) : "memory", "scc");
-                             else asm volatile(EDLIB_AMD_M0_EVEN("%[pr]") "s_nop 0\n\t" EDLIB_AMD_RD("%0", 0) : "=v"(n[0]) : [pr] "s"(pr) : "memory", "scc"); }
-#define EDLIB_AMD_WOFF [w1] "n"(S * 256), [w2] "n"(S * 512), [w3] "n"(S * 768), [w4] "n"(S * 1024), [w5] "n"(S * 1280), [w6] "n"(S * 1536), [w7] "n"(S * 1792)
+    static_assert(CNT >= 1 && CNT <= 8 && W0 + CNT <= NA, "chunk of band words");
+#define EDLIB_AMD_WOFF [w0] "n"((W0 + 0) * S * 256), [w1] "n"((W0 + 1) * S * 256), [w2] "n"((W0 + 2) * S * 256), [w3] "n"((W0 + 3) * S * 256), \
+                       [w4] "n"((W0 + 4) * S * 256), [w5] "n"((W0 + 5) * S * 256), [w6] "n"((W0 + 6) * S * 256), [w7] "n"((W0 + 7) * S * 256)
 #define EDLIB_AMD_ROWS_ASM(READS, OUTS)                                                                              \
     { if constexpr (J & 1) asm volatile(EDLIB_AMD_M0_ODD("%[pr]") "s_nop 0\n\t" READS : OUTS : [pr] "s"(pr), EDLIB_AMD_WOFF : "memory", "scc");   \
       else asm volatile(EDLIB_AMD_M0_EVEN("%[pr]") "s_nop 0\n\t" READS : OUTS : [pr] "s"(pr), EDLIB_AMD_WOFF : "memory", "scc"); }
-#define O1 "=v"(n[0])
-#define O2 O1, "=v"(n[1])
-#define O3 O2, "=v"(n[2])
-#define O4 O3, "=v"(n[3])
-#define O5 O4, "=v"(n[4])
-#define O6 O5, "=v"(n[5])
-#define O7 O6, "=v"(n[6])
-#define O8 O7, "=v"(n[7])
-#define R2 EDLIB_AMD_RD("%0", 0) EDLIB_AMD_RDW("%1", 1)
+#define O1 "=v"(n[W0])
+#define O2 O1, "=v"(n[W0 + (CNT > 1 ? 1 : 0)])
+#define O3 O2, "=v"(n[W0 + (CNT > 2 ? 2 : 0)])
+#define O4 O3, "=v"(n[W0 + (CNT > 3 ? 3 : 0)])
+#define O5 O4, "=v"(n[W0 + (CNT > 4 ? 4 : 0)])
+#define O6 O5, "=v"(n[W0 + (CNT > 5 ? 5 : 0)])
+#define O7 O6, "=v"(n[W0 + (CNT > 6 ? 6 : 0)])
+#define O8 O7, "=v"(n[W0 + (CNT > 7 ? 7 : 0)])
+#define R1 EDLIB_AMD_RDW("%0", 0)
+#define R2 R1 EDLIB_AMD_RDW("%1", 1)
 #define R3 R2 EDLIB_AMD_RDW("%2", 2)
 #define R4 R3 EDLIB_AMD_RDW("%3", 3)
 #define R5 R4 EDLIB_AMD_RDW("%4", 4)
 #define R6 R5 EDLIB_AMD_RDW("%5", 5)
 #define R7 R6 EDLIB_AMD_RDW("%6", 6)
 #define R8 R7 EDLIB_AMD_RDW("%7", 7)
-    if constexpr (NA == 2) EDLIB_AMD_ROWS_ASM(R2, O2)
-    if constexpr (NA == 3) EDLIB_AMD_ROWS_ASM(R3, O3)
-    if constexpr (NA == 4) EDLIB_AMD_ROWS_ASM(R4, O4)
-    if constexpr (NA == 5) EDLIB_AMD_ROWS_ASM(R5, O5)
-    if constexpr (NA == 6) EDLIB_AMD_ROWS_ASM(R6, O6)
-    if constexpr (NA == 7) EDLIB_AMD_ROWS_ASM(R7, O7)
-    if constexpr (NA == 8) EDLIB_AMD_ROWS_ASM(R8, O8)
+    if constexpr (CNT == 1) EDLIB_AMD_ROWS_ASM(R1, O1)
+    if constexpr (CNT == 2) EDLIB_AMD_ROWS_ASM(R2, O2)
+    if constexpr (CNT == 3) EDLIB_AMD_ROWS_ASM(R3, O3)
+    if constexpr (CNT == 4) EDLIB_AMD_ROWS_ASM(R4, O4)
+    if constexpr (CNT == 5) EDLIB_AMD_ROWS_ASM(R5, O5)
+    if constexpr (CNT == 6) EDLIB_AMD_ROWS_ASM(R6, O6)
+    if constexpr (CNT == 7) EDLIB_AMD_ROWS_ASM(R7, O7)
+    if constexpr (CNT == 8) EDLIB_AMD_ROWS_ASM(R8, O8)
+}
+template <int NA, int J, int S>
+__device__ __forceinline__ void lds_rows_request(u32 (&n)[NA], const u32 lo, const u32 hi)
+{
+    static_assert(NA >= 1 && NA <= 16, "band height");
+    const u32 pr = (J < 2) ? lo : hi;
+    if constexpr (NA <= 8) lds_rows_chunk<NA, 0, NA, J, S>(n, pr);
+    else { lds_rows_chunk<NA, 0, 8, J, S>(n, pr); lds_rows_chunk<NA, 8, NA - 8, J, S>(n, pr); }
+}
+template <int NA, int W0, int CNT>
+__device__ __forceinline__ void lds_rows_wait_chunk(u32 (&n)[NA])
+{
+#define N_(i) "+v"(n[W0 + (CNT > i ? i : 0)])
+    if constexpr (CNT == 1) asm volatile("s_waitcnt lgkmcnt(0)" : N_(0));
+    if constexpr (CNT == 2) asm volatile("s_waitcnt lgkmcnt(0)" : N_(0), N_(1));
+    if constexpr (CNT == 3) asm volatile("s_waitcnt lgkmcnt(0)" : N_(0), N_(1), N_(2));
+    if constexpr (CNT == 4) asm volatile("s_waitcnt lgkmcnt(0)" : N_(0), N_(1), N_(2), N_(3));
+    if constexpr (CNT == 5) asm volatile("s_waitcnt lgkmcnt(0)" : N_(0), N_(1), N_(2), N_(3), N_(4));
+    if constexpr (CNT == 6) asm volatile("s_waitcnt lgkmcnt(0)" : N_(0), N_(1), N_(2), N_(3), N_(4), N_(5));
+    if constexpr (CNT == 7) asm volatile("s_waitcnt lgkmcnt(0)" : N_(0), N_(1), N_(2), N_(3), N_(4), N_(5), N_(6));
+    if constexpr (CNT == 8) asm volatile("s_waitcnt lgkmcnt(0)" : N_(0), N_(1), N_(2), N_(3), N_(4), N_(5), N_(6), N_(7));
+#undef N_
 }
 template <int NA>
 __device__ __forceinline__ void lds_rows_wait(u32 (&n)[NA])
 {
-    if constexpr (NA == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]));
-    if constexpr (NA == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]), "+v"(n[1]));
-    if constexpr (NA == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]));
-    if constexpr (NA == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]));
-    if constexpr (NA == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]), "+v"(n[4]));
-    if constexpr (NA == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]), "+v"(n[4]), "+v"(n[5]));
-    if constexpr (NA == 7) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]), "+v"(n[4]), "+v"(n[5]), "+v"(n[6]));
-    if constexpr (NA == 8) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]), "+v"(n[4]), "+v"(n[5]), "+v"(n[6]), "+v"(n[7]));
+    if constexpr (NA <= 8) lds_rows_wait_chunk<NA, 0, NA>(n);
+    else { lds_rows_wait_chunk<NA, 0, 8>(n); lds_rows_wait_chunk<NA, 8, NA - 8>(n); }   // the second wait is free
 }
 
 // ---- the band of one word carries the rows of the NEXT quad across quads (requested while the current
@@ -572,8 +590,23 @@ __device__ __forceinline__ void column_step_hw(const u32 (&Eq)[NA], u32 (&Pv)[NW
         Mh[i] = Pv[i] & Xh;
     }
     if (NA == NWD) {                                   // bottom row is in the band: follow its score
-        e += (int)((Ph[NA - 1] >> sh) & 1u);
-        e -= (int)((Mh[NA - 1] >> sh) & 1u);
+        if constexpr (NWD <= 8) {
+            e += (int)((Ph[NA - 1] >> sh) & 1u);
+            e -= (int)((Mh[NA - 1] >> sh) & 1u);
+        } else {
+            // groups of 12 and 16 words hold queries of 9..12 and 13..16 words: sh is m - 1 itself, the row's word
+            // (one of the last four) is picked per lane
+            const u32 lw = sh >> 5;
+            u32 phs = Ph[NWD - 1], mhs = Mh[NWD - 1];
+#pragma unroll
+            for (int d = 2; d <= 4; ++d) {
+                const bool here = lw == (u32)(NWD - d);
+                phs = here ? Ph[NWD - d] : phs;
+                mhs = here ? Mh[NWD - d] : mhs;
+            }
+            e += (int)((phs >> (sh & 31u)) & 1u);
+            e -= (int)((mhs >> (sh & 31u)) & 1u);
+        }
         flag |= e;
     }
 #pragma unroll
@@ -591,6 +624,16 @@ __device__ __forceinline__ void column_step_hw(const u32 (&Eq)[NA], u32 (&Pv)[NW
         Mv[i] = ph & Xv;
     }
 }
+
+// Band heights the banded kernel is unrolled for: every height up to 8 words; the groups of 12 and 16 words (reads of
+// 257..512 bases) step 1, 2, 3, 4, 6, 8, 12(, 16) -- the code of a height is four unrolled quads of NA words each, and
+// a band that tall is moving fast anyway.
+template <int NWD> __host__ __device__ constexpr bool band_height_ok(int h)
+{
+    return h >= 1 && h <= NWD && (NWD <= 8 || h <= 4 || h == 6 || h == 8 || h == 12 || h == NWD);
+}
+template <int NWD> __host__ __device__ constexpr int band_height_up(int h)   { int n = h + 1; while (n < NWD && !band_height_ok<NWD>(n)) ++n; return n; }
+template <int NWD> __host__ __device__ constexpr int band_height_down(int h) { int n = h - 1; while (n > 1 && !band_height_ok<NWD>(n)) --n; return n; }
 
 struct HwTrack {            // per-lane tracking state of the banded kernel
     int best, cnt, cap;
@@ -697,21 +740,31 @@ __device__ __forceinline__ int band_quad(const u32 lo, const u32 hi, const u32 n
         return 2;
     } else {
         if (Q == 3) {                                                       // end of the block: every 16 columns
-            int Sprev = 0;
+            constexpr int DN = band_height_down<NWD>(NA);                   // NA - 1 up to 8 words
+            int cum[NA];                                                    // score of the last row of every word
+            {
+                int acc = 0;
 #pragma unroll
-            for (int i = 0; i + 1 < NA; ++i) Sprev += __popc(Pv[i]) - __popc(Mv[i]);
-            const int Sb = Sprev + __popc(Pv[NA - 1]) - __popc(Mv[NA - 1]);
+                for (int i = 0; i < NA; ++i) { acc += __popc(Pv[i]) - __popc(Mv[i]); cum[i] = acc; }
+            }
+            const int Sb = cum[NA - 1];
             if constexpr (NA < NWD) {
                 if (__builtin_amdgcn_ballot_w64(Sb <= tr.best + 15) != 0ull) {
-                    Pv[NA < NWD ? NA : 0] = ~0u; Mv[NA < NWD ? NA : 0] = 0u;
-                    if (NA + 1 == NWD) { e = Sb + lastRows - tr.best - 1; flag = 0; } // row m-1 is lastRows rows below
-                    return NA + 1;
+                    constexpr int UP = band_height_up<NWD>(NA);             // NA + 1 up to 8 words
+#pragma unroll
+                    for (int i = NA; i < UP; ++i) { Pv[i < NWD ? i : 0] = ~0u; Mv[i < NWD ? i : 0] = 0u; }
+                    // row m-1 is lastRows + 32 (NWD - 1 - NA) rows below the band's bottom row
+                    if (UP == NWD) { e = Sb + lastRows + 32 * (NWD - 1 - NA) - tr.best - 1; flag = 0; }
+                    return UP;
                 }
             }
-            // drop the last word when (a) every cell of it exceeds k: a cell j rows below Sprev's row is
-            // >= max(Sprev - j, Sb - (32 - j)) >= (Sprev + Sb - 32) / 2, and (b) the new bottom 16 rows do too
-            const bool keep = (Sprev <= tr.best + 16) || (Sprev + Sb <= 2 * tr.best + 34);
-            if (__builtin_amdgcn_ballot_w64(keep) == 0ull) return NA - 1;
+            // drop the words from DN on when (a) every cell of them exceeds k: in a word between the scores A (row
+            // above it) and B (its last row) a cell j rows down is >= max(A - j, B - (32 - j)) >= (A + B - 32) / 2,
+            // and (b) the new bottom 16 rows do too
+            bool keep = cum[DN - 1] <= tr.best + 16;
+#pragma unroll
+            for (int i = DN; i < NA; ++i) keep = keep || (cum[i - 1] + cum[i] <= 2 * tr.best + 34);
+            if (__builtin_amdgcn_ballot_w64(keep) == 0ull) return DN;
         }
         return NA;
     }
@@ -733,8 +786,8 @@ scan_reads_banded_kernel(const ReadScanArgs a)
 
     u32 Pv[NWD], Mv[NWD];
     const int m = a.qlen[slot];
-    const u32 sh = (u32)(m - 1) & 31u;                                // row m-1 inside the last word
-    const int lastRows = m - 32 * (NWD - 1);                          // query rows in the last word
+    const u32 sh = NWD <= 8 ? (u32)(m - 1) & 31u : (u32)(m - 1);      // row m-1 inside the last word (12 / 16 words: m - 1, column_step_hw)
+    const int lastRows = m - 32 * (NWD - 1);                          // query rows in the last word (12 / 16 words: may be <= 0)
     // the four Peq rows of the wave's queries: HBM -> LDS, [word][symbol][lane].  The only LDS object of a
     // one-wave workgroup: it sits at LDS address 0, which is what lets M0 be the bare row offset.
     __shared__ __attribute__((aligned(1024))) u32 s_eq[NWD][S][64];
@@ -793,7 +846,7 @@ scan_reads_banded_kernel(const ReadScanArgs a)
                      sh, lastRows);
 #define ADVANCE { q = 0; ++b; cur = nxt; nxt = tx[b + 1]; }
 #define CASE(NA) case NA:                                                                                       \
-            if (NA <= NWD) {                                                                                    \
+            if constexpr (band_height_ok<NWD>(NA)) {                                                            \
                 const int q0 = b * 4 + q;                                                                       \
                 QuadRows qr;                                                                                    \
                 /* the one-word band starts with the rows of its first quad in registers */                     \
@@ -816,7 +869,7 @@ scan_reads_banded_kernel(const ReadScanArgs a)
                 bandWork += (unsigned int)NA * (unsigned int)(b * 4 + q - q0);                                  \
             }                                                                                                   \
             break;
-            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(12) CASE(16)
 #undef CASE
 #undef ADVANCE
 #undef QUAD
@@ -845,7 +898,7 @@ scan_reads_full_kernel(const ReadScanArgs a)
     const int slot = live ? (a.slotmap ? a.slotmap[idx] : idx) : 0;
     u32 Pv[NWD], Mv[NWD];
     const int m = a.qlen[slot];
-    const u32 sh = (u32)(m - 1) & 31u;
+    const u32 sh = NWD <= 8 ? (u32)(m - 1) & 31u : (u32)(m - 1);
     const int lastRows = m - 32 * (NWD - 1);
     __shared__ __attribute__((aligned(1024))) u32 s_eq[NWD][S][64];
     {
@@ -899,6 +952,8 @@ static hipError_t launch_scan_reads_full_s(int nwords, const ReadScanArgs& a, hi
     switch (nwords) {
 #define CASE(N) case N: hipLaunchKernelGGL((scan_reads_full_kernel<N, S>), grid, block, 0, stream, a); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+        case 12: if constexpr (S <= 8) { hipLaunchKernelGGL((scan_reads_full_kernel<12, S>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
+        case 16: if constexpr (S <= 8) { hipLaunchKernelGGL((scan_reads_full_kernel<16, S>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
 #undef CASE
         default: return hipErrorInvalidValue;
     }
@@ -924,6 +979,9 @@ static hipError_t launch_scan_reads_banded_s(int nwords, const ReadScanArgs& a, 
     switch (nwords) {
 #define CASE(N) case N: hipLaunchKernelGGL((scan_reads_banded_kernel<N, S>), grid, block, 0, stream, a); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+        // reads of 257..512 bases: targets of up to 8 symbols (16 would need 64 KB of LDS rows per wave)
+        case 12: if constexpr (S <= 8) { hipLaunchKernelGGL((scan_reads_banded_kernel<12, S>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
+        case 16: if constexpr (S <= 8) { hipLaunchKernelGGL((scan_reads_banded_kernel<16, S>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
 #undef CASE
         default: return hipErrorInvalidValue;
     }

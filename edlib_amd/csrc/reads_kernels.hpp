@@ -6,7 +6,11 @@
 
 namespace edlib_amd {
 
-constexpr int kMaxReadWords = 8;      // queries up to 256 symbols stay in VGPRs
+constexpr int kMaxReadWords = 8;      // queries up to 256 symbols: one kernel instance per word count, every mode
+// HW against up to 8 target symbols, banded kernel only: queries of 257..384 / 385..512 symbols run in groups of 12 /
+// 16 words (the row m-1 of a lane may sit in any of the group's last four words)
+constexpr int kMaxLongReadWords = 16;
+inline int read_group_words(int m) { const int w = (m + 31) / 32; return w <= kMaxReadWords ? w : (w <= 12 ? 12 : 16); }
 constexpr int kLanes = 64;            // wave64, hard-coded (gfx950)
 
 // Everything the scan kernel needs; plain pointers into HBM.
