@@ -150,6 +150,7 @@ EDLIB_API void edlibAmdTrim(void) { pool_trim(); }
 
 EDLIB_API int edlibAmdBatchStats(EdlibAmdBatch* b, EdlibAmdBatchStats* out) {
     if (!b || !out) { set_error("null argument"); return EDLIB_STATUS_ERROR; }
+    b->impl.finishStats();
     *out = b->impl.stats;
     return EDLIB_STATUS_OK;
 }

@@ -253,48 +253,42 @@ static void build_tables(Tables& tab, const uint8_t* targets, long long totalTar
 
 // Number of distinct byte values in query (and, for non-shared batches, target):
 // the alphabetLength field (edlib.cpp:162, transformSequences :1417-1462).
-// One workgroup per unit: aligned dword loads (four symbols each; the pools are padded), a 256-bit presence set per
-// thread in four 64-bit words, OR-reduced across the wave and then across the four waves through LDS.
+// One workgroup per unit: aligned 16-byte loads (the pools are padded by 16 bytes and 16-byte aligned), every byte
+// marks its entry of a 256-entry table in LDS (lanes that write the same entry write the same value), and the count
+// of marked entries is the answer.  (Round 1 / 2 kept a 256-bit set per thread in registers: ~25 VALU ops per byte
+// behind dword loads, 2.0 ms for 100,000 pairs of 10 kb -- 1 TB/s; this form is bound by the loads.)
 __global__ void __launch_bounds__(256)
 alphabet_count_kernel(const uint8_t* __restrict__ qpool, const long long* __restrict__ qoff,
                       const uint8_t* __restrict__ tpool, const long long* __restrict__ toff,
                       int shared, const uint32_t* __restrict__ basePresence,
                       const int* __restrict__ unitIdx, int* __restrict__ out)
 {
-    __shared__ unsigned long long s_set[4][4];
+    __shared__ uint32_t s_seen[256];
+    s_seen[threadIdx.x] = 0u;
+    __syncthreads();
     const int u = unitIdx[blockIdx.x];
-    unsigned long long s[4] = {0, 0, 0, 0};
-    auto add = [&](uint32_t b) {
-        const unsigned long long bit = 1ull << (b & 63);
-        const uint32_t w = b >> 6;
-        s[0] |= (w == 0) ? bit : 0ull; s[1] |= (w == 1) ? bit : 0ull;
-        s[2] |= (w == 2) ? bit : 0ull; s[3] |= (w == 3) ? bit : 0ull;
-    };
     auto scan = [&](const uint8_t* pool, long long lo, long long hi) {
-        for (long long w = (lo >> 2) + threadIdx.x; (w << 2) < hi; w += blockDim.x) {
-            const uint32_t v = *reinterpret_cast<const uint32_t*>(pool + (w << 2));
+        for (long long c = (lo >> 4) + threadIdx.x; (c << 4) < hi; c += 256) {
+            const uint4 v = *reinterpret_cast<const uint4*>(pool + (c << 4));
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+            const long long at = c << 4;
+            if (at >= lo && at + 16 <= hi) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const long long at = (w << 2) + k;
-                if (at >= lo && at < hi) add((v >> (8 * k)) & 0xffu);
+                for (int k = 0; k < 16; ++k) s_seen[(d[k >> 2] >> (8 * (k & 3))) & 0xffu] = 1u;
+            } else {                                                     // first / last chunk of the sequence
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (at + k >= lo && at + k < hi) s_seen[(d[k >> 2] >> (8 * (k & 3))) & 0xffu] = 1u;
             }
         }
     };
     scan(qpool, qoff[u], qoff[u + 1]);
     if (!shared) scan(tpool, toff[u], toff[u + 1]);
-    for (int off = 32; off > 0; off >>= 1)
-        for (int k = 0; k < 4; ++k) s[k] |= __shfl_xor(s[k], off);
-    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 4; ++k) s_set[threadIdx.x >> 6][k] = s[k];
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int n = 0;
-        for (int k = 0; k < 4; ++k) {
-            unsigned long long v = s_set[0][k] | s_set[1][k] | s_set[2][k] | s_set[3][k];
-            if (shared) v |= ((unsigned long long)basePresence[2 * k + 1] << 32) | basePresence[2 * k];
-            n += __popcll(v);
-        }
-        out[blockIdx.x] = n;
-    }
+    bool present = s_seen[threadIdx.x] != 0u;
+    if (shared) present = present || ((basePresence[threadIdx.x >> 5] >> (threadIdx.x & 31)) & 1u);
+    const int n = __syncthreads_count(present ? 1 : 0);
+    if (threadIdx.x == 0) out[blockIdx.x] = n;
 }
 
 // overflow census of the reads path: how many slots need the exact second pass
@@ -309,6 +303,7 @@ count_flags_kernel(const int* __restrict__ flags, int n, int* __restrict__ count
 
 Batch::~Batch() {
     DeviceGuard guard(device_);
+    if (side_) { (void)hipStreamSynchronize(side_); pool_stream_release(side_); }
     if (stream_) { (void)hipStreamSynchronize(stream_); pool_stream_release(stream_); }
     for (auto& p : scanEvents_) { pool_event_release(p.first); pool_event_release(p.second); }
 }
@@ -421,6 +416,13 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
     }
     stats.cells = 0;
     for (int u = 0; u < n; ++u) stats.cells += (long long)qlen(u) * tlen(u);
+    {   // units whose alphabetLength the reads path does not produce
+        alphaUnits_ = emptyUnits_;
+        alphaUnits_.insert(alphaUnits_.end(), pairUnits_.begin(), pairUnits_.end());
+        long long total = 0;
+        for (int u : alphaUnits_) total += qlen(u) + (shared_ ? 0 : tlen(u));
+        alphaOnHost_ = h_in_.p && d_qpool_.p && !d_qpool_.owned && total <= 65536;
+    }
 
     // reads-per-lane groups: one per query word count, slots padded to whole waves
     const int T = shared_ ? tlen(0) : 0;
@@ -907,7 +909,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     PinBuf descsPin;                                   // built in pinned staging: the H2D runs at link rate
     EDLIB_AMD_HIP(descsPin.alloc(n * sizeof(PairDesc)));
     PairDesc* descs = reinterpret_cast<PairDesc*>(descsPin.p);
-    std::vector<long long> opsOff(n + 1, 0);
+    std::vector<long long> opsOff(wantPath ? n + 1 : 1, 0);           // [n] = total op bytes (0 without PATH)
     long long peqWords = 0, auxInts = 0, storeEntries = 0, nbMax = 0;
     for (size_t i = 0; i < n; ++i) {
         const UnitSpec& s = units[ua + i];
@@ -923,7 +925,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         d.posCap = wantPositions ? kPosCap : 0;
         d.posOff = (long long)i * kPosCap;
         d.colOff = -1; d.bandT = 0; d.ring = ring;
-        opsOff[i + 1] = opsOff[i] + (wantPath ? (long long)s.qlen + s.tlen : 0);
+        if (wantPath) opsOff[i + 1] = opsOff[i] + (long long)s.qlen + s.tlen;
         // executed work: whole matrix, or one 64-block wave per column inside the band
         stats.word_steps += ring ? 2LL * ring * ((long long)s.tlen + nb - 1) : 2 * nb * (long long)s.tlen;
     }
@@ -931,7 +933,8 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     // device-visible pinned host memory -- no download commands behind the launches, one stream synchronisation.
     // (Descriptors still go up with a copy: the packed rings re-read them, and every read of host memory is a PCIe
     // round trip.)  Larger chunks stage through HBM: a PCIe transaction per store does not scale.
-    const bool zeroCopy = n <= 16 && opsOff[n] <= (64 << 10) && pool_enabled();
+    const long long opsTotal = wantPath ? opsOff[n] : 0;
+    const bool zeroCopy = n <= 16 && opsTotal <= (64 << 10) && pool_enabled();
     PinBuf outPin;
     int* hOut3 = nullptr; int* hPos = nullptr; int* hOpsLen = nullptr; long long* hOpsOff = nullptr;
     std::shared_ptr<PinBuf> ops;
@@ -942,7 +945,8 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         EDLIB_AMD_HIP(outPin.alloc(bytes));
         hOpsOff = reinterpret_cast<long long*>(outPin.p);
         hOut3 = reinterpret_cast<int*>(hOpsOff + n + 1); hPos = hOut3 + 3 * n; hOpsLen = hPos + n * kPosCap;
-        memcpy(hOpsOff, opsOff.data(), (n + 1) * sizeof(long long));
+        if (wantPath) memcpy(hOpsOff, opsOff.data(), (n + 1) * sizeof(long long));
+        else memset(hOpsOff, 0, (n + 1) * sizeof(long long));
         EDLIB_AMD_HIP(d_descs_.ensure(n));
         d_out3_.alias(hOut3, 3 * n); d_posPool_.alias(hPos, n * kPosCap);
         d_opsLen_.alias(hOpsLen, n); d_opsOff_.alias(hOpsOff, n + 1);
@@ -997,31 +1001,34 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         EDLIB_AMD_HIP(launch_traceback(tb, stream_));
     }
     if (lap.on) { EDLIB_AMD_HIP(hipStreamSynchronize(stream_)); lap("chunk: kernels"); }
-    std::vector<int> out3(3 * n), pool, opsLen;
-    const int* score = out3.data(); const int* count = score + n; const int* last = count + n;
+    // downloads land in pinned staging (a pageable std::vector took 5 ms for the 17 MB of end positions of 262,144
+    // short HW pairs); a zero-copy chunk is read where the kernels wrote it
+    PinBuf stage;
+    const int* score = nullptr; const int* pool = nullptr; const int* opsLen = nullptr;
     if (zeroCopy) {
         EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-        memcpy(out3.data(), hOut3, 3 * n * sizeof(int));
-        if (wantPositions) pool.assign(hPos, hPos + n * kPosCap);
-        if (wantPath) { opsLen.assign(hOpsLen, hOpsLen + n); if (ops) out.opsBufs.push_back(ops); }
-    }
-    if (!zeroCopy) EDLIB_AMD_HIP(hipMemcpyAsync(out3.data(), d_out3_.p, 3 * n * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    if (wantPositions && !zeroCopy) {
-        pool.resize(n * kPosCap);
-        EDLIB_AMD_HIP(hipMemcpyAsync(pool.data(), d_posPool_.p, n * kPosCap * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    }
-    if (wantPath && !zeroCopy) {
-        opsLen.resize(n);
-        EDLIB_AMD_HIP(hipMemcpyAsync(opsLen.data(), d_opsLen_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
-        if (opsOff[n] > 0) {
-            // the op slots (qlen + tlen bytes per unit, filled from the back) land in pinned staging and
-            // are read from there by results(): no intermediate host copies
-            ops = std::make_shared<PinBuf>();
-            EDLIB_AMD_HIP(ops->alloc((size_t)opsOff[n]));
-            EDLIB_AMD_HIP(hipMemcpyAsync(ops->p, d_ops_.p, (size_t)opsOff[n], hipMemcpyDeviceToHost, stream_));
-            out.opsBufs.push_back(ops);
+        score = hOut3; pool = hPos; opsLen = hOpsLen;
+        if (wantPath && ops) out.opsBufs.push_back(ops);
+    } else {
+        const size_t nPos = wantPositions ? n * kPosCap : 0, nLen = wantPath ? n : 0;
+        EDLIB_AMD_HIP(stage.alloc((3 * n + nPos + nLen) * sizeof(int)));
+        int* h = reinterpret_cast<int*>(stage.p);
+        score = h; pool = h + 3 * n; opsLen = h + 3 * n + nPos;
+        EDLIB_AMD_HIP(hipMemcpyAsync(h, d_out3_.p, 3 * n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        if (nPos) EDLIB_AMD_HIP(hipMemcpyAsync(h + 3 * n, d_posPool_.p, nPos * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        if (nLen) {
+            EDLIB_AMD_HIP(hipMemcpyAsync(h + 3 * n + nPos, d_opsLen_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+            if (opsOff[n] > 0) {
+                // the op slots (qlen + tlen bytes per unit, filled from the back) land in pinned staging and
+                // are read from there by results(): no intermediate host copies
+                ops = std::make_shared<PinBuf>();
+                EDLIB_AMD_HIP(ops->alloc((size_t)opsOff[n]));
+                EDLIB_AMD_HIP(hipMemcpyAsync(ops->p, d_ops_.p, (size_t)opsOff[n], hipMemcpyDeviceToHost, stream_));
+                out.opsBufs.push_back(ops);
+            }
         }
     }
+    const int* count = score + n; const int* last = count + n;
     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
     lap("chunk: kernels+D2H");
 
@@ -1057,6 +1064,11 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         }
     }
     size_t oj = 0;
+    if (wantPositions && mode != EDLIB_MODE_NW) {
+        size_t tot = ovfPos.size();
+        for (size_t i = 0; i < n; ++i) tot += (size_t)std::min(std::max(count[i], 0), kPosCap);
+        out.posFlat.reserve(out.posFlat.size() + tot);
+    }
     for (size_t i = 0; i < n; ++i) {
         const size_t g = ua + i;
         out.score[g] = score[i]; out.count[g] = count[i]; out.last[g] = last[i];
@@ -1065,7 +1077,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
                 out.posFlat.insert(out.posFlat.end(), ovfPos.begin() + ovfOff[oj], ovfPos.begin() + ovfOff[oj + 1]);
                 ++oj;
             } else {
-                out.posFlat.insert(out.posFlat.end(), pool.begin() + i * kPosCap, pool.begin() + i * kPosCap + count[i]);
+                out.posFlat.insert(out.posFlat.end(), pool + i * kPosCap, pool + i * kPosCap + count[i]);
             }
         }
         out.posStart[g + 1] = (long long)out.posFlat.size();
@@ -1082,39 +1094,56 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     return 0;
 }
 
-int Batch::alphabetLengths(const std::vector<int>& units, std::vector<UnitResult>& res)
+// alphabetLength of the units the reads path does not cover (reference transformSequences, edlib.cpp:1417-1462:
+// the number of distinct bytes of query and target).  It depends on the sequences only, not on any scan, so it runs
+// on a side stream next to phase 1 and is collected after it.
+int Batch::alphabetLengthsBegin()
 {
-    if (units.empty()) return 0;
-    {   // a handful of short sequences (edlibAlign() on a pair): counting distinct bytes on the host costs less than
-        // a launch and a round trip; the sequences are still in the staging block of init()
-        long long total = 0;
-        for (int u : units) total += qlen(u) + (shared_ ? 0 : tlen(u));
-        if (h_in_.p && d_qpool_.p && !d_qpool_.owned && total <= 65536) {
-            const uint8_t* hq = h_in_.p + (d_qpool_.p - d_in_.p);
-            const uint8_t* ht = h_in_.p + (d_tpool_.p - d_in_.p);
-            for (int u : units) {
-                bool seen[256] = {false};
-                int cnt = 0;
-                auto add = [&](const uint8_t* p, long long len) { for (long long i = 0; i < len; ++i) if (!seen[p[i]]) { seen[p[i]] = true; ++cnt; } };
-                add(hq + qoff_[u], qlen(u));
-                if (!shared_) add(ht + toff_[u], tlen(u));
-                else for (int b = 0; b < 256; ++b) if ((tab_.presence[b >> 5] >> (b & 31)) & 1u) { if (!seen[b]) { seen[b] = true; ++cnt; } }
-                res[u].alphabetLength = cnt;
-            }
-            return 0;
-        }
+    alphaPending_ = false;
+    if (alphaUnits_.empty() || alphaOnHost_) return 0;
+    const size_t n = alphaUnits_.size();
+    if (!side_) EDLIB_AMD_HIP(pool_stream(&side_));
+    EDLIB_AMD_HIP(evA_.create());
+    if (!d_alphaIdx_.p) {
+        EDLIB_AMD_HIP(d_alphaIdx_.alloc(n)); EDLIB_AMD_HIP(d_alphaOut_.alloc(n)); EDLIB_AMD_HIP(alphaPin_.alloc(n * sizeof(int)));
+        EDLIB_AMD_HIP(hipMemcpyAsync(d_alphaIdx_.p, alphaUnits_.data(), n * sizeof(int), hipMemcpyHostToDevice, side_));
     }
-    DevBuf<int> d_idx, d_out;
-    EDLIB_AMD_HIP(d_idx.alloc(units.size())); EDLIB_AMD_HIP(d_out.alloc(units.size()));
-    EDLIB_AMD_HIP(hipMemcpyAsync(d_idx.p, units.data(), units.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
-    hipLaunchKernelGGL(alphabet_count_kernel, dim3((unsigned)units.size()), dim3(256), 0, stream_,
+    // the inputs went up on stream_ (init): the side stream starts behind whatever stream_ holds now
+    EDLIB_AMD_HIP(hipEventRecord(evA_.e, stream_));
+    EDLIB_AMD_HIP(hipStreamWaitEvent(side_, evA_.e, 0));
+    hipLaunchKernelGGL(alphabet_count_kernel, dim3((unsigned)n), dim3(256), 0, side_,
                        d_qpool_.p, d_qoff_.p, d_tpool_.p, d_toff_.p, shared_ ? 1 : 0, d_presence_.p,
-                       d_idx.p, d_out.p);
+                       d_alphaIdx_.p, d_alphaOut_.p);
     EDLIB_AMD_HIP(hipGetLastError());
-    std::vector<int> out(units.size());
-    EDLIB_AMD_HIP(hipMemcpyAsync(out.data(), d_out.p, out.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-    for (size_t i = 0; i < units.size(); ++i) res[units[i]].alphabetLength = out[i];
+    EDLIB_AMD_HIP(hipMemcpyAsync(alphaPin_.p, d_alphaOut_.p, n * sizeof(int), hipMemcpyDeviceToHost, side_));
+    alphaPending_ = true;
+    return 0;
+}
+
+int Batch::alphabetLengthsEnd(std::vector<UnitResult>& res)
+{
+    if (alphaUnits_.empty()) return 0;
+    if (alphaOnHost_) {
+        // a handful of short sequences (edlibAlign() on a pair): counting distinct bytes on the host costs less than
+        // a launch and a round trip; the sequences are still in the staging block of init()
+        const uint8_t* hq = h_in_.p + (d_qpool_.p - d_in_.p);
+        const uint8_t* ht = h_in_.p + (d_tpool_.p - d_in_.p);
+        for (int u : alphaUnits_) {
+            bool seen[256] = {false};
+            int cnt = 0;
+            auto add = [&](const uint8_t* p, long long len) { for (long long i = 0; i < len; ++i) if (!seen[p[i]]) { seen[p[i]] = true; ++cnt; } };
+            add(hq + qoff_[u], qlen(u));
+            if (!shared_) add(ht + toff_[u], tlen(u));
+            else for (int b = 0; b < 256; ++b) if ((tab_.presence[b >> 5] >> (b & 31)) & 1u) { if (!seen[b]) { seen[b] = true; ++cnt; } }
+            res[u].alphabetLength = cnt;
+        }
+        return 0;
+    }
+    if (!alphaPending_) return 0;
+    EDLIB_AMD_HIP(hipStreamSynchronize(side_));
+    alphaPending_ = false;
+    const int* out = reinterpret_cast<const int*>(alphaPin_.p);
+    for (size_t i = 0; i < alphaUnits_.size(); ++i) res[alphaUnits_[i]].alphabetLength = out[i];
     return 0;
 }
 
@@ -1492,17 +1521,30 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
             if (blocks(i) <= ringOf[l] || est <= ring_max_k(ringOf[l])) return l;
         return est <= 2.0 * ring_max_k(64) ? nl - 1 : nl;               // far above every band: straight to the strips
     };
-    std::vector<int> lvl(n);
+    std::vector<int>& lvl = lvlScratch_;
+    lvl.resize(n);
     // A few units do not fill the chip at any ring size: a level then costs its ~T dependent steps on one wave
     // whether it succeeds or not (a 10 kb pair: 1.7 ms per level), so units with more blocks than a ring holds
     // go straight to whole-wave rings (K = 3968) instead of climbing.
     const bool fewUnits = n <= 512 && rate == 0.0;
-    for (size_t i = 0; i < n; ++i) {
-        lvl[i] = bandOff ? nl : first_level(i);
-        if (!bandOff && fewUnits && lvl[i] < nl - 1 && blocks(i) > ringOf[lvl[i]]) lvl[i] = nl - 1;
+    std::vector<size_t> atLevel(nl + 2, 0);
+    {
+        int lastQ = -1, lastT = -1, lastL = 0;                           // batches of equal shapes: one evaluation
+        for (size_t i = 0; i < n; ++i) {
+            if (units[i].qlen != lastQ || units[i].tlen != lastT) {
+                lastQ = units[i].qlen; lastT = units[i].tlen;
+                lastL = bandOff ? nl : first_level(i);
+                if (!bandOff && fewUnits && lastL < nl - 1 && blocks(i) > ringOf[lastL]) lastL = nl - 1;
+            }
+            lvl[i] = lastL;
+            ++atLevel[lastL];
+        }
     }
     for (int l = 0; l <= nl; ++l) {
-        std::vector<UnitSpec> sel; std::vector<size_t> who;
+        if (atLevel[l] == 0) continue;
+        std::vector<UnitSpec>& sel = selScratch_; std::vector<size_t>& who = whoScratch_;
+        sel.clear(); who.clear();
+        sel.reserve(atLevel[l]); who.reserve(atLevel[l]);
         for (size_t i = 0; i < n; ++i) {
             if (lvl[i] != l) continue;
             UnitSpec u = units[i];
@@ -1510,13 +1552,13 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
             sel.push_back(u); who.push_back(i);
         }
         if (sel.empty()) continue;
-        SolveOut so;
+        SolveOut& so = soLevel_;
         if (solve(EDLIB_MODE_NW, false, false, sel, so, l < nl ? ringOf[l] : 0)) return 1;
         for (size_t q = 0; q < sel.size(); ++q) {
             const size_t i = who[q];
             if (l == nl || so.score[q] <= sel[q].kinit) score[i] = so.score[q];         // exact
             else if (sel[q].kinit >= kcap) score[i] = kInf;                              // > k: final
-            else lvl[i] = l + 1;                                                         // next level
+            else { lvl[i] = l + 1; ++atLevel[l + 1]; }                                   // next level
         }
     }
     return 0;
@@ -1566,6 +1608,7 @@ int Batch::run()
         else if (mode == EDLIB_MODE_SHW || mode == EDLIB_MODE_HW) { r.editDistance = m; r.ends.assign(1, -1); r.hasEnds = true; }
         else r.status = EDLIB_STATUS_ERROR;
     }
+    if (alphabetLengthsBegin()) return 1;
     // ---- phase 1: distance + end locations
     if (runReads()) return 1;
     readsCollected_ = groups_.empty();
@@ -1574,15 +1617,18 @@ int Batch::run()
     if (!readsCollected_ && cfg_.task != EDLIB_TASK_DISTANCE && collectReads(res)) return 1;
     lap("run: collect reads");
     if (!pairUnits_.empty()) {
-        std::vector<UnitSpec> units(pairUnits_.size());
+        // scratch that a run needs per unit lives in the batch: a fresh 10 MB std::vector is an mmap, its page faults
+        // and a munmap (45 MB of them were 5 of the 9 ms a run over 262,144 short pairs took)
+        std::vector<UnitSpec>& units = pairSpecs_;
+        units.resize(pairUnits_.size());
         for (size_t i = 0; i < units.size(); ++i) {
             const int u = pairUnits_[i], m = qlen(u);
             units[i] = UnitSpec{qoff_[u], m, 1, tbase(u), tlen(u), 1,
                                 (cfg_.k < 0 || cfg_.k > m) ? m : cfg_.k};
         }
-        SolveOut so;
+        SolveOut& so = soMain_;
         if (scanMode == EDLIB_MODE_NW) {
-            std::vector<int> score;
+            std::vector<int>& score = scoreMain_;
             if (solveGlobalDistances(units, score)) return 1;
             for (size_t i = 0; i < units.size(); ++i)
                 finalize_global(res[pairUnits_[i]], cfg_.k, mode, units[i].tlen, score[i]);
@@ -1593,11 +1639,7 @@ int Batch::run()
                                     so.posFlat.data() + so.posStart[i], so.posStart[i + 1] - so.posStart[i]);
         }
     }
-    {   // alphabetLength for everything the reads path did not cover
-        std::vector<int> rest(emptyUnits_);
-        rest.insert(rest.end(), pairUnits_.begin(), pairUnits_.end());
-        if (alphabetLengths(rest, res)) return 1;
-    }
+    if (alphabetLengthsEnd(res)) return 1;      // alphabetLength for everything the reads path did not cover
     lap("run: phase 1 (distance)");
     std::vector<int>& live = live_;            // non-empty units with a solution (only the later phases want them)
     live.clear();
@@ -1695,19 +1737,28 @@ int Batch::run()
             }
         }
         stats.algo_bytes = algoBase_;
-    } else {
-        stats.algo_bytes = 0;
-        for (int u = 0; u < n_; ++u) {
-            const long long m = qlen(u);
-            const long long sigma = res[u].alphabetLength ? res[u].alphabetLength : tab_.sigmaT;
-            stats.algo_bytes += tlen(u) + m + 8LL * (sigma + 1) * ((m + 63) / 64) + 16
-                                + 4LL * std::max<long long>(1, (long long)res[u].ends.size());
-        }
-    }
+        algoDirty_ = false;
+    } else algoDirty_ = true;                   // a walk over every record: done when somebody asks (finishStats)
     results_.swap(res);
     haveResults_ = true;
     lap("run: stats");
     return 0;
+}
+
+// algorithmic bytes of the last run: target + query + Peq + result header + end locations.  A walk
+// over every record: done when the statistics are asked for, not in every run.
+void Batch::finishStats()
+{
+    if (!algoDirty_) return;
+    algoDirty_ = false;
+    const std::vector<UnitResult>& res = results_;
+    stats.algo_bytes = 0;
+    for (int u = 0; u < n_ && (size_t)u < res.size(); ++u) {
+        const long long m = qlen(u);
+        const long long sigma = res[u].alphabetLength ? res[u].alphabetLength : tab_.sigmaT;
+        stats.algo_bytes += tlen(u) + m + 8LL * (sigma + 1) * ((m + 63) / 64) + 16
+                            + 4LL * std::max<long long>(1, (long long)res[u].ends.size());
+    }
 }
 
 // ------------------------------------------------------------ marshalling

@@ -119,6 +119,7 @@ public:
     int resultsFlat(int* status, int* editDistance, int* numLocations, int* alphabetLength, long long* locOffsets,
                     int** endLocations, int** startLocations, long long* alnOffsets, unsigned char** alignment);
     EdlibAmdBatchStats stats{};
+    void finishStats();          // fills the fields of `stats` that cost a walk over the records (algo_bytes)
 
 private:
     // ---- configuration
@@ -190,7 +191,12 @@ private:
     // SHW / HW units: short queries packed on 4- and 16-lane rings, the rest on the strips
     int solveSemiGlobal(int mode, bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out);
     int solveSemiGlobalUnits(int mode, bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out);
-    int alphabetLengths(const std::vector<int>& units, std::vector<UnitResult>& res);
+    // alphabetLength of the empty / pair units: launched on a side stream before phase 1, collected after it
+    int alphabetLengthsBegin();
+    int alphabetLengthsEnd(std::vector<UnitResult>& res);
+    std::vector<int> alphaUnits_; bool alphaOnHost_ = false, alphaPending_ = false;
+    hipStream_t side_ = nullptr;
+    DevBuf<int> d_alphaIdx_, d_alphaOut_; PinBuf alphaPin_;
     // linear-space paths (reference obtainAlignmentHirschberg, edlib.cpp:1231-1396)
     struct Piece { long long qoff; int m; long long toff; int T; int score; };
     int hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& splitRow,
@@ -212,6 +218,10 @@ private:
     std::vector<UnitSpec> startUnits_; std::vector<std::pair<int, int>> startWhere_; std::vector<int> live_;
     bool haveResults_ = false;
     long long algoBase_ = -1;     // algorithmic bytes of the batch while its results are still on the device
+    bool algoDirty_ = false;
+    // per-unit scratch of the pair path, kept across runs (fresh multi-megabyte vectors are mmap + page faults + munmap)
+    std::vector<UnitSpec> pairSpecs_, selScratch_; std::vector<size_t> whoScratch_; std::vector<int> lvlScratch_, scoreMain_;
+    SolveOut soMain_, soLevel_;
 };
 
 // single-pair convenience used by edlibAlign()

@@ -58,20 +58,25 @@ long long pair_store_entries(int qlen, int tlen) {
 
 // ------------------------------------------------------------------ buildPeq
 
-// One workgroup per unit.  The equality relation of 32 target symbols at a time is folded into a
-// 256-entry LDS table (query byte -> bit s set iff it equals symbol s); a thread then owns one block of
-// four symbols: 64 query bytes, one table lookup each, four 64-bit words out.
+// The equality relation of 32 target symbols at a time is folded into a 256-entry LDS table (query byte -> bit s set
+// iff it equals symbol s).  A wave then builds 64 rows at once: the lanes load 64 consecutive query bytes (one
+// coalesced line), look their symbol sets up, and a ballot per symbol IS the 64-bit Peq word of that block; lane j of
+// the wave keeps the words of block j of a tile of 64 blocks, so the tile goes out as whole lines per symbol row.
+// (Round 1 / 2 gave every thread a block: 64 dependent byte loads each from its own line, and a 256-thread workgroup
+// per unit of which three threads had work when the units were 150-base reads.)
 // bit r of Peq[sym][b] = eq8[query[64b+r]][byte of sym]; rows past the query end are 0
 // (the kernels follow row m-1 explicitly, so the reference's wildcard padding,
 // edlib.cpp:373-375, is not needed).
+// perWave = 1: a wave per unit (many short units); 0: a workgroup per unit, its four waves taking tiles in turn.
 __global__ void __launch_bounds__(256)
-build_peq_pairs_kernel(const PairDesc* __restrict__ descs, const uint8_t* __restrict__ qpool,
+build_peq_pairs_kernel(const PairDesc* __restrict__ descs, int numUnits, int perWave, const uint8_t* __restrict__ qpool,
                        const uint8_t* __restrict__ eq8, const uint8_t* __restrict__ idToByte,
                        int sigmaT, u64* __restrict__ peq)
 {
     __shared__ u32 s_mask[256];
-    const PairDesc d = descs[blockIdx.x];
-    const int nb = num_blocks(d.qlen);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int u0 = perWave ? blockIdx.x * 4 + wv : blockIdx.x, ustep = perWave ? gridDim.x * 4 : gridDim.x;
+    const int tile0 = perWave ? 0 : wv * 64, tstep = perWave ? 64 : 256;
     for (int g0 = 0; g0 < sigmaT; g0 += 32) {
         const int ns = (sigmaT - g0) < 32 ? (sigmaT - g0) : 32;
         __syncthreads();
@@ -84,24 +89,32 @@ build_peq_pairs_kernel(const PairDesc* __restrict__ descs, const uint8_t* __rest
             s_mask[threadIdx.x] = mk;
         }
         __syncthreads();
-        const int nch = (ns + 3) >> 2;
-        for (int it = threadIdx.x; it < nb * nch; it += blockDim.x) {
-            const int ch = it / nb, blk = it - ch * nb;            // neighbouring threads: neighbouring blocks
-            const int r0 = blk * 64;
-            const int rn = (d.qlen - r0) < 64 ? (d.qlen - r0) : 64;
-            const uint8_t* qp = qpool + d.qoff + (long long)r0 * d.qstep;
-            u64 w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-            for (int r = 0; r < rn; ++r) {
-                const u32 mk = s_mask[qp[(long long)r * d.qstep]] >> (4 * ch);
-                w0 |= (u64)(mk & 1u) << r; w1 |= (u64)((mk >> 1) & 1u) << r;
-                w2 |= (u64)((mk >> 2) & 1u) << r; w3 |= (u64)((mk >> 3) & 1u) << r;
+        for (int u = u0; u < numUnits; u += ustep) {                       // wave-uniform
+            const long long qoff = descs[u].qoff, peqOff = descs[u].peqOff;
+            const int qlen = descs[u].qlen, qstep = descs[u].qstep;
+            const int nb = num_blocks(qlen);
+            for (int t0 = tile0; t0 < nb; t0 += tstep) {
+                const int tn = (nb - t0) < 64 ? (nb - t0) : 64;
+                for (int c0 = 0; c0 < ns; c0 += 4) {                       // four symbols per trip over the tile's bytes
+                    u64 w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+                    for (int j = 0; j < tn; ++j) {
+                        const int row = (t0 + j) * 64 + lane;
+                        u32 mk = 0;
+                        if (row < qlen) mk = s_mask[qpool[qoff + (long long)row * qstep]] >> c0;
+                        const u64 b0 = __builtin_amdgcn_ballot_w64((mk & 1u) != 0), b1 = __builtin_amdgcn_ballot_w64((mk & 2u) != 0);
+                        const u64 b2 = __builtin_amdgcn_ballot_w64((mk & 4u) != 0), b3 = __builtin_amdgcn_ballot_w64((mk & 8u) != 0);
+                        const bool mine = lane == j;
+                        w0 = mine ? b0 : w0; w1 = mine ? b1 : w1; w2 = mine ? b2 : w2; w3 = mine ? b3 : w3;
+                    }
+                    if (lane < tn) {
+                        u64* out = peq + peqOff + (long long)(g0 + c0) * nb + t0 + lane;
+                        out[0] = w0;
+                        if (c0 + 1 < ns) out[nb] = w1;
+                        if (c0 + 2 < ns) out[2LL * nb] = w2;
+                        if (c0 + 3 < ns) out[3LL * nb] = w3;
+                    }
+                }
             }
-            const int s0 = g0 + 4 * ch;
-            u64* out = peq + d.peqOff + (long long)s0 * nb + blk;
-            out[0] = w0;
-            if (s0 + 1 < g0 + ns) out[nb] = w1;
-            if (s0 + 2 < g0 + ns) out[2LL * nb] = w2;
-            if (s0 + 3 < g0 + ns) out[3LL * nb] = w3;
         }
     }
 }
@@ -111,8 +124,12 @@ hipError_t launch_build_peq_pairs(const PairDesc* descs, int numUnits, const uin
                                   u64* peq, hipStream_t stream)
 {
     if (numUnits == 0) return hipSuccess;
-    hipLaunchKernelGGL(build_peq_pairs_kernel, dim3(numUnits), dim3(256), 0, stream,
-                       descs, qpool, eq8, idToByte, sigmaT, peq);
+    // a handful of (possibly very long) units: a workgroup each; many units: a wave each, enough workgroups to
+    // fill the chip several times
+    const int perWave = numUnits >= 2048 ? 1 : 0;
+    const int wgs = perWave ? (numUnits + 3) / 4 : numUnits;
+    hipLaunchKernelGGL(build_peq_pairs_kernel, dim3(wgs < 16384 ? wgs : 16384), dim3(256), 0, stream,
+                       descs, numUnits, perWave, qpool, eq8, idToByte, sigmaT, peq);
     return hipGetLastError();
 }
 
