@@ -1064,23 +1064,25 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         }
     }
     size_t oj = 0;
-    if (wantPositions && mode != EDLIB_MODE_NW) {
-        size_t tot = ovfPos.size();
-        for (size_t i = 0; i < n; ++i) tot += (size_t)std::min(std::max(count[i], 0), kPosCap);
-        out.posFlat.reserve(out.posFlat.size() + tot);
+    const bool lists = wantPositions && mode != EDLIB_MODE_NW;
+    size_t w = out.posFlat.size();                                     // positions are written in place: one resize per chunk
+    if (lists) {
+        size_t tot = 0;
+        for (size_t i = 0; i < n; ++i) if (score[i] >= 0) tot += (size_t)std::max(count[i], 0);
+        out.posFlat.resize(w + tot);
     }
+    int* pf = out.posFlat.data();
     for (size_t i = 0; i < n; ++i) {
         const size_t g = ua + i;
         out.score[g] = score[i]; out.count[g] = count[i]; out.last[g] = last[i];
-        if (wantPositions && mode != EDLIB_MODE_NW && score[i] >= 0) {
-            if (oj < ovf.size() && ovf[oj] == (int)i) {
-                out.posFlat.insert(out.posFlat.end(), ovfPos.begin() + ovfOff[oj], ovfPos.begin() + ovfOff[oj + 1]);
-                ++oj;
-            } else {
-                out.posFlat.insert(out.posFlat.end(), pool + i * kPosCap, pool + i * kPosCap + count[i]);
-            }
+        if (lists && score[i] >= 0) {
+            const int* src = pool + i * kPosCap;
+            if (oj < ovf.size() && ovf[oj] == (int)i) { src = ovfPos.data() + ovfOff[oj]; ++oj; }
+            const int c = std::max(count[i], 0);
+            for (int k = 0; k < c; ++k) pf[w + k] = src[k];
+            w += (size_t)c;
         }
-        out.posStart[g + 1] = (long long)out.posFlat.size();
+        out.posStart[g + 1] = (long long)w;
         if (wantPath && ops) {
             out.opsPtr[g] = ops->p + opsOff[i + 1] - opsLen[i];
             out.opsLen[g] = opsLen[i];
