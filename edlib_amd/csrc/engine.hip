@@ -1514,7 +1514,7 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
     // of a unit of length L at rate r scatters like a sum of L Bernoulli trials (sigma = sqrt(r L)).  A ring of G
     // lanes costs G / 64 of a wave per unit, so trying the smaller ring first pays as long as fewer than a quarter
     // to a half of the units fail on it and move up: the estimate is the mean plus half a sigma (10 kb pairs at
-    // 11.4 % sit under the 21-lane ring's 1216 -- three units per wave instead of two -- and the 1 % above it rerun).
+    // 11.4 % sit under the 21-lane ring's 1216 -- three units per wave instead of two -- and the 7 % above it rerun).
     auto first_level = [&](size_t i) {
         const UnitSpec& u = units[i];
         const double mean = rate * std::min(u.qlen, u.tlen) + std::abs(u.qlen - u.tlen);
