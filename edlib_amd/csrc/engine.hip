@@ -404,10 +404,11 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
         const char* env = getenv("EDLIB_AMD_BAND");
         banded_ = (mode == EDLIB_MODE_HW) && (!(env && env[0] == '0') || syms_ > 4);   // more than 4 symbols: banded kernel only
     }
-    // reads of 257..512 bases: banded / full-height HW kernels only, up to 8 target symbols (EDLIB_AMD_LONGREADS=0: pair path)
+    // reads of 257..1024 bases (..512 above four target symbols): banded / full-height HW kernels only (EDLIB_AMD_LONGREADS=0: pair path)
     static const bool longReads = !(getenv("EDLIB_AMD_LONGREADS") && getenv("EDLIB_AMD_LONGREADS")[0] == '0');
-    const int maxReadLen = 32 * ((banded_ && modeIn == EDLIB_MODE_HW && syms_ <= 8 && longReads) ? kMaxLongReadWords : kMaxReadWords);
-    std::vector<std::vector<int>> byWords(kMaxLongReadWords + 1);
+    const int maxReadLen = 32 * ((banded_ && modeIn == EDLIB_MODE_HW && syms_ <= 8 && longReads)
+                                     ? (syms_ == 4 ? kMaxLongReadWords4 : kMaxLongReadWords) : kMaxReadWords);
+    std::vector<std::vector<int>> byWords(kMaxLongReadWords4 + 1);
     for (int u = 0; u < n; ++u) {
         const int m = qlen(u), T = tlen(u);
         if (m == 0 || T == 0) emptyUnits_.push_back(u);
@@ -426,7 +427,7 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
 
     // reads-per-lane groups: one per query word count, slots padded to whole waves
     const int T = shared_ ? tlen(0) : 0;
-    for (int w = 1; w <= kMaxLongReadWords; ++w) {
+    for (int w = 1; w <= kMaxLongReadWords4; ++w) {
         if (byWords[w].empty()) continue;
         std::unique_ptr<ReadGroup> g(new ReadGroup);
         g->nwords = w;

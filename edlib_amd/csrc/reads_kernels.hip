@@ -216,7 +216,7 @@ hipError_t launch_build_peq_reads(int nwords, int syms, const uint8_t* reads, co
     if (syms != 4 && syms != 8 && syms != 16) return hipErrorInvalidValue;
     switch (nwords) {
 #define CASE(N) case N: return launch_build_peq_t<N>(reads, qoff, perm, nslots, syms, eqtbl, tpres, kcfg, peq, qlen, kinit, alphaExtra, stream);
-        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(12) CASE(16)
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(12) CASE(16) CASE(24) CASE(32)
 #undef CASE
     }
     return hipErrorInvalidValue;
@@ -501,10 +501,12 @@ __device__ __forceinline__ void lds_rows_chunk(u32 (&n)[NA], const u32 pr)
 template <int NA, int J, int S>
 __device__ __forceinline__ void lds_rows_request(u32 (&n)[NA], const u32 lo, const u32 hi)
 {
-    static_assert(NA >= 1 && NA <= 16, "band height");
+    static_assert(NA >= 1 && NA <= 32, "band height");
     const u32 pr = (J < 2) ? lo : hi;
-    if constexpr (NA <= 8) lds_rows_chunk<NA, 0, NA, J, S>(n, pr);
-    else { lds_rows_chunk<NA, 0, 8, J, S>(n, pr); lds_rows_chunk<NA, 8, NA - 8, J, S>(n, pr); }
+    lds_rows_chunk<NA, 0, (NA < 8 ? NA : 8), J, S>(n, pr);
+    if constexpr (NA > 8) lds_rows_chunk<NA, 8, (NA - 8 < 8 ? NA - 8 : 8), J, S>(n, pr);
+    if constexpr (NA > 16) lds_rows_chunk<NA, 16, (NA - 16 < 8 ? NA - 16 : 8), J, S>(n, pr);
+    if constexpr (NA > 24) lds_rows_chunk<NA, 24, NA - 24, J, S>(n, pr);
 }
 template <int NA, int W0, int CNT>
 __device__ __forceinline__ void lds_rows_wait_chunk(u32 (&n)[NA])
@@ -523,8 +525,10 @@ __device__ __forceinline__ void lds_rows_wait_chunk(u32 (&n)[NA])
 template <int NA>
 __device__ __forceinline__ void lds_rows_wait(u32 (&n)[NA])
 {
-    if constexpr (NA <= 8) lds_rows_wait_chunk<NA, 0, NA>(n);
-    else { lds_rows_wait_chunk<NA, 0, 8>(n); lds_rows_wait_chunk<NA, 8, NA - 8>(n); }   // the second wait is free
+    lds_rows_wait_chunk<NA, 0, (NA < 8 ? NA : 8)>(n);                                     // the waits after the first are free
+    if constexpr (NA > 8) lds_rows_wait_chunk<NA, 8, (NA - 8 < 8 ? NA - 8 : 8)>(n);
+    if constexpr (NA > 16) lds_rows_wait_chunk<NA, 16, (NA - 16 < 8 ? NA - 16 : 8)>(n);
+    if constexpr (NA > 24) lds_rows_wait_chunk<NA, 24, NA - 24>(n);
 }
 
 // ---- the band of one word carries the rows of the NEXT quad across quads (requested while the current
@@ -594,12 +598,12 @@ __device__ __forceinline__ void column_step_hw(const u32 (&Eq)[NA], u32 (&Pv)[NW
             e += (int)((Ph[NA - 1] >> sh) & 1u);
             e -= (int)((Mh[NA - 1] >> sh) & 1u);
         } else {
-            // groups of 12 and 16 words hold queries of 9..12 and 13..16 words: sh is m - 1 itself, the row's word
-            // (one of the last four) is picked per lane
+            // groups of 12 / 16 / 24 / 32 words hold queries of 9..12 / 13..16 / 17..24 / 25..32 words: sh is m - 1
+            // itself, the row's word (one of the last four or eight) is picked per lane
             const u32 lw = sh >> 5;
             u32 phs = Ph[NWD - 1], mhs = Mh[NWD - 1];
 #pragma unroll
-            for (int d = 2; d <= 4; ++d) {
+            for (int d = 2; d <= (NWD > 16 ? 8 : 4); ++d) {
                 const bool here = lw == (u32)(NWD - d);
                 phs = here ? Ph[NWD - d] : phs;
                 mhs = here ? Mh[NWD - d] : mhs;
@@ -625,12 +629,12 @@ __device__ __forceinline__ void column_step_hw(const u32 (&Eq)[NA], u32 (&Pv)[NW
     }
 }
 
-// Band heights the banded kernel is unrolled for: every height up to 8 words; the groups of 12 and 16 words (reads of
-// 257..512 bases) step 1, 2, 3, 4, 6, 8, 12(, 16) -- the code of a height is four unrolled quads of NA words each, and
-// a band that tall is moving fast anyway.
+// Band heights the banded kernel is unrolled for: every height up to 8 words; the groups of 12, 16, 24 and 32 words
+// (reads of 257..1024 bases) step 1, 2, 3, 4, 6, 8, 12, 16, 24, 32 -- the code of a height is four unrolled quads of NA
+// words each, and a band that tall is moving fast anyway.
 template <int NWD> __host__ __device__ constexpr bool band_height_ok(int h)
 {
-    return h >= 1 && h <= NWD && (NWD <= 8 || h <= 4 || h == 6 || h == 8 || h == 12 || h == NWD);
+    return h >= 1 && h <= NWD && (NWD <= 8 || h <= 4 || h == 6 || h == 8 || h == 12 || h == 16 || h == 24 || h == NWD);
 }
 template <int NWD> __host__ __device__ constexpr int band_height_up(int h)   { int n = h + 1; while (n < NWD && !band_height_ok<NWD>(n)) ++n; return n; }
 template <int NWD> __host__ __device__ constexpr int band_height_down(int h) { int n = h - 1; while (n > 1 && !band_height_ok<NWD>(n)) --n; return n; }
@@ -869,7 +873,7 @@ scan_reads_banded_kernel(const ReadScanArgs a)
                 bandWork += (unsigned int)NA * (unsigned int)(b * 4 + q - q0);                                  \
             }                                                                                                   \
             break;
-            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(12) CASE(16)
+            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(12) CASE(16) CASE(24) CASE(32)
 #undef CASE
 #undef ADVANCE
 #undef QUAD
@@ -954,6 +958,8 @@ static hipError_t launch_scan_reads_full_s(int nwords, const ReadScanArgs& a, hi
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
         case 12: if constexpr (S <= 8) { hipLaunchKernelGGL((scan_reads_full_kernel<12, S>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
         case 16: if constexpr (S <= 8) { hipLaunchKernelGGL((scan_reads_full_kernel<16, S>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
+        case 24: if constexpr (S == 4) { hipLaunchKernelGGL((scan_reads_full_kernel<24, S>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
+        case 32: if constexpr (S == 4) { hipLaunchKernelGGL((scan_reads_full_kernel<32, S>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
 #undef CASE
         default: return hipErrorInvalidValue;
     }
@@ -982,6 +988,9 @@ static hipError_t launch_scan_reads_banded_s(int nwords, const ReadScanArgs& a, 
         // reads of 257..512 bases: targets of up to 8 symbols (16 would need 64 KB of LDS rows per wave)
         case 12: if constexpr (S <= 8) { hipLaunchKernelGGL((scan_reads_banded_kernel<12, S>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
         case 16: if constexpr (S <= 8) { hipLaunchKernelGGL((scan_reads_banded_kernel<16, S>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
+        // 513..1024 bases: four-symbol targets (24 / 32 KB of LDS rows per wave)
+        case 24: if constexpr (S == 4) { hipLaunchKernelGGL((scan_reads_banded_kernel<24, S>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
+        case 32: if constexpr (S == 4) { hipLaunchKernelGGL((scan_reads_banded_kernel<32, S>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
 #undef CASE
         default: return hipErrorInvalidValue;
     }

@@ -7,10 +7,12 @@
 namespace edlib_amd {
 
 constexpr int kMaxReadWords = 8;      // queries up to 256 symbols: one kernel instance per word count, every mode
-// HW against up to 8 target symbols, banded kernel only: queries of 257..384 / 385..512 symbols run in groups of 12 /
-// 16 words (the row m-1 of a lane may sit in any of the group's last four words)
-constexpr int kMaxLongReadWords = 16;
-inline int read_group_words(int m) { const int w = (m + 31) / 32; return w <= kMaxReadWords ? w : (w <= 12 ? 12 : 16); }
+// HW, banded kernel only: queries of 257..384 / 385..512 symbols run in groups of 12 / 16 words (targets of up to 8
+// symbols), 513..768 / 769..1024 in groups of 24 / 32 words (four symbols); the row m-1 of a lane may sit in any of
+// the group's last four (eight) words
+constexpr int kMaxLongReadWords = 16;       // targets of 5..8 symbols
+constexpr int kMaxLongReadWords4 = 32;      // targets of up to 4 symbols
+inline int read_group_words(int m) { const int w = (m + 31) / 32; return w <= kMaxReadWords ? w : (w <= 12 ? 12 : (w <= 16 ? 16 : (w <= 24 ? 24 : 32))); }
 constexpr int kLanes = 64;            // wave64, hard-coded (gfx950)
 
 // Everything the scan kernel needs; plain pointers into HBM.

@@ -1,6 +1,6 @@
-"""-m gpu: HW reads of 257..512 bases against a shared target stay on the reads-per-lane kernels (groups of 12 and 16
-words: the bottom row of a lane sits in any of the group's last four words, band heights step 1, 2, 3, 4, 6, 8, 12,
-16).  Reference semantics: edlib.cpp:550-704 (the semi-global scan and its band), 197-217 (k-doubling).  Every field
+"""-m gpu: HW reads of 257..1024 bases against a shared target stay on the reads-per-lane kernels (groups of 12, 16, 24
+and 32 words: the bottom row of a lane sits in any of the group's last four / eight words, band heights step 1, 2,
+3, 4, 6, 8, 12, 16, 24, 32; above four target symbols the limit is 512 bases).  Reference semantics: edlib.cpp:550-704 (the semi-global scan and its band), 197-217 (k-doubling).  Every field
 of every read is compared with the oracle (native thread pool over the reference / the restatement)."""
 import numpy as np
 import pytest
@@ -111,7 +111,7 @@ def test_neighbours_of_the_range_and_short_reads_in_one_batch(engine):
     lengths = [1, 31, 32, 33, 150, 255, 256, 257, 512, 513, 514, 600, 1000] * 6
     reads = _reads(target, [max(m, 1) for m in lengths], 73, unrelated_every=5)
     st = _check(engine, reads, target, "distance")
-    assert st["path"] == 3
+    assert st["path"] == 1
     _check(engine, reads, target, "path")
 
 
@@ -140,3 +140,62 @@ def test_repeats_overflow_the_end_location_lists(engine):
             reads.append(r)
     _check(engine, reads, target, "distance")
     _check(engine, reads, target, "locations")
+
+
+_EDGES_1K = [513, 514, 543, 544, 545, 576, 577, 640, 641, 704, 705, 736, 737, 767, 768, 769, 770, 800, 801, 832, 833, 896,
+             897, 960, 961, 992, 993, 1023, 1024]
+
+
+@pytest.mark.parametrize("task", ["distance", "locations", "path"])
+def test_mixed_lengths_513_to_1024(engine, task):
+    target = synth.random_dna(81, 60_000)
+    rng = np.random.default_rng(82)
+    n = 500 if task == "distance" else 150
+    lengths = _EDGES_1K + [int(x) for x in rng.integers(513, 1025, n)]
+    reads = _reads(target, lengths, 83, unrelated_every=9)
+    st = _check(engine, reads, target, task)
+    if task == "distance":
+        assert st["path"] == 1, "a read of 513..1024 bases left the reads-per-lane kernels"
+
+
+@pytest.mark.parametrize("k", [0, 5, 60, 150, 2000])
+def test_fixed_k_up_to_1024(engine, k):
+    target = synth.random_dna(84, 40_000)
+    rng = np.random.default_rng(85 + k)
+    lengths = _EDGES_1K + [int(x) for x in rng.integers(257, 1025, 200)]
+    reads = _reads(target, lengths, 86 + k, unrelated_every=7, max_err=0.2)
+    _check(engine, reads, target, "distance", k=k)
+
+
+def test_every_group_in_one_batch_and_1025_on_the_pair_path(engine):
+    target = synth.random_dna(87, 30_000)
+    lengths = [20, 150, 256, 257, 384, 385, 512, 513, 768, 769, 1024, 1025, 1500] * 5
+    reads = _reads(target, lengths, 88, unrelated_every=6)
+    st = _check(engine, reads, target, "distance")
+    assert st["path"] == 3
+    _check(engine, reads, target, "locations")
+
+
+def test_five_symbols_stop_at_512(engine):
+    target = synth.masked_genome(89, 30_000, frac_lower=0.0)
+    reads = _reads(target, [300, 512, 513, 700, 1024] * 8, 90)
+    st = _check(engine, reads, target, "distance")
+    assert st["path"] == 3
+
+
+def test_large_long_batch_through_probe_and_both_passes(engine):
+    """>= 16384 slots in the 24- and 32-word groups: probe, pass 1, and unrelated leftovers on scan_reads_full_kernel"""
+    target = synth.random_dna(91, 8_000)
+    rng = np.random.default_rng(92)
+    lengths = [int(x) for x in rng.integers(513, 769, 16500)] + [int(x) for x in rng.integers(769, 1025, 16500)]
+    reads = _reads(target, lengths, 93, unrelated_every=3, max_err=0.02)
+    st = _check(engine, reads, target, "distance")
+    assert st["path"] == 1
+
+
+def test_equalities_with_long_reads(engine):
+    target = synth.random_dna(94, 30_000)
+    reads = _reads(target, [300, 500, 700, 1000] * 12, 95)
+    for r in reads[::3]:
+        r[::17] = ord("N")
+    _check(engine, reads, target, "locations", eq=[("N", "A"), ("N", "C"), ("N", "G"), ("N", "T")])

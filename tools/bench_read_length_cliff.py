@@ -1,4 +1,4 @@
-"""HW reads of 150 .. 600 bases against 5 Mb: where the reads-per-lane kernels end (512 bases) and what the step
+"""HW reads of 150 .. 1200 bases against 5 Mb: where the reads-per-lane kernels end (1024 bases) and what the step
 costs.  16,384 Illumina-like reads per length; one JSON object.  A strided sample of every batch is checked against
 the oracle (test infrastructure) so that the rates are rates of correct results."""
 import sys, os, json
@@ -11,7 +11,7 @@ from oracle import oracle as O
 T = synth.random_dna(12345, 5_000_000)
 out = {}
 n = 16384
-for m in (150, 256, 257, 300, 384, 385, 450, 512, 513, 600):
+for m in (150, 256, 257, 300, 384, 385, 450, 512, 513, 600, 768, 769, 1024, 1025, 1200):
     R = synth.illumina_reads(T, n, m=m)["reads"]
     b = edlib_amd.SharedBatch(R, T, mode="HW", task="distance")
     b.run(); st = b.run(); got = b.results_flat(); b.close()
