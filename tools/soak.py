@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Differential soak of the batch entry points against the oracle (test infrastructure) for a time budget: random
+shared-target batches over every read-length group of the lane-per-read kernels (1 .. 1100 bases), random pair
+batches over the ring sizes; every field of every unit is compared.  usage: soak.py [seconds] [seed] [max cases]"""
+import sys, os, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np
+import edlib_amd
+from edlib_amd import synth
+from oracle import oracle as O
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 30
+rng = np.random.default_rng(seed)
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+FIELDS = ("status", "editDistance", "numLocations", "alphabetLength", "locOff", "ends", "alnOff", "alignment")
+LENS = [1, 5, 31, 32, 33, 64, 65, 100, 150, 160, 161, 255, 256, 257, 258, 300, 383, 384, 385, 400, 511, 512, 513, 600, 767, 768,
+        769, 900, 1023, 1024, 1025, 1100]
+
+
+def mutate(w, m, rate):
+    n = int(rate * m)
+    for _ in range(n):
+        p = int(rng.integers(0, max(1, min(m, len(w)))))
+        kind = int(rng.integers(0, 3))
+        if kind == 0: w[p] = ACGT[rng.integers(0, 4)]
+        elif kind == 1 and len(w) > 1: w = np.delete(w, p)
+        else: w = np.insert(w, p, ACGT[rng.integers(0, 4)])
+    w = w[:m]
+    if len(w) < m: w = np.concatenate([w, ACGT[rng.integers(0, 4, m - len(w))]])
+    return np.ascontiguousarray(w)
+
+
+def compare(got, ref, task, what):
+    for f in FIELDS:
+        if not np.array_equal(got[f], ref[f]):
+            bad = np.nonzero(got["editDistance"] != ref["editDistance"])[0][:5] if f == "editDistance" else []
+            return "%s: field %s differs %s" % (what, f, list(bad))
+    if task != "distance":
+        # (no unit with a solution: the flat call returns no start array at all)
+        gs = got["starts"] if got["starts"] is not None else np.zeros(0, dtype=np.int32)
+        rs = ref["starts"] if ref["starts"] is not None else np.zeros(0, dtype=np.int32)
+        if len(gs) or len(rs) or len(got["ends"]):
+            if not np.array_equal(gs, rs): return "%s: starts differ" % what
+    return None
+
+
+def shared_case():
+    kind = rng.random()
+    tn = int(rng.choice([2000, 9000, 40000, 150000]))
+    if kind < 0.15:
+        unit = ACGT[rng.integers(0, 4, int(rng.choice([1, 2, 7, 31, 331])))]
+        target = np.tile(unit, tn // len(unit) + 1)[:tn].copy()
+    elif kind < 0.3:
+        target = synth.masked_genome(int(rng.integers(1 << 30)), tn, frac_lower=0.0)      # ACGT + N
+    else:
+        target = synth.random_dna(int(rng.integers(1 << 30)), tn)
+    nq = int(rng.choice([1, 7, 64, 65, 300, 1500]))
+    if rng.random() < 0.4:
+        lens = [int(rng.choice(LENS))] * nq
+    else:
+        lens = [int(rng.choice(LENS)) for _ in range(nq)]
+    reads = []
+    for m in lens:
+        if rng.random() < 0.8 and tn > m + 80:
+            s = int(rng.integers(0, tn - m - 70))
+            reads.append(mutate(target[s:s + m + 64].copy(), m, float(rng.choice([0.0, 0.01, 0.04, 0.1, 0.25]))))
+        else:
+            reads.append(ACGT[rng.integers(0, 4, m)])
+    mode = str(rng.choice(["HW", "HW", "HW", "HW", "SHW", "NW"]))
+    if mode != "HW" and tn > 9000: target = target[:9000]
+    task = str(rng.choice(["distance", "distance", "locations", "path"]))
+    k = int(rng.choice([-1, -1, -1, 0, 4, 8, 9, 30, 100, 700]))
+    b = edlib_amd.SharedBatch(reads, target, mode=mode, task=task, k=k)
+    try:
+        b.run(); got = b.results_flat()
+    finally:
+        b.close()
+    qoff = np.zeros(len(reads) + 1, dtype=np.int64); qoff[1:] = np.cumsum([len(r) for r in reads])
+    ref = O.pool_align(np.concatenate(reads), qoff, target, np.array([0, len(target)], dtype=np.int64), True, mode, task, k)
+    return len(reads), compare(got, ref, task, "shared mode=%s task=%s k=%d tn=%d nq=%d lens=%s" % (mode, task, k, len(target), nq, sorted(set(lens))[:8]))
+
+
+def pair_case():
+    nq = int(rng.choice([1, 5, 17, 300, 3000]))
+    base = int(rng.choice([20, 150, 400, 1000, 3000]))
+    qs, ts = [], []
+    sig = int(rng.choice([2, 4, 4, 4, 20]))
+    alpha = np.frombuffer(b"ACGTDEFHIKLMNPQRSVWY", dtype=np.uint8)[:sig]
+    for _ in range(nq):
+        tn = max(1, int(base * (0.5 + rng.random())))
+        t = alpha[rng.integers(0, sig, tn)]
+        if rng.random() < 0.8:
+            m = max(1, int(tn * (0.6 + 0.6 * rng.random())))
+            q = t[:m].copy() if m <= tn else np.concatenate([t, alpha[rng.integers(0, sig, m - tn)]])
+            nm = int(float(rng.choice([0.0, 0.02, 0.1, 0.3])) * m)
+            for p in rng.integers(0, m, nm): q[p] = alpha[rng.integers(0, sig)]
+        else:
+            q = alpha[rng.integers(0, sig, max(1, int(base * (0.5 + rng.random()))))]
+        qs.append(np.ascontiguousarray(q)); ts.append(np.ascontiguousarray(t))
+    mode = str(rng.choice(["NW", "NW", "HW", "SHW"]))
+    task = str(rng.choice(["distance", "locations", "path"]))
+    k = int(rng.choice([-1, -1, 0, 5, 50, 1000]))
+    b = edlib_amd.PairBatch(qs, ts, mode=mode, task=task, k=k)
+    try:
+        b.run(); got = b.results_flat()
+    finally:
+        b.close()
+    qoff = np.zeros(nq + 1, dtype=np.int64); qoff[1:] = np.cumsum([len(r) for r in qs])
+    toff = np.zeros(nq + 1, dtype=np.int64); toff[1:] = np.cumsum([len(r) for r in ts])
+    ref = O.pool_align(np.concatenate(qs), qoff, np.concatenate(ts), toff, False, mode, task, k)
+    return nq, compare(got, ref, task, "pairs mode=%s task=%s k=%d nq=%d base=%d sigma=%d" % (mode, task, k, nq, base, sig))
+
+
+t0 = time.time(); cases = units = 0; failures = []
+while time.time() - t0 < budget and cases < max_cases:
+    n, err = shared_case() if rng.random() < 0.6 else pair_case()
+    cases += 1; units += n
+    if err:
+        failures.append(err); print("MISMATCH", err, file=sys.stderr)
+        if len(failures) >= 5: break
+print(json.dumps({"seconds": round(time.time() - t0, 1), "seed": seed, "cases": cases, "units": units, "failures": failures}))
+sys.exit(1 if failures else 0)
