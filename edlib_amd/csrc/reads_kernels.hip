@@ -639,6 +639,16 @@ template <int NWD> __host__ __device__ constexpr bool band_height_ok(int h)
 template <int NWD> __host__ __device__ constexpr int band_height_up(int h)   { int n = h + 1; while (n < NWD && !band_height_ok<NWD>(n)) ++n; return n; }
 template <int NWD> __host__ __device__ constexpr int band_height_down(int h) { int n = h - 1; while (n > 1 && !band_height_ok<NWD>(n)) --n; return n; }
 
+static_assert(band_height_up<5>(3) == 4 && band_height_down<5>(3) == 2 && band_height_up<8>(7) == 8, "up to 8 words: every height");
+static_assert(band_height_up<12>(4) == 6 && band_height_up<12>(8) == 12 && band_height_down<12>(12) == 8 && band_height_down<12>(6) == 4, "12-word ladder");
+static_assert(band_height_up<16>(12) == 16 && band_height_down<16>(16) == 12, "16-word ladder");
+static_assert(band_height_up<24>(16) == 24 && band_height_down<24>(24) == 16 && band_height_up<24>(12) == 16, "24-word ladder");
+static_assert(band_height_up<32>(24) == 32 && band_height_down<32>(32) == 24 && band_height_up<32>(16) == 24, "32-word ladder");
+// the per-lane bottom row (word (m-1)/32) must be outside every height below the full one: the group's shortest
+// read has NWD - 4 (NWD - 8 above 16 words) full words above its last one
+static_assert(band_height_down<12>(12) <= 12 - 4 && band_height_down<16>(16) <= 16 - 4 && band_height_down<24>(24) <= 24 - 8 &&
+              band_height_down<32>(32) <= 32 - 8, "bottom row inside the band only at full height");
+
 struct HwTrack {            // per-lane tracking state of the banded kernel
     int best, cnt, cap;
     int* pos;
