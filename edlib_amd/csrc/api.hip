@@ -19,6 +19,17 @@ static void fail_loudly(const char* where) {
     fprintf(stderr, "edlib (MI355X engine): %s failed: %s\n", where, last_error().c_str());
 }
 
+// No C++ exception may cross the C boundary (a caller written in C, or the reference's own clients, have no handler:
+// std::bad_alloc out of a std::vector would be std::terminate).  Every entry point that can allocate runs inside this.
+template <typename R, typename F>
+static R guarded(const char* where, R failValue, F&& body) noexcept {
+    try { return body(); }
+    catch (const std::bad_alloc&) { try { set_error("%s: out of host memory", where); } catch (...) {} }
+    catch (const std::exception& e) { try { set_error("%s: %s", where, e.what()); } catch (...) {} }
+    catch (...) { try { set_error("%s: unknown C++ exception", where); } catch (...) {} }
+    return failValue;
+}
+
 static EdlibAlignResult blank_result(int status) {
     EdlibAlignResult r;
     r.status = status; r.editDistance = -1;
@@ -60,7 +71,8 @@ EDLIB_API EdlibAlignResult edlibAlign(const char* query, int queryLength, const 
                                       int targetLength, const EdlibAlignConfig config) {
     EdlibAlignResult r = blank_result(EDLIB_STATUS_OK);
     if (queryLength < 0 || targetLength < 0) { r.status = EDLIB_STATUS_ERROR; return r; }
-    if (align_one(query, queryLength, target, targetLength, config, &r)) {
+    const int rc = guarded("edlibAlign", 1, [&] { return align_one(query, queryLength, target, targetLength, config, &r); });
+    if (rc) {
         fail_loudly("edlibAlign");
         return blank_result(EDLIB_STATUS_ERROR);
     }
@@ -73,19 +85,21 @@ EDLIB_API char* edlibAlignmentToCigar(const unsigned char* alignment, int alignm
     if (cigarFormat != EDLIB_CIGAR_EXTENDED && cigarFormat != EDLIB_CIGAR_STANDARD) return nullptr;
     static const char ext[4] = {'=', 'I', 'D', 'X'}, stdc[4] = {'M', 'I', 'D', 'M'};
     const char* letters = (cigarFormat == EDLIB_CIGAR_STANDARD) ? stdc : ext;
-    std::string out;
-    int i = 0;
-    while (i < alignmentLength) {
-        if (alignment[i] > 3) return nullptr;
-        const char c = letters[alignment[i]];
-        int run = 0;
-        while (i < alignmentLength && alignment[i] <= 3 && letters[alignment[i]] == c) { ++run; ++i; }
-        out += std::to_string(run);
-        out += c;
-    }
-    char* s = static_cast<char*>(malloc(out.size() + 1));
-    if (s) memcpy(s, out.c_str(), out.size() + 1);
-    return s;
+    return guarded("edlibAlignmentToCigar", static_cast<char*>(nullptr), [&]() -> char* {
+        std::string out;
+        int i = 0;
+        while (i < alignmentLength) {
+            if (alignment[i] > 3) return nullptr;
+            const char c = letters[alignment[i]];
+            int run = 0;
+            while (i < alignmentLength && alignment[i] <= 3 && letters[alignment[i]] == c) { ++run; ++i; }
+            out += std::to_string(run);
+            out += c;
+        }
+        char* s = static_cast<char*>(malloc(out.size() + 1));
+        if (s) memcpy(s, out.c_str(), out.size() + 1);
+        return s;
+    });
 }
 
 // ------------------------------------------------------------ edlib_amd.h
@@ -97,10 +111,13 @@ EDLIB_API const char* edlibAmdVersion(void) { return "edlib-mi355x 0.1 (API of e
 EDLIB_API EdlibAmdBatch* edlibAmdBatchCreateShared(const char* queries, const long long* queryOffsets,
                                                    int numQueries, const char* target, int targetLength,
                                                    EdlibAlignConfig config, int device) {
-    EdlibAmdBatch* b = new (std::nothrow) EdlibAmdBatch;
-    if (!b) { set_error("out of memory"); return nullptr; }
+    EdlibAmdBatch* b = guarded("edlibAmdBatchCreateShared", static_cast<EdlibAmdBatch*>(nullptr), [] { return new EdlibAmdBatch; });
+    if (!b) return nullptr;
     const long long toff[2] = {0, targetLength};
-    if (targetLength < 0 || b->impl.init(queries, queryOffsets, numQueries, target, toff, 1, config, device)) {
+    const int rc = targetLength < 0 ? 1 : guarded("edlibAmdBatchCreateShared", 1, [&] {
+        return b->impl.init(queries, queryOffsets, numQueries, target, toff, 1, config, device); });
+    if (targetLength < 0) set_error("negative target length");
+    if (rc) {
         delete b;
         return nullptr;
     }
@@ -110,10 +127,11 @@ EDLIB_API EdlibAmdBatch* edlibAmdBatchCreateShared(const char* queries, const lo
 EDLIB_API EdlibAmdBatch* edlibAmdBatchCreatePairs(const char* queries, const long long* queryOffsets,
                                                   const char* targets, const long long* targetOffsets,
                                                   int numPairs, EdlibAlignConfig config, int device) {
-    EdlibAmdBatch* b = new (std::nothrow) EdlibAmdBatch;
-    if (!b) { set_error("out of memory"); return nullptr; }
+    EdlibAmdBatch* b = guarded("edlibAmdBatchCreatePairs", static_cast<EdlibAmdBatch*>(nullptr), [] { return new EdlibAmdBatch; });
+    if (!b) return nullptr;
     // a one-pair batch is also a shared-target batch
-    if (b->impl.init(queries, queryOffsets, numPairs, targets, targetOffsets, numPairs, config, device)) {
+    if (guarded("edlibAmdBatchCreatePairs", 1, [&] {
+            return b->impl.init(queries, queryOffsets, numPairs, targets, targetOffsets, numPairs, config, device); })) {
         delete b;
         return nullptr;
     }
@@ -122,20 +140,21 @@ EDLIB_API EdlibAmdBatch* edlibAmdBatchCreatePairs(const char* queries, const lon
 
 EDLIB_API int edlibAmdBatchRun(EdlibAmdBatch* b) {
     if (!b) { set_error("null batch"); return EDLIB_STATUS_ERROR; }
-    return b->impl.run() ? EDLIB_STATUS_ERROR : EDLIB_STATUS_OK;
+    return guarded("edlibAmdBatchRun", 1, [&] { return b->impl.run(); }) ? EDLIB_STATUS_ERROR : EDLIB_STATUS_OK;
 }
 
 EDLIB_API int edlibAmdBatchResults(EdlibAmdBatch* b, EdlibAlignResult* results) {
     if (!b || !results) { set_error("null argument"); return EDLIB_STATUS_ERROR; }
-    return b->impl.results(results) ? EDLIB_STATUS_ERROR : EDLIB_STATUS_OK;
+    return guarded("edlibAmdBatchResults", 1, [&] { return b->impl.results(results); }) ? EDLIB_STATUS_ERROR : EDLIB_STATUS_OK;
 }
 
 EDLIB_API int edlibAmdBatchResultsFlat(EdlibAmdBatch* b, int* status, int* editDistance, int* numLocations,
                                        int* alphabetLength, long long* locOffsets, int** endLocations,
                                        int** startLocations, long long* alnOffsets, unsigned char** alignment) {
     if (!b) { set_error("null argument"); return EDLIB_STATUS_ERROR; }
-    return b->impl.resultsFlat(status, editDistance, numLocations, alphabetLength, locOffsets, endLocations,
-                               startLocations, alnOffsets, alignment) ? EDLIB_STATUS_ERROR : EDLIB_STATUS_OK;
+    return guarded("edlibAmdBatchResultsFlat", 1, [&] {
+               return b->impl.resultsFlat(status, editDistance, numLocations, alphabetLength, locOffsets, endLocations,
+                                          startLocations, alnOffsets, alignment); }) ? EDLIB_STATUS_ERROR : EDLIB_STATUS_OK;
 }
 
 EDLIB_API void edlibAmdFreeResults(EdlibAlignResult* results, int n) {
@@ -146,11 +165,11 @@ EDLIB_API void edlibAmdFreeResults(EdlibAlignResult* results, int n) {
     }
 }
 
-EDLIB_API void edlibAmdTrim(void) { pool_trim(); }
+EDLIB_API void edlibAmdTrim(void) { (void)guarded("edlibAmdTrim", 0, [] { pool_trim(); return 0; }); }
 
 EDLIB_API int edlibAmdBatchStats(EdlibAmdBatch* b, EdlibAmdBatchStats* out) {
     if (!b || !out) { set_error("null argument"); return EDLIB_STATUS_ERROR; }
-    b->impl.finishStats();
+    (void)guarded("edlibAmdBatchStats", 0, [&] { b->impl.finishStats(); return 0; });
     *out = b->impl.stats;
     return EDLIB_STATUS_OK;
 }
@@ -226,9 +245,12 @@ static int run_sharded(const char* q, const long long* qoff, const char* t, cons
     std::vector<int> rc(world, EDLIB_STATUS_OK);
     std::vector<std::string> err(world);
     const int per = (n + world - 1) / world;                     // same rule as edlib_amd/parallel.py
-    auto work = [&](int r) {
-        const int lo = std::min(n, r * per), hi = std::min(n, lo + per);
-        if (hi > lo || n == 0) rc[r] = run_shard(q, qoff, t, toff, targetLength, lo, hi, config, devs[r], results, &err[r]);
+    auto work = [&](int r) {                                     // a thread body: nothing may escape it
+        rc[r] = guarded(where, (int)EDLIB_STATUS_ERROR, [&] {
+            const int lo = std::min(n, r * per), hi = std::min(n, lo + per);
+            return (hi > lo || n == 0) ? run_shard(q, qoff, t, toff, targetLength, lo, hi, config, devs[r], results, &err[r])
+                                       : (int)EDLIB_STATUS_OK;
+        });
     };
     if (world == 1) work(0);
     else {
@@ -253,22 +275,26 @@ EDLIB_API int edlibAlignBatchSharedTarget(const char* const* queries, const int*
                                           const char* target, int targetLength, EdlibAlignConfig config,
                                           EdlibAlignResult* results) {
     if (numQueries < 0 || targetLength < 0) { set_error("negative size"); return EDLIB_STATUS_ERROR; }
-    Packed q;
     for (int i = 0; i < numQueries; ++i) results[i] = blank_result(EDLIB_STATUS_ERROR);
-    if (!pack(queries, queryLengths, numQueries, q)) return EDLIB_STATUS_ERROR;
-    return run_sharded(q.data(), q.off.data(), target, nullptr, targetLength, numQueries, config, results,
-                       "edlibAlignBatchSharedTarget");
+    return guarded("edlibAlignBatchSharedTarget", (int)EDLIB_STATUS_ERROR, [&] {
+        Packed q;
+        if (!pack(queries, queryLengths, numQueries, q)) return (int)EDLIB_STATUS_ERROR;
+        return run_sharded(q.data(), q.off.data(), target, nullptr, targetLength, numQueries, config, results,
+                           "edlibAlignBatchSharedTarget");
+    });
 }
 
 EDLIB_API int edlibAlignBatchPairs(const char* const* queries, const int* queryLengths,
                                    const char* const* targets, const int* targetLengths, int numPairs,
                                    EdlibAlignConfig config, EdlibAlignResult* results) {
     if (numPairs < 0) { set_error("negative size"); return EDLIB_STATUS_ERROR; }
-    Packed q, t;
     for (int i = 0; i < numPairs; ++i) results[i] = blank_result(EDLIB_STATUS_ERROR);
-    if (!pack(queries, queryLengths, numPairs, q) || !pack(targets, targetLengths, numPairs, t)) return EDLIB_STATUS_ERROR;
-    return run_sharded(q.data(), q.off.data(), t.data(), t.off.data(), 0, numPairs, config, results,
-                       "edlibAlignBatchPairs");
+    return guarded("edlibAlignBatchPairs", (int)EDLIB_STATUS_ERROR, [&] {
+        Packed q, t;
+        if (!pack(queries, queryLengths, numPairs, q) || !pack(targets, targetLengths, numPairs, t)) return (int)EDLIB_STATUS_ERROR;
+        return run_sharded(q.data(), q.off.data(), t.data(), t.off.data(), 0, numPairs, config, results,
+                           "edlibAlignBatchPairs");
+    });
 }
 
 }  // extern "C"

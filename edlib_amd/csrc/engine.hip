@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
@@ -1781,6 +1782,7 @@ int Batch::results(EdlibAlignResult* out)
         if (results_.size() != (size_t)n_) results_.assign((size_t)n_, UnitResult{});
         if (collectReads(results_)) return 1;
     }
+    std::atomic<int> oom(0);                      // a failed malloc: the unit reports EDLIB_STATUS_ERROR, the call fails
     auto marshal = [&](int lo, int hi) {
         for (int u = lo; u < hi; ++u) {
             const UnitResult& r = results_[u];
@@ -1796,8 +1798,14 @@ int Batch::results(EdlibAlignResult* out)
                 const uint8_t* src = r.opsView;
                 const size_t len = (size_t)r.opsViewLen;
                 o.alignment = static_cast<unsigned char*>(malloc(std::max<size_t>(len, 1)));
-                if (len) memcpy(o.alignment, src, len);
+                if (len && o.alignment) memcpy(o.alignment, src, len);
                 o.alignmentLength = (int)len;
+            }
+            if ((r.hasEnds && !o.endLocations) || (r.hasStarts && !o.startLocations) || (r.hasAlignment && !o.alignment)) {
+                free(o.endLocations); free(o.startLocations); free(o.alignment);
+                o.endLocations = nullptr; o.startLocations = nullptr; o.alignment = nullptr;
+                o.numLocations = 0; o.alignmentLength = 0; o.status = EDLIB_STATUS_ERROR; o.editDistance = -1;
+                oom.store(1);
             }
         }
     };
@@ -1809,6 +1817,16 @@ int Batch::results(EdlibAlignResult* out)
         for (int t = 0; t < nthreads; ++t) th.emplace_back(marshal, (int)((long long)n_ * t / nthreads), (int)((long long)n_ * (t + 1) / nthreads));
         for (auto& x : th) x.join();
     } else marshal(0, n_);
+    if (oom.load()) {                             // all or nothing: the caller gets no half-filled array to clean up
+        for (int u = 0; u < n_; ++u) {
+            EdlibAlignResult& o = out[u];
+            free(o.endLocations); free(o.startLocations); free(o.alignment);
+            o.endLocations = nullptr; o.startLocations = nullptr; o.alignment = nullptr;
+            o.numLocations = 0; o.alignmentLength = 0; o.status = EDLIB_STATUS_ERROR; o.editDistance = -1;
+        }
+        set_error("out of host memory while marshalling results");
+        return 1;
+    }
     return 0;
 }
 
