@@ -77,7 +77,9 @@ EDLIB_API EdlibAmdBatch* edlibAmdBatchCreatePairs(
 EDLIB_API int edlibAmdBatchRun(EdlibAmdBatch* batch);
 
 /* Copy the results of the last Run to the host as EdlibAlignResult[numQueries]
- * (malloc'd arrays, caller frees each with edlibFreeAlignResult). */
+ * (malloc'd arrays, caller frees each with edlibFreeAlignResult).  On failure (EDLIB_STATUS_ERROR, e.g. host
+ * memory exhausted) every entry is blank with status EDLIB_STATUS_ERROR: nothing is left for the caller to free.
+ * No entry point of this library lets a C++ exception out. */
 EDLIB_API int edlibAmdBatchResults(EdlibAmdBatch* batch, EdlibAlignResult* results);
 
 /* The same results as flat arrays: no per-unit malloc, one array per field (what a numpy / columnar caller
