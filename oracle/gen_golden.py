@@ -182,6 +182,13 @@ def synth_cases():
                           "input": {"kind": "read", "seed": 777 + m, "tseed": 4242, "tn": 50000, "m": m,
                                     "index": i, "n": 64},
                           "mode": "HW", "task": ["distance", "locations", "path"][i % 3], "k": -1, "eq": None})
+    # reads of 257..1024 bases (the 12 / 16 / 24 / 32-word groups of the lane-per-read kernels), and 1100 (pair path)
+    for m in (257, 300, 384, 385, 512, 513, 700, 768, 769, 1024, 1100):
+        for i in range(3):
+            cases.append({"name": "c2.m%d.read%d" % (m, i),
+                          "input": {"kind": "read", "seed": 777 + m, "tseed": 4243, "tn": 40000, "m": m,
+                                    "index": i, "n": 8},
+                          "mode": "HW", "task": ["distance", "locations", "path"][i % 3], "k": -1, "eq": None})
     # config-4 shape: 10 kb ONT-like NW pairs (4/4/4 %) and a lighter 1/1/1 %
     for i in range(6):
         cases.append({"name": "c4.pair%d" % i,
