@@ -607,7 +607,6 @@ int Batch::runReads()
     // unknown mode values are computed as NW (edlib.cpp:205-215)
     const int mode = (cfg_.mode == EDLIB_MODE_HW || cfg_.mode == EDLIB_MODE_SHW) ? (int)cfg_.mode : (int)EDLIB_MODE_NW;
     const bool banded = banded_ && mode == EDLIB_MODE_HW;
-    const int kFirstMax = 8;                // first threshold of the k-doubling (edlib.cpp:197-217 starts at 64)
     const int kNoCap = 0x3fffffff;
     stats.path |= 1;
     EDLIB_AMD_HIP(hipMemsetAsync(d_wordSteps_.p, 0, sizeof(unsigned long long), stream_));
@@ -619,6 +618,10 @@ int Batch::runReads()
                                              d_eqtbl_.p, d_presence_.p, cfg_.k, g.d_peq.p, g.d_qlen.p,
                                              g.d_kinit.p, g.d_alphaExtra.p, stream_));
         // ---- pass 1: all slots; banded: threshold min(k, kFirst)
+        // first threshold of the k-doubling (edlib.cpp:197-217 starts at 64): 8 up to 512 bases; the groups of 24 / 32
+        // words take 12 / 16 -- at 1 % error a 1024-base read has distance ~10, and a read that fails the first level
+        // pays the full 32-word height over the whole target
+        const int kFirstMax = std::max(8, g.nwords / 2);
         int kFirst = kFirstMax;
         bool twoPass = banded && (cfg_.k < 0 || cfg_.k > kFirst) && 32 * g.nwords > kFirst;
         if (twoPass && g.nslots >= 16384) {
