@@ -75,7 +75,8 @@ def make_workload(cfg_id, units, rank, world, strong):
     from edlib_amd import synth
     from edlib_amd.parallel import shard_range
     w = {"config": cfg_id}
-    workers = max(1, min(os.cpu_count() or 1, 64) // max(1, world))
+    from edlib_amd.parallel import host_cpus
+    workers = max(1, min(host_cpus(), 64) // max(1, world))     # the cgroup quota, not os.cpu_count(): 8 ranks share 16 CPUs
     if cfg_id == 2:
         target = synth.random_dna(12345, TARGET_LEN)
         if strong and world > 1:
@@ -256,10 +257,106 @@ def e2e_config2(w):
         ed = np.frombuffer(res, dtype=np.uint8).reshape(n, C.sizeof(edlib_amd.AlignResult))[:, 4:8].copy().view(np.int32).ravel()
         L.edlibAmdFreeResults(res, n)
         best = dt if best is None else min(best, dt)
-    return {"value": round(n * m * len(tbytes) / best / 1e9, 1), "unit": "GCUPS", "seconds": round(best, 4),
-            "what": "edlibAlignBatchSharedTarget(): %d host query pointers + host target in, %d malloc'd EdlibAlignResult "
-                    "out; best of 2 calls" % (n, n)}, ed
+    e2e = {"value": round(n * m * len(tbytes) / best / 1e9, 1), "unit": "GCUPS", "seconds": round(best, 4),
+           "what": "edlibAlignBatchSharedTarget(): %d host query pointers + host target in, %d malloc'd EdlibAlignResult "
+                   "out; best of 2 calls" % (n, n)}
+    # the in-library sharding of the same entry point (one host thread + stream per listed device, contiguous
+    # slices, target replicated).  A 1-GPU box lists its device twice: the figure prices the host side of the fan-out
+    # (two packs / uploads / marshalling threads), not a second GPU.
+    old = os.environ.get("EDLIB_AMD_DEVICES")
+    os.environ["EDLIB_AMD_DEVICES"] = "0,0" if edlib_amd.device_count() < 2 else "all"
+    try:
+        t0 = time.perf_counter()
+        rc = L.edlibAlignBatchSharedTarget(ptrs.ctypes.data_as(C.POINTER(C.c_char_p)), qlen.ctypes.data_as(C.POINTER(C.c_int)),
+                                           n, tbytes, len(tbytes), cfg, res)
+        dts = time.perf_counter() - t0
+        if rc == 0:
+            ed2 = np.frombuffer(res, dtype=np.uint8).reshape(n, C.sizeof(edlib_amd.AlignResult))[:, 4:8].copy().view(np.int32).ravel()
+            L.edlibAmdFreeResults(res, n)
+            sharded = {"value": round(n * m * len(tbytes) / dts / 1e9, 1), "unit": "GCUPS", "seconds": round(dts, 4),
+                       "EDLIB_AMD_DEVICES": os.environ["EDLIB_AMD_DEVICES"], "devices_visible": edlib_amd.device_count(),
+                       "distances_equal_unsharded": bool(np.array_equal(ed, ed2))}
+        else:
+            sharded = {"error": edlib_amd.last_error()}
+    finally:
+        if old is None:
+            os.environ.pop("EDLIB_AMD_DEVICES", None)
+        else:
+            os.environ["EDLIB_AMD_DEVICES"] = old
+    return e2e, ed, sharded
 
+
+
+def traffic_of(cfg_id, units):
+    """HBM bytes per step from the rocprofv3 --pmc passes of tools/gpu_visit.sh (profiles/hbm_traffic.json records the
+    commit they were taken at); None when there is no entry for this batch size"""
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        ent = json.load(open(tpath)).get("configs", {}).get(str(cfg_id))
+        if ent and ent.get("units") == units:
+            return ent.get("bytes_per_step"), {"file": "profiles/hbm_traffic.json", "commit": ent.get("commit"),
+                                               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_visit.sh traffic) at "
+                                                       "that commit, not measured inside this run"}
+    except Exception:
+        pass
+    return None, None
+
+
+def report(cfg_id, w, st, scan_ms, launches, steps, warmup, dt, value, world, scaling):
+    """the JSON line of one config from the stats of its timed steps"""
+    c = CONFIGS[cfg_id]
+    main_scan_ms = scan_ms / steps               # all scan launches of a step (HIP events on the batch's stream)
+    algo_bytes = st["algo_bytes"]
+    achieved = algo_bytes / (main_scan_ms * 1e-3) / 1e9 if main_scan_ms > 0 else 0.0
+    traffic, traffic_src = traffic_of(cfg_id, w["n"])
+    lane_ops = st["word_steps"] * VALU_OPS_PER_WORD_STEP
+    valu_achieved = lane_ops / (main_scan_ms * 1e-3) if main_scan_ms > 0 else 0.0
+    return {
+        "metric": "GCUPS (cell updates/s), %s" % c["name"],
+        "value": round(value, 1), "unit": "GCUPS", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": c["dtype"], "data": "synthetic",
+        "config": {"workload": w["describe"], "baseline_config": cfg_id, "units_per_gpu": w["n"],
+                   "parallelism": "units sharded over %d rank(s), one per GPU, target replicated, no collective"
+                                  % world},
+        "roofline": {"bound": "hbm", "kernel": c["kernel"],
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_step": algo_bytes,
+                     "scan_ms_per_step": round(main_scan_ms, 3),
+                     "scan_launches_per_step": launches / steps},
+        "valu_roofline": {"bound": "valu-int32", "achieved": round(valu_achieved / 1e12, 2),
+                          "peak": round(VALU_LANE_OPS / 1e12, 2), "unit": "T lane-ops/s",
+                          "frac": round(valu_achieved / VALU_LANE_OPS, 4),
+                          "word_steps_per_step": st["word_steps"],
+                          "valu_ops_per_word_step": VALU_OPS_PER_WORD_STEP},
+        "overflow_units": st["overflow_units"],
+    }
+
+
+def measure_secondary(cfg_id, device, torch, steps=5, warmup=2):
+    """One more BASELINE config on this rank's device: resident batch, `warmup` + `steps` timed steps between two
+    device synchronisations, then the reference over the WHOLE batch (parity of every field + the CPU baseline)."""
+    w = make_workload(cfg_id, CONFIGS[cfg_id]["units"], 0, 1, False)
+    batch = make_batch(w, device)
+    try:
+        for _ in range(warmup):
+            batch.run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        scan_ms, launches, st = 0.0, 0, None
+        for _ in range(steps):
+            st = batch.run()
+            scan_ms += st["scan_ms"]; launches += st["scan_launches"]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        flat = batch.results_flat()
+        out = report(cfg_id, w, st, scan_ms, launches, steps, warmup, dt, st["cells"] * steps / dt / 1e9, 1, "weak")
+        out["cpu_baseline"], out["parity_sample"] = cpu_baseline_and_parity(w, flat, w["n"])
+    finally:
+        batch.close()
+    return out
 
 # ------------------------------------------------------------------------------------------ main
 
@@ -275,6 +372,8 @@ def main():
                     help="strong scaling (BASELINE config 3): --units is the TOTAL, split evenly over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the configs 4 / 5 lines that a default (config 2, full size, 1 GPU) run appends")
     ap.add_argument("--parity-sample", type=int, default=None,
                     help="units checked against the reference (default: 20000 for config 2, the whole batch for 4 / 5)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo with --share-gpu)")
@@ -293,6 +392,9 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s): refusing to report a wrong n_gpus"
                          % (args.gpus, world))
     import torch
+    from edlib_amd.parallel import host_cpus
+    # the library's host fan-outs (marshalling, packing) share the container's CPU quota with the other ranks
+    os.environ.setdefault("EDLIB_AMD_HOST_THREADS", str(max(1, min(6, host_cpus() // max(1, world)))))
     import edlib_amd
     ndev = edlib_amd.device_count()
     if ndev < 1:
@@ -359,49 +461,11 @@ def main():
     value = cells_all / dt / 1e9
     out = None
     if rank == 0:
-        steps = max(1, args.steps)
-        main_scan_ms = scan_ms / steps               # all scan launches of a step (HIP events on the batch's stream)
-        algo_bytes = st["algo_bytes"]
-        achieved = algo_bytes / (main_scan_ms * 1e-3) / 1e9 if main_scan_ms > 0 else 0.0
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                ent = tj.get("configs", {}).get(str(args.config))
-                if ent and ent.get("units") == w["n"]:
-                    traffic = ent.get("bytes_per_step")
-                    traffic_src = {"file": "profiles/hbm_traffic.json", "commit": ent.get("commit"),
-                                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_traffic.sh) at that "
-                                           "commit, not measured inside this run"}
-            except Exception:
-                traffic = None
-        lane_ops = st["word_steps"] * VALU_OPS_PER_WORD_STEP
-        valu_achieved = lane_ops / (main_scan_ms * 1e-3) if main_scan_ms > 0 else 0.0
-        out = {
-            "metric": "GCUPS (cell updates/s), %s" % c["name"],
-            "value": round(value, 1), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
-            "dtype": c["dtype"], "data": "synthetic",
-            "config": {"workload": w["describe"], "baseline_config": args.config, "units_per_gpu": w["n"],
-                       "parallelism": "units sharded over %d rank(s), one per GPU, target replicated, no collective"
-                                      % world},
-            "per_rank_ms_per_step": per_rank_ms,
-            "devices": devices, "devices_distinct": len(set(devices)),
-            "roofline": {"bound": "hbm", "kernel": c["kernel"],
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_step": algo_bytes,
-                         "scan_ms_per_step": round(main_scan_ms, 3),
-                         "scan_launches_per_step": launches / steps},
-            "valu_roofline": {"bound": "valu-int32", "achieved": round(valu_achieved / 1e12, 2),
-                              "peak": round(VALU_LANE_OPS / 1e12, 2), "unit": "T lane-ops/s",
-                              "frac": round(valu_achieved / VALU_LANE_OPS, 4),
-                              "word_steps_per_step": st["word_steps"],
-                              "valu_ops_per_word_step": VALU_OPS_PER_WORD_STEP},
-            "overflow_units": st["overflow_units"],
-        }
+        out = report(args.config, w, st, scan_ms, launches, max(1, args.steps), args.warmup, dt, value, world,
+                     "strong" if args.strong else "weak")
+        out["per_rank_ms_per_step"] = per_rank_ms
+        out["devices"] = devices
+        out["devices_distinct"] = len(set(devices))
         if args.share_gpu:
             out["dry_run_shared_gpu"] = True
         if world == 1 and not args.no_cpu_baseline:
@@ -417,9 +481,21 @@ def main():
                 out["e2e"] = r[0]
                 if flat is not None:
                     out["e2e"]["distances_equal_resident"] = bool(np.array_equal(r[1], flat["editDistance"]))
+                if len(r) > 2:
+                    out["e2e_sharded"] = r[2]
             else:
                 out["e2e"] = r
     batch.close()
+    del batch, w, flat
+    # BASELINE configs 4 and 5 at their full sizes, AFTER the headline's timed region and on the same device: every
+    # default run carries a driver-visible line for them (value, rooflines, reference baseline, whole-batch parity)
+    if rank == 0 and world == 1 and args.config == 2 and args.units is None and not args.no_secondary and not args.no_cpu_baseline:
+        out["secondary"] = {}
+        for cid in (4, 5):
+            try:
+                out["secondary"]["config%d" % cid] = measure_secondary(cid, device, torch)
+            except Exception as e:                                    # the headline line must survive
+                out["secondary"]["config%d" % cid] = {"error": "%s: %s" % (type(e).__name__, e)}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -196,13 +197,21 @@ static bool pack(const char* const* seqs, const int* lens, int n, Packed& out) {
     if (bytes >= (1u << 20) && device_count() > 0 && out.pin.alloc(bytes) == hipSuccess) dst = reinterpret_cast<char*>(out.pin.p);
     else { (void)hipGetLastError(); out.pin.release(); out.small.resize(bytes); dst = out.small.data(); }
     auto copy = [&](int lo, int hi) { for (int i = lo; i < hi; ++i) if (lens[i] > 0) memcpy(dst + out.off[i], seqs[i], (size_t)lens[i]); };
-    const int nthreads = bytes >= (32u << 20) ? 6 : 1;
-    if (nthreads == 1) copy(0, n);
-    else {
+    const int nthreads = bytes >= (32u << 20) ? host_threads(6) : 1;
+    int done = 0;
+    if (nthreads > 1) {
         std::vector<std::thread> th;
-        for (int t = 0; t < nthreads; ++t) th.emplace_back(copy, (int)((long long)n * t / nthreads), (int)((long long)n * (t + 1) / nthreads));
-        for (auto& x : th) x.join();
+        th.reserve(nthreads);
+        ThreadJoiner join(th);
+        try {
+            for (int t = 0; t < nthreads; ++t) {
+                const int hi = (int)((long long)n * (t + 1) / nthreads);
+                th.emplace_back(copy, done, hi);
+                done = hi;
+            }
+        } catch (const std::system_error&) {}          // thread limit: this thread copies the rest
     }
+    if (done < n) copy(done, n);
     return true;
 }
 
@@ -255,8 +264,14 @@ static int run_sharded(const char* q, const long long* qoff, const char* t, cons
     if (world == 1) work(0);
     else {
         std::vector<std::thread> th;
-        for (int r = 0; r < world; ++r) th.emplace_back(work, r);
-        for (auto& x : th) x.join();
+        th.reserve(world);
+        int started = 0;
+        {
+            ThreadJoiner join(th);
+            try { for (; started < world; ++started) th.emplace_back(work, started); }
+            catch (const std::system_error&) {}        // thread limit: the shards without a thread run here, one by one
+            for (int r = started; r < world; ++r) work(r);
+        }
     }
     for (int r = 0; r < world; ++r) {
         if (rc[r] == EDLIB_STATUS_OK) continue;

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace edlib_amd {
@@ -64,8 +65,8 @@ struct DevBuf {
         owned = true;
         return pool_alloc(reinterpret_cast<void**>(&p), count * sizeof(T), &granted);
     }
-    // grow-only
-    hipError_t ensure(size_t count) { return (count <= n && p) ? hipSuccess : alloc(count); }
+    // grow-only; a view (alias()) is never "enough": its block belongs to somebody else and may be gone
+    hipError_t ensure(size_t count) { return (count <= n && p && owned) ? hipSuccess : alloc(count); }
     size_t bytes() const { return n * sizeof(T); }
 };
 
@@ -102,13 +103,24 @@ struct DeviceGuard {
 };
 
 // events are cached like streams (a batch of one pays for every hipEventCreate / hipEventDestroy it makes)
-hipError_t pool_event(hipEvent_t* e);
-void pool_event_release(hipEvent_t e);
+// An event belongs to the device that was current when it was created: the cache is keyed on that device, not on
+// whatever device is current when the event is handed back (a Batch's members die after its DeviceGuard).
+hipError_t pool_event(hipEvent_t* e, int* device);
+void pool_event_release(hipEvent_t e, int device);
 
 struct Event {
     hipEvent_t e = nullptr;
-    ~Event() { if (e) pool_event_release(e); }
-    hipError_t create() { return e ? hipSuccess : pool_event(&e); }
+    int device = -1;
+    ~Event() { if (e) pool_event_release(e, device); }
+    hipError_t create() { return e ? hipSuccess : pool_event(&e, &device); }
+};
+
+// Joins the threads of a fan-out on every exit path: a std::thread that is still joinable when its vector unwinds
+// (thread creation failed part-way: EAGAIN) would be std::terminate before guarded() sees the exception.
+struct ThreadJoiner {
+    std::vector<std::thread>& th;
+    explicit ThreadJoiner(std::vector<std::thread>& t) : th(t) {}
+    ~ThreadJoiner() { for (auto& x : th) if (x.joinable()) x.join(); }
 };
 
 }  // namespace edlib_amd

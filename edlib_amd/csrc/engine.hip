@@ -23,6 +23,7 @@
 #include <cstdarg>
 #include <cstring>
 #include <mutex>
+#include <system_error>
 #include <thread>
 
 namespace edlib_amd {
@@ -167,9 +168,10 @@ void pool_stream_release(hipStream_t s) {
     (void)hipStreamDestroy(s);
 }
 
-hipError_t pool_event(hipEvent_t* e) {
+hipError_t pool_event(hipEvent_t* e, int* device) {
     int dev = 0;
     (void)hipGetDevice(&dev);
+    *device = dev;
     if (dev < Pool::kMaxDev && pool_enabled()) {
         std::lock_guard<std::mutex> g(pool().mu);
         auto& v = pool().events[dev];
@@ -178,14 +180,33 @@ hipError_t pool_event(hipEvent_t* e) {
     return hipEventCreate(e);
 }
 
-void pool_event_release(hipEvent_t e) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < Pool::kMaxDev && pool_enabled()) {
+void pool_event_release(hipEvent_t e, int dev) {
+    if (dev >= 0 && dev < Pool::kMaxDev && pool_enabled()) {
         std::lock_guard<std::mutex> g(pool().mu);
         if (pool().events[dev].size() < 64) { pool().events[dev].push_back(e); return; }
     }
     (void)hipEventDestroy(e);
+}
+
+// Helper threads of a host fan-out (marshalling, packing): EDLIB_AMD_HOST_THREADS if set, else at most `cap` and at
+// most the CPUs this process may really use (cgroup quota / affinity: the GPU boxes show 256 logical CPUs behind a
+// 16-CPU quota, and 8 ranks share it).
+int host_threads(int cap) {
+    static const int avail = [] {
+        if (const char* env = getenv("EDLIB_AMD_HOST_THREADS")) { const int v = atoi(env); if (v >= 1) return v; }
+        int n = (int)std::thread::hardware_concurrency();
+        if (n < 1) n = 1;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char a[64] = {0}; long long per = 0;
+            if (fscanf(f, "%63s %lld", a, &per) == 2 && strcmp(a, "max") != 0 && per > 0) {
+                const long long q = (atoll(a) + per / 2) / per;
+                if (q >= 1 && q < n) n = (int)q;
+            }
+            fclose(f);
+        }
+        return n;
+    }();
+    return std::max(1, std::min(cap, avail));
 }
 
 int device_count() {
@@ -306,7 +327,7 @@ Batch::~Batch() {
     DeviceGuard guard(device_);
     if (side_) { (void)hipStreamSynchronize(side_); pool_stream_release(side_); }
     if (stream_) { (void)hipStreamSynchronize(stream_); pool_stream_release(stream_); }
-    for (auto& p : scanEvents_) { pool_event_release(p.first); pool_event_release(p.second); }
+    for (auto& p : scanEvents_) { pool_event_release(p.first, device_); pool_event_release(p.second, device_); }
 }
 
 static int roundup(int x, int q) { return (x + q - 1) / q * q; }
@@ -496,8 +517,8 @@ hipError_t Batch::uploadEq8() {
 
 void Batch::scanTimerStart() {
     if (scanEventsUsed_ == scanEvents_.size()) {
-        hipEvent_t a = nullptr, b = nullptr;
-        (void)pool_event(&a); (void)pool_event(&b);
+        hipEvent_t a = nullptr, b = nullptr; int dev = 0;       // run() holds the DeviceGuard: dev == device_
+        (void)pool_event(&a, &dev); (void)pool_event(&b, &dev);
         scanEvents_.push_back({a, b});
     }
     (void)hipEventRecord(scanEvents_[scanEventsUsed_].first, stream_);
@@ -1757,6 +1778,12 @@ int Batch::run()
 void Batch::finishStats()
 {
     if (!algoDirty_) return;
+    if (haveResults_ && !readsCollected_) {        // a DISTANCE batch that mixes reads-path and pair units: the read units' records are still on the device
+        DeviceGuard guard(device_);
+        if (guard.status != hipSuccess) return;
+        if (results_.size() != (size_t)n_) results_.resize((size_t)n_);
+        if (collectReads(results_)) return;
+    }
     algoDirty_ = false;
     const std::vector<UnitResult>& res = results_;
     stats.algo_bytes = 0;
@@ -1778,6 +1805,12 @@ static int* malloc_ints(const LocList& v) {
 
 int Batch::results(EdlibAlignResult* out)
 {
+    // the failure contract of edlib_amd.h: on ANY failure every entry is blank with status ERROR (nothing to free)
+    for (int u = 0; u < n_; ++u) {
+        EdlibAlignResult& o = out[u];
+        o.status = EDLIB_STATUS_ERROR; o.editDistance = -1; o.endLocations = nullptr; o.startLocations = nullptr;
+        o.numLocations = 0; o.alignment = nullptr; o.alignmentLength = 0; o.alphabetLength = 0;
+    }
     if (!haveResults_) { set_error("results() before a successful run()"); return 1; }
     if (!readsCollected_) {
         DeviceGuard guard(device_);
@@ -1815,10 +1848,21 @@ int Batch::results(EdlibAlignResult* out)
     // one malloc per array is the reference's ownership contract (edlib.h:177-205); a million of them are worth a
     // few threads (glibc arenas are per thread; free() of a block from any thread is fine)
     if (n_ >= 65536) {
-        const int nthreads = 6;
+        const int nthreads = host_threads(6);
         std::vector<std::thread> th;
-        for (int t = 0; t < nthreads; ++t) th.emplace_back(marshal, (int)((long long)n_ * t / nthreads), (int)((long long)n_ * (t + 1) / nthreads));
-        for (auto& x : th) x.join();
+        th.reserve(nthreads);
+        int done = 0;                                 // units [0, done) are covered by a started thread
+        {
+            ThreadJoiner join(th);
+            try {
+                for (int t = 0; t < nthreads; ++t) {
+                    const int hi = (int)((long long)n_ * (t + 1) / nthreads);
+                    th.emplace_back(marshal, done, hi);
+                    done = hi;
+                }
+            } catch (const std::system_error&) {}     // thread limit: this thread does the rest
+        }
+        if (done < n_) marshal(done, n_);
     } else marshal(0, n_);
     if (oom.load()) {                             // all or nothing: the caller gets no half-filled array to clean up
         for (int u = 0; u < n_; ++u) {
@@ -1838,9 +1882,13 @@ int Batch::resultsFlat(int* status, int* editDistance, int* numLocations, int* a
                        long long* locOffsets, int** endLocations, int** startLocations,
                        long long* alnOffsets, unsigned char** alignment)
 {
+    if (endLocations) *endLocations = nullptr;
+    if (startLocations) *startLocations = nullptr;
+    if (alignment) *alignment = nullptr;
     if (!haveResults_) { set_error("results() before a successful run()"); return 1; }
     if (!readsCollected_) {
         DeviceGuard guard(device_);
+        EDLIB_AMD_HIP(guard.status);
         if (results_.size() != (size_t)n_) results_.assign((size_t)n_, UnitResult{});
         if (collectReads(results_)) return 1;
     }
@@ -1863,7 +1911,9 @@ int Batch::resultsFlat(int* status, int* editDistance, int* numLocations, int* a
     for (int u = 0; u < n_ && !anyStarts; ++u) anyStarts = results_[u].hasStarts;
     int* starts = (startLocations && anyStarts) ? static_cast<int*>(malloc(sizeof(int) * (size_t)std::max<long long>(nloc, 1))) : nullptr;
     unsigned char* aln = alignment ? static_cast<unsigned char*>(malloc((size_t)std::max<long long>(naln, 1))) : nullptr;
-    if ((endLocations && !ends) || (alignment && !aln)) { free(ends); free(starts); free(aln); set_error("out of memory"); return 1; }
+    if ((endLocations && !ends) || (startLocations && anyStarts && !starts) || (alignment && !aln)) {
+        free(ends); free(starts); free(aln); set_error("out of memory"); return 1;
+    }
     long long li = 0, ai = 0;
     for (int u = 0; u < n_; ++u) {
         const UnitResult& r = results_[u];

@@ -228,6 +228,7 @@ private:
 int align_one(const char* q, int qn, const char* t, int tn, EdlibAlignConfig cfg, EdlibAlignResult* out);
 
 int device_count();
+int host_threads(int cap);
 int default_device();
 
 }  // namespace edlib_amd

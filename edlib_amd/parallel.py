@@ -6,7 +6,32 @@ SUM of the work, and (optionally) a gather of per-unit results to rank 0.  The
 backend is whatever torch.distributed was initialised with: "nccl" (= RCCL over xGMI)
 on the GPU box, "gloo" in the CPU tests.
 """
+import os
+
 import numpy as np
+
+
+def host_cpus():
+    """CPUs this process may really use: the cgroup CPU quota (cpu.max, or cfs_quota_us on cgroup v1) capped by the
+    affinity mask.  The GPU boxes show 256 logical CPUs behind a 16-CPU quota; worker pools sized from
+    os.cpu_count() there only measure the throttle, and 8 ranks doing so start 64 threads each on 16 CPUs."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if a != "max":
+            quota = float(a) / float(b)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
 
 
 def shard_range(n_units, rank, world):

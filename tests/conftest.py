@@ -33,6 +33,13 @@ def ref():
 
 
 @pytest.fixture(scope="session")
+def checker(ref, oracle):
+    """What the differential GPU tests compare with: the compiled, unmodified reference where it travelled
+    (oracle/_ref/libedlib_ref.so rides along to the GPU box), the C99 restatement otherwise."""
+    return ref if ref is not None else oracle
+
+
+@pytest.fixture(scope="session")
 def engine():
     """The product library; on the GPU box it must load and see a device (no fallback)."""
     import edlib_amd

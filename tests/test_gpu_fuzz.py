@@ -1,4 +1,5 @@
-"""-m gpu: seeded differential fuzz of the batch entry points against the oracle, aimed at the band
+"""-m gpu: seeded differential fuzz of the batch entry points against the compiled reference (`checker`: oracle/_ref when it
+travelled, else the C99 restatement), aimed at the band
 logic of the reads kernel (word-count groups, thresholds around the first k of the doubling, low
 complexity targets where the band stays tall, fixed k) and at the pair kernels (strips, banded NW)."""
 import os
@@ -28,7 +29,8 @@ def _mut(rng, s, rate, sigma_bytes):
     return bytes(out) or bytes([sigma_bytes[0]])
 
 
-def test_fuzz_shared_target_batches(engine, oracle):
+def test_fuzz_shared_target_batches(engine, checker):
+    oracle = checker
     rng = random.Random(int(os.environ.get("EDLIB_FUZZ_SEED", "2024")))
     nbad = 0
     for it in range(int(os.environ.get("EDLIB_FUZZ_ITERS", "70"))):   # soak runs: EDLIB_FUZZ_ITERS=500 EDLIB_FUZZ_SEED=n
@@ -69,7 +71,8 @@ def test_fuzz_shared_target_batches(engine, oracle):
     assert nbad == 0
 
 
-def test_fuzz_pair_batches_long(engine, oracle):
+def test_fuzz_pair_batches_long(engine, checker):
+    oracle = checker
     """Pairs around the strip (64 blocks = 4096 rows) and band limits of the pair kernels."""
     rng = random.Random(77)
     for it in range(6):
