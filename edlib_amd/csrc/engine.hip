@@ -330,7 +330,7 @@ Batch::~Batch() {
     for (auto& p : scanEvents_) { pool_event_release(p.first, device_); pool_event_release(p.second, device_); }
 }
 
-static int roundup(int x, int q) { return (x + q - 1) / q * q; }
+int roundup(int x, int q) { return (x + q - 1) / q * q; }
 
 // EDLIB_AMD_DEBUG: host wall time between named points of a run (stderr)
 struct Lap {
@@ -428,13 +428,18 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
     }
     // reads of 257..1024 bases (..512 above four target symbols): banded / full-height HW kernels only (EDLIB_AMD_LONGREADS=0: pair path)
     static const bool longReads = !(getenv("EDLIB_AMD_LONGREADS") && getenv("EDLIB_AMD_LONGREADS")[0] == '0');
-    const int maxReadLen = 32 * ((banded_ && modeIn == EDLIB_MODE_HW && syms_ <= 8 && longReads)
+    // HW queries longer than kernel A's 256 rows against the shared target: piece filter + window verification
+    // (long_reads.hip); EDLIB_AMD_FILTER=0 restores the groups of 12 / 16 / 24 / 32 words (up to 1024 bases) and kernel W
+    static const bool filterOn = !(getenv("EDLIB_AMD_FILTER") && getenv("EDLIB_AMD_FILTER")[0] == '0');
+    const bool filter = filterOn && readsOk && banded_ && modeIn == EDLIB_MODE_HW;
+    const int maxReadLen = 32 * ((banded_ && modeIn == EDLIB_MODE_HW && syms_ <= 8 && longReads && !filter)
                                      ? (syms_ == 4 ? kMaxLongReadWords4 : kMaxLongReadWords) : kMaxReadWords);
     std::vector<std::vector<int>> byWords(kMaxLongReadWords4 + 1);
     for (int u = 0; u < n; ++u) {
         const int m = qlen(u), T = tlen(u);
         if (m == 0 || T == 0) emptyUnits_.push_back(u);
         else if (readsOk && m <= maxReadLen) { readUnits_.push_back(u); byWords[read_group_words(m)].push_back(u); }
+        else if (filter) longUnits_.push_back(u);
         else pairUnits_.push_back(u);
     }
     stats.cells = 0;
@@ -442,6 +447,7 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
     {   // units whose alphabetLength the reads path does not produce
         alphaUnits_ = emptyUnits_;
         alphaUnits_.insert(alphaUnits_.end(), pairUnits_.begin(), pairUnits_.end());
+        alphaUnits_.insert(alphaUnits_.end(), longUnits_.begin(), longUnits_.end());
         long long total = 0;
         for (int u : alphaUnits_) total += qlen(u) + (shared_ ? 0 : tlen(u));
         alphaOnHost_ = h_in_.p && d_qpool_.p && !d_qpool_.owned && total <= 65536;
@@ -495,7 +501,7 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
         }
         groups_.push_back(std::move(g));
     }
-    if (!groups_.empty()) {
+    if (!groups_.empty() || !longUnits_.empty()) {
         EDLIB_AMD_HIP(d_tpk_.alloc((size_t)(T + 15) / 16 + 4));
         // the banded kernel reads whole dwords; on OUR stream: the null stream does not order with it
         EDLIB_AMD_HIP(hipMemsetAsync(d_tpk_.p, 0, d_tpk_.bytes(), stream_));
@@ -538,7 +544,7 @@ void Batch::scanTimerStop() {
 //  * the empty target prefix (position -1, score m) takes part exactly when the
 //    reference's padded last block would see it, i.e. when W = 64*ceil(m/64)-m > 0
 //    (edlib.cpp:661,670,681-693; oracle-verified: m=64 all-mismatch has no -1).
-static void finalize_semiglobal(UnitResult& r, int kcfg, int m, int best, const int* pos, long long npos) {
+void finalize_semiglobal(UnitResult& r, int kcfg, int m, int best, const int* pos, long long npos) {
     const int W = ((m + 63) / 64) * 64 - m;
     const bool kAllowsM = (kcfg < 0 || kcfg >= m);
     r.ends.clear();
@@ -576,6 +582,7 @@ int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, i
     a.segBest = segBest; a.segCnt = segCnt; a.segPos = segPos; a.cap = cap;
     a.posOff = posOff; a.posCap = posCap;
     a.kcap = kcap; a.wordSteps = wordSteps ? wordSteps : d_wordSteps_.p;
+    a.filter = filterScan_ ? 1 : 0;
     static const bool dbg = getenv("EDLIB_AMD_DEBUG") != nullptr;
     if (dbg) {
         EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
@@ -608,7 +615,7 @@ int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, i
 }
 
 // segmentation of a launch over `nlanes` lanes: enough waves to fill the chip, segments >= 4096 columns
-static void plan_segments(int nlanes, int T, int mode, int warmFull, long long wantWaves,
+void plan_segments(int nlanes, int T, int mode, int warmFull, long long wantWaves,
                           int& S, int& segLen, int& warm)
 {
     S = 1; segLen = roundup(T, 16); warm = 0;
@@ -630,9 +637,6 @@ int Batch::runReads()
     const bool banded = banded_ && mode == EDLIB_MODE_HW;
     const int kNoCap = 0x3fffffff;
     stats.path |= 1;
-    EDLIB_AMD_HIP(hipMemsetAsync(d_wordSteps_.p, 0, sizeof(unsigned long long), stream_));
-    if (syms_ == 4) EDLIB_AMD_HIP(launch_pack_target_2bit(d_tpool_.p, d_tlut_.p, T, d_tpk_.p, stream_));
-    if (banded) EDLIB_AMD_HIP(launch_pack_target_rows(d_tpool_.p, d_tlut_.p, T, d_trows_.p, (int)d_trows_.n, stream_));
     for (auto& gp : groups_) {
         ReadGroup& g = *gp;
         EDLIB_AMD_HIP(launch_build_peq_reads(g.nwords, syms_, d_qpool_.p, d_qoff_.p, g.d_perm.p, g.nslots,
@@ -827,11 +831,17 @@ int Batch::runReads()
         EDLIB_AMD_HIP(hipStreamSynchronize(stream_));                    // temporaries die here
         stats.overflow_units += (int)no;
     }
-    if (banded) {            // read back with the run's final synchronisation (Batch::run)
-        EDLIB_AMD_HIP(h_wordSteps_.alloc(sizeof(unsigned long long)));
-        EDLIB_AMD_HIP(hipMemcpyAsync(h_wordSteps_.p, d_wordSteps_.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
-        wordStepsPending_ = true;
-    }
+    return 0;
+}
+
+// the shared target in the forms the reads-per-lane kernels read (once per run; the work counter of the banded kernel)
+int Batch::packTarget()
+{
+    if (groups_.empty() && longUnits_.empty()) return 0;
+    const int T = tlen(0);
+    EDLIB_AMD_HIP(hipMemsetAsync(d_wordSteps_.p, 0, sizeof(unsigned long long), stream_));
+    if (syms_ == 4) EDLIB_AMD_HIP(launch_pack_target_2bit(d_tpool_.p, d_tlut_.p, T, d_tpk_.p, stream_));
+    if (banded_) EDLIB_AMD_HIP(launch_pack_target_rows(d_tpool_.p, d_tlut_.p, T, d_trows_.p, (int)d_trows_.n, stream_));
     return 0;
 }
 
@@ -1185,7 +1195,7 @@ static bool needs_hirschberg(int m, int T) {
 // One level of the divide step for a set of pieces: forward scan of (query, left half) and reverse
 // scan of (reversed query, reversed right half), both NW and dumped at their last column
 // (edlib.cpp:1246-1260), then the split search on the device (edlib.cpp:1314-1353).
-int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& splitRow,
+int Batch::hirschbergLevel(const std::vector<PathPiece>& big, std::vector<int>& splitRow,
                            std::vector<int>& leftScore, std::vector<int>& rightScore)
 {
     const size_t np = big.size();
@@ -1195,7 +1205,7 @@ int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& spli
     static const int rings[kNumRings + 1] = {4, 8, 16, 21, 32, 64, 0};
     // (packing only pays with enough pieces to fill the chip: a handful of long pieces runs faster one per wave)
     const bool packed = np >= 256;
-    auto ring_of = [&](const Piece& pc) {
+    auto ring_of = [&](const PathPiece& pc) {
         const bool off = getenv("EDLIB_AMD_NWBAND") && getenv("EDLIB_AMD_NWBAND")[0] == '0';
         if (off) return kNumRings;
         if (!packed) return (pc.m > 64 * 64 && pc.score <= kMaxBandK) ? kNumRings - 1 : kNumRings;
@@ -1211,7 +1221,7 @@ int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& spli
     std::vector<int> best(np);
     long long peqWords = 0, auxInts = 0, colBlocks = 0;
     for (size_t q = 0; q < np; ++q) {
-        const Piece& pc = big[order[q]];
+        const PathPiece& pc = big[order[q]];
         const int ring = rings[groupOf[order[q]]];
         const bool banded = ring != 0;
         const int lw = pc.T / 2, rw = pc.T - lw;                         // :1247-1248
@@ -1252,7 +1262,7 @@ int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& spli
     a.posPool = d_posPool_.p;
     {
         long long nbMax = 0;
-        for (const Piece& pc : big) nbMax = std::max<long long>(nbMax, (pc.m + 63) / 64);
+        for (const PathPiece& pc : big) nbMax = std::max<long long>(nbMax, (pc.m + 63) / 64);
         a.peqRowStride = peq_row_stride(nbMax);
         a.peqFullStride = (int)std::min<long long>((long long)a.peqRowStride * tab_.sigmaT, 1 << 20);
     }
@@ -1286,24 +1296,24 @@ int Batch::hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& spli
 // Alignment paths of NW jobs of any size (reference obtainAlignment, edlib.cpp:1161-1213): pieces at
 // or above the 1 MiB column-store estimate are halved Hirschberg-style, level by level across the
 // whole batch, until every piece fits the traceback branch; the pieces' op strings concatenate.
-int Batch::solvePaths(const std::vector<Piece>& jobs, std::vector<OpsOut>& opsOut, std::vector<int>& status)
+int Batch::solvePaths(const std::vector<PathPiece>& jobs, std::vector<OpsOut>& opsOut, std::vector<int>& status)
 {
     const size_t nj = jobs.size();
     Lap lap;
     opsOut.clear(); opsOut.resize(nj); status.assign(nj, EDLIB_STATUS_OK);
     // only jobs at or above the 1 MiB rule are ever split: the others stay a single implicit piece
-    std::vector<std::vector<Piece>> pieces(nj);
+    std::vector<std::vector<PathPiece>> pieces(nj);
     std::vector<size_t> bigJobs;
     for (size_t j = 0; j < nj; ++j)
         if (needs_hirschberg(jobs[j].m, jobs[j].T)) { pieces[j].push_back(jobs[j]); bigJobs.push_back(j); }
     auto npieces = [&](size_t j) { return pieces[j].empty() ? (size_t)1 : pieces[j].size(); };
-    auto piece = [&](size_t j, size_t i) -> const Piece& { return pieces[j].empty() ? jobs[j] : pieces[j][i]; };
+    auto piece = [&](size_t j, size_t i) -> const PathPiece& { return pieces[j].empty() ? jobs[j] : pieces[j][i]; };
     for (int level = 0; level < 64 && !bigJobs.empty(); ++level) {
-        std::vector<Piece> big; std::vector<std::pair<size_t, size_t>> where;
+        std::vector<PathPiece> big; std::vector<std::pair<size_t, size_t>> where;
         for (size_t j : bigJobs) {
             if (status[j] != EDLIB_STATUS_OK) continue;
             for (size_t i = 0; i < pieces[j].size(); ++i) {
-                const Piece& pc = pieces[j][i];
+                const PathPiece& pc = pieces[j][i];
                 if (pc.m > 0 && pc.T > 0 && needs_hirschberg(pc.m, pc.T)) {
                     if (pc.T < 2) { status[j] = EDLIB_STATUS_ERROR; break; }   // the reference has no answer here either
                     big.push_back(pc); where.push_back({j, i});
@@ -1318,10 +1328,10 @@ int Batch::solvePaths(const std::vector<Piece>& jobs, std::vector<OpsOut>& opsOu
             const size_t j = where[b].first, i = where[b].second;
             if (status[j] != EDLIB_STATUS_OK) continue;
             if (row[b] == -2) { status[j] = EDLIB_STATUS_ERROR; continue; }          // edlib.cpp:1358-1362
-            const Piece pc = pieces[j][i];
+            const PathPiece pc = pieces[j][i];
             const int lw = pc.T / 2, ulH = row[b] + 1;                                // :1367-1370
-            const Piece ul{pc.qoff, ulH, pc.toff, lw, ls[b]};
-            const Piece lr{pc.qoff + ulH, pc.m - ulH, pc.toff + lw, pc.T - lw, rs[b]};
+            const PathPiece ul{pc.qoff, ulH, pc.toff, lw, ls[b]};
+            const PathPiece lr{pc.qoff + ulH, pc.m - ulH, pc.toff + lw, pc.T - lw, rs[b]};
             pieces[j][i] = ul;
             pieces[j].insert(pieces[j].begin() + i + 1, lr);
         }
@@ -1332,7 +1342,7 @@ int Batch::solvePaths(const std::vector<Piece>& jobs, std::vector<OpsOut>& opsOu
     for (size_t j = 0; j < nj; ++j) {
         if (status[j] != EDLIB_STATUS_OK) continue;
         for (size_t i = 0; i < npieces(j); ++i) {
-            const Piece& pc = piece(j, i);
+            const PathPiece& pc = piece(j, i);
             // kinit = the piece's distance: the storing scan runs inside exactly that band (the reference's
             // second call with k = bestScore, edlib.cpp:1196-1199)
             if (pc.m > 0 && pc.T > 0) units.push_back(UnitSpec{pc.qoff, pc.m, 1, pc.toff, pc.T, 1, pc.score});
@@ -1389,7 +1399,7 @@ int Batch::solvePaths(const std::vector<Piece>& jobs, std::vector<OpsOut>& opsOu
             continue;
         }
         for (size_t i = 0; i < npieces(j); ++i) {
-            const Piece& pc = piece(j, i);
+            const PathPiece& pc = piece(j, i);
             if (pc.m == 0) o.own.insert(o.own.end(), (size_t)pc.T, (uint8_t)EDLIB_EDOP_DELETE);
             else if (pc.T == 0) o.own.insert(o.own.end(), (size_t)pc.m, (uint8_t)EDLIB_EDOP_INSERT);
             else { o.own.insert(o.own.end(), leafPtr[u], leafPtr[u] + leafLen[u]); ++u; }
@@ -1608,7 +1618,7 @@ int Batch::run()
     opsOwned_.clear();
     // TASK_DISTANCE over reads-path units only: nothing is assembled on the host until results() asks for it, so
     // the per-unit records (160 bytes each) are not even allocated in the timed run
-    const bool lazy = cfg_.task == EDLIB_TASK_DISTANCE && pairUnits_.empty() && emptyUnits_.empty() && !groups_.empty();
+    const bool lazy = cfg_.task == EDLIB_TASK_DISTANCE && pairUnits_.empty() && longUnits_.empty() && emptyUnits_.empty() && !groups_.empty();
     // the records of the run before last are recycled (no 160-byte-per-unit allocation + page faults per run)
     std::vector<UnitResult>& res = work_;
     if (lazy) res.clear();
@@ -1638,12 +1648,28 @@ int Batch::run()
     }
     if (alphabetLengthsBegin()) return 1;
     // ---- phase 1: distance + end locations
+    if (packTarget()) return 1;
     if (runReads()) return 1;
     readsCollected_ = groups_.empty();
     // TASK_DISTANCE leaves the reads-path results in HBM until results(); LOC/PATH need them now
     lap("run: reads scans");
     if (!readsCollected_ && cfg_.task != EDLIB_TASK_DISTANCE && collectReads(res)) return 1;
     lap("run: collect reads");
+    // long HW queries against the shared target: piece filter + window verification; what it hands back (low
+    // complexity, thresholds beyond a quarter of the piece) joins the pair units below
+    pairNow_ = pairUnits_;
+    if (!longUnits_.empty()) {
+        std::vector<int> fb;
+        if (solveLongReads(res, fb)) return 1;
+        pairNow_.insert(pairNow_.end(), fb.begin(), fb.end());
+        lap("run: long reads");
+    }
+    if (banded_ && (!groups_.empty() || !longUnits_.empty())) {   // read back with the run's final synchronisation
+        EDLIB_AMD_HIP(h_wordSteps_.alloc(sizeof(unsigned long long)));
+        EDLIB_AMD_HIP(hipMemcpyAsync(h_wordSteps_.p, d_wordSteps_.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+        wordStepsPending_ = true;
+    }
+    const std::vector<int>& pairUnits_ = pairNow_;          // (shadows the member: the units of THIS run's pair phase)
     if (!pairUnits_.empty()) {
         // scratch that a run needs per unit lives in the batch: a fresh 10 MB std::vector is an mmap, its page faults
         // and a munmap (45 MB of them were 5 of the 9 ms a run over 262,144 short pairs took)
@@ -1711,7 +1737,7 @@ int Batch::run()
     lap("run: phase 2 (starts)");
     // ---- phase 3: alignment path of the first location (edlib.cpp:276-289, 1161-1213)
     if (cfg_.task == EDLIB_TASK_PATH) {
-        std::vector<Piece> jobs; std::vector<int> where;
+        std::vector<PathPiece> jobs; std::vector<int> where;
         jobs.reserve(live.size()); where.reserve(live.size());
         for (int u : live) {
             UnitResult& r = res[u];
@@ -1723,7 +1749,7 @@ int Batch::run()
                 opsOwned_.emplace_back((size_t)m, (uint8_t)EDLIB_EDOP_INSERT);
                 r.opsView = opsOwned_.back().data(); r.opsViewLen = m; r.hasAlignment = true; continue;
             }
-            jobs.push_back(Piece{qoff_[u], m, tbase(u) + s, len, r.editDistance});
+            jobs.push_back(PathPiece{qoff_[u], m, tbase(u) + s, len, r.editDistance});
             where.push_back(u);
         }
         lap("paths: jobs");
@@ -1754,7 +1780,7 @@ int Batch::run()
         stats.scan_ms += t;
     }
     // algorithmic bytes: target + query + Peq + result header + end locations
-    if (!readsCollected_ && pairUnits_.empty() && emptyUnits_.empty()) {
+    if (!readsCollected_ && pairUnits_.empty() && longUnits_.empty() && emptyUnits_.empty()) {
         // everything is still resident on the device (reads path, TASK_DISTANCE): every unit is priced with
         // sigma = |target alphabet| and one end location -- a constant of the batch, summed once
         if (algoBase_ < 0) {

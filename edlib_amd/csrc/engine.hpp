@@ -144,6 +144,8 @@ private:
 
     // ---- unit classification (phase 1)
     std::vector<int> emptyUnits_, readUnits_, pairUnits_;
+    std::vector<int> longUnits_;                 // HW queries above 256 rows against the shared target (long_reads.hip)
+    std::vector<int> pairNow_;                   // pair units of the current run: pairUnits_ + what the piece filter handed back
 
     // ---- reads-per-lane path
     struct ReadGroup {
@@ -162,7 +164,14 @@ private:
     PinBuf h_wordSteps_; bool wordStepsPending_ = false;
     bool banded_ = false;        // HW groups use the Ukkonen-banded kernel with k-doubling
     int syms_ = 4;               // Peq rows per word of the reads kernels: target symbols rounded up to 4, 8 or 16
+    int packTarget();
     int runReads();                                   // device work only; results stay in HBM
+    // ---- long HW queries: piece filter on the reads-per-lane kernel + window verification on kernel W (long_reads.hip)
+    struct Piece { long long off; int len; int thr; };           // rows [off, off + len) of the query pool, threshold of its scan
+    int scanPieces(const std::vector<Piece>& pieces, bool filter, std::vector<std::pair<int, int>>* cand,
+                   std::vector<uint8_t>* overflow, std::vector<int>* best);
+    int solveLongReads(std::vector<UnitResult>& res, std::vector<int>& fallback);
+    bool filterScan_ = false;
     int collectReads(std::vector<UnitResult>& res);   // D2H + result semantics (lazy for TASK_DISTANCE)
     bool readsCollected_ = true;
     int scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, int kcap, const int* d_kinit,
@@ -198,10 +207,10 @@ private:
     hipStream_t side_ = nullptr;
     DevBuf<int> d_alphaIdx_, d_alphaOut_; PinBuf alphaPin_;
     // linear-space paths (reference obtainAlignmentHirschberg, edlib.cpp:1231-1396)
-    struct Piece { long long qoff; int m; long long toff; int T; int score; };
-    int hirschbergLevel(const std::vector<Piece>& big, std::vector<int>& splitRow,
+    struct PathPiece { long long qoff; int m; long long toff; int T; int score; };
+    int hirschbergLevel(const std::vector<PathPiece>& big, std::vector<int>& splitRow,
                         std::vector<int>& leftScore, std::vector<int>& rightScore);
-    int solvePaths(const std::vector<Piece>& jobs, std::vector<OpsOut>& opsOut, std::vector<int>& status);
+    int solvePaths(const std::vector<PathPiece>& jobs, std::vector<OpsOut>& opsOut, std::vector<int>& status);
     std::vector<std::shared_ptr<PinBuf>> opsKeep_;      // staging blocks the last run's op views point into
     std::deque<std::vector<uint8_t>> opsOwned_;         // op strings assembled on the host (Hirschberg pieces, empty windows)
 
@@ -226,6 +235,11 @@ private:
 
 // single-pair convenience used by edlibAlign()
 int align_one(const char* q, int qn, const char* t, int tn, EdlibAlignConfig cfg, EdlibAlignResult* out);
+
+// helpers shared by engine.hip and long_reads.hip
+int roundup(int x, int q);
+void plan_segments(int nlanes, int T, int mode, int warmFull, long long wantWaves, int& S, int& segLen, int& warm);
+void finalize_semiglobal(UnitResult& r, int kcfg, int m, int best, const int* pos, long long npos);
 
 int device_count();
 int host_threads(int cap);

@@ -652,6 +652,9 @@ static_assert(band_height_down<12>(12) <= 12 - 4 && band_height_down<16>(16) <= 
 struct HwTrack {            // per-lane tracking state of the banded kernel
     int best, cnt, cap;
     int* pos;
+    // filter mode (ReadScanArgs::filter, wave-uniform): the threshold stays where it is and the lane lists the 16-column
+    // blocks that hold a column scoring <= best, each once (the piece filter of long reads, engine.hip)
+    int filter;
 };
 
 // Rows carried from quad to quad by the one-word band (the next quad's rows, already in registers); local to a run
@@ -698,7 +701,20 @@ __device__ __forceinline__ int band_quad(const u32 lo, const u32 hi, const u32 n
         }
     }
     if (NA == NWD) {
-        if (track && __builtin_amdgcn_ballot_w64(flag < 0) != 0ull) {   // wave-uniform
+        if (track && __builtin_amdgcn_ballot_w64(flag < 0) != 0ull && tr.filter) {   // wave-uniform
+            // the four columns of a quad share their 16-column block
+            const int blk = colBase >> 4;
+            bool hit = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hit = hit || (eh[j] < 0 && colBase + j < colEnd);
+            // the last listed block is re-read (rare path) rather than kept in a register of the hot loop; a list that
+            // has overflowed is discarded by the host, so duplicates past the cap do not matter
+            bool fresh = hit;
+            if (hit && tr.cnt > 0 && tr.cnt <= tr.cap) fresh = tr.pos[tr.cnt - 1] != blk;
+            if (fresh && tr.cnt < tr.cap) tr.pos[tr.cnt] = blk;
+            tr.cnt += fresh ? 1 : 0;
+            flag = 0;                                                   // e stays relative to the fixed threshold
+        } else if (track && __builtin_amdgcn_ballot_w64(flag < 0) != 0ull) {   // wave-uniform
             const int bestIn = tr.best;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -823,6 +839,7 @@ scan_reads_banded_kernel(const ReadScanArgs a)
         tr.best = k0 < a.kcap ? k0 : a.kcap;
     }
     tr.cnt = 0;
+    tr.filter = a.filter;
     {
         // lanes past nlanes (the tail of the last wave) own no record: they must not even read the tables
         const long long item = (long long)idx * a.numSegments + blockIdx.y;   // (lane, segment) record
@@ -929,6 +946,7 @@ scan_reads_full_kernel(const ReadScanArgs a)
     HwTrack tr;
     tr.best = a.kinit[slot];
     tr.cnt = 0;
+    tr.filter = 0;
     {
         const long long item = (long long)idx * a.numSegments + blockIdx.y;
         tr.cap = live ? (a.posCap ? a.posCap[item] : a.cap) : 0;
@@ -1016,6 +1034,34 @@ hipError_t launch_scan_reads_banded(int nwords, int syms, const ReadScanArgs& a,
         case 16: return launch_scan_reads_banded_s<16>(nwords, a, stream);
     }
     return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------- filter candidates
+
+__global__ void __launch_bounds__(256)
+collect_candidates_kernel(const int* __restrict__ segCnt, const int* __restrict__ segPos, int S, int cap, int nlanes,
+                          int* __restrict__ out, int maxOut, int* __restrict__ counter, int* __restrict__ overflow)
+{
+    const long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;    // (lane, segment) record
+    if (item >= (long long)nlanes * S) return;
+    const int c = segCnt[item];
+    if (c <= 0) return;
+    const int lane = (int)(item / S);
+    if (c > cap) overflow[lane] = 1;
+    const int take = c < cap ? c : cap;
+    const int at = atomicAdd(counter, take);
+    for (int i = 0; i < take; ++i)
+        if (at + i < maxOut) { out[2 * (at + i)] = lane; out[2 * (at + i) + 1] = segPos[item * cap + i]; }
+}
+
+hipError_t launch_collect_candidates(const int* segCnt, const int* segPos, int numSegments, int cap, int nlanes,
+                                     int* out, int maxOut, int* counter, int* overflow, hipStream_t stream)
+{
+    const long long items = (long long)nlanes * numSegments;
+    if (items == 0) return hipSuccess;
+    hipLaunchKernelGGL(collect_candidates_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
+                       segCnt, segPos, numSegments, cap, nlanes, out, maxOut, counter, overflow);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------- the merge

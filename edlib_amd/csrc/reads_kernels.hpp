@@ -37,6 +37,8 @@ struct ReadScanArgs {
     const int* posCap;        // optional [lanes][numSegments] capacity (exact pass)
     int kcap;                 // banded HW kernel: effective threshold = min(kinit[slot], kcap)
     unsigned long long* wordSteps;   // banded HW kernel: += 32-row word-columns actually computed (may be null)
+    int filter;               // banded HW kernel: 1 = fixed threshold, segPos lists the 16-column BLOCKS that hold a column
+                              // scoring <= kinit (each once), segCnt their number (piece filter of long reads)
 };
 
 // mode: 0 NW, 1 SHW, 2 HW (values of EdlibAlignMode).  Returns hipSuccess or the launch error.
@@ -63,6 +65,12 @@ hipError_t launch_build_peq_reads(int nwords, int syms, const uint8_t* reads, co
                                   const uint32_t* targetPresence /*8 dwords*/, int kcfg,
                                   uint32_t* peq, int* qlen, int* kinit, int* alphaExtra,
                                   hipStream_t stream);
+
+// Piece filter: gathers the (lane, block) candidates of a filter scan into one list.  out[2i] = lane, out[2i+1] = block;
+// *counter = number of candidates (may exceed maxOut: the caller retries with a larger list); overflow[lane] = 1 when a
+// (lane, segment) record held more than `cap` blocks.
+hipError_t launch_collect_candidates(const int* segCnt, const int* segPos, int numSegments, int cap, int nlanes,
+                                     int* out, int maxOut, int* counter, int* overflow, hipStream_t stream);
 
 hipError_t launch_merge_segments(const int* segBest, const int* segCnt, const int* segPos,
                                  int numSegments, int cap, int nlanes, const int* slotmap, int capFinal,

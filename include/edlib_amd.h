@@ -104,7 +104,7 @@ typedef struct {
     long long cells;        /* sum over units of queryLength * targetLength (GCUPS numerator)*/
     long long word_steps;   /* 32-row word-column updates the scan kernels executed          */
     long long algo_bytes;   /* algorithmic bytes: target+query+Peq+results    */
-    int path;               /* 1 = reads-per-lane kernel, 2 = block-per-lane kernel, 3 = both*/
+    int path;               /* bit 0 reads-per-lane kernel, bit 1 block-per-lane kernel, bit 2 piece filter (long HW reads) */
     int overflow_units;     /* units whose end-location list needed the exact second pass    */
 } EdlibAmdBatchStats;
 

@@ -1,7 +1,12 @@
-"""-m gpu: HW reads of 257..1024 bases against a shared target stay on the reads-per-lane kernels (groups of 12, 16, 24
-and 32 words: the bottom row of a lane sits in any of the group's last four / eight words, band heights step 1, 2,
-3, 4, 6, 8, 12, 16, 24, 32; above four target symbols the limit is 512 bases).  Reference semantics: edlib.cpp:550-704 (the semi-global scan and its band), 197-217 (k-doubling).  Every field
-of every read is compared with the oracle (native thread pool over the reference / the restatement)."""
+"""-m gpu: HW reads longer than 256 bases against a shared target: piece filter on the reads-per-lane kernel + window
+verification on kernel W (edlib_amd/csrc/long_reads.hip; stats path bit 2), any length, targets of up to 16 symbols; what the
+filter cannot narrow (unrelated reads, low complexity) is handed back to kernel W over the whole target.
+Reference semantics: edlib.cpp:550-704 (the semi-global scan and its band), 197-217 (k-doubling).  Every field
+of every read is compared with the oracle (native thread pool over the reference / the restatement).
+EDLIB_AMD_FILTER=0 restores round 2's groups of 12 / 16 / 24 / 32 words (test_round2_word_groups_still_agree)."""
+import os
+import subprocess
+import sys
 import numpy as np
 import pytest
 
@@ -72,10 +77,7 @@ def test_mixed_lengths_257_to_512(engine, task):
     lengths = _EDGES + [int(x) for x in rng.integers(257, 513, n)]
     reads = _reads(target, lengths, 63, unrelated_every=9)
     st = _check(engine, reads, target, task)
-    if task == "distance":
-        assert st["path"] == 1, "a read of 257..512 bases left the reads-per-lane kernels"
-    else:
-        assert st["path"] & 1
+    assert st["path"] & 4, "reads of 257..512 bases did not take the piece filter"
 
 
 @pytest.mark.parametrize("k", [0, 3, 25, 70, 600])
@@ -94,16 +96,16 @@ def test_target_with_n_runs_eight_row_layout(engine):
     lengths = _EDGES + [int(x) for x in rng.integers(257, 513, 400)]
     reads = _reads(target, lengths, 69, unrelated_every=8)
     st = _check(engine, reads, target, "distance")
-    assert st["path"] == 1
+    assert st["path"] & 4
     _check(engine, reads[:200], target, "locations")
 
 
-def test_nine_symbols_keep_long_reads_on_the_pair_path(engine):
+def test_nine_symbols_sixteen_row_layout(engine):
     target = synth.masked_genome(70, 20_000)
     assert len(set(target.tolist())) > 8
-    reads = _reads(target, [300, 400, 512, 257] * 8 + [100, 150] * 8, 71)
+    reads = _reads(target, [300, 400, 512, 257, 1500] * 8 + [100, 150] * 8, 71)
     st = _check(engine, reads, target, "distance")
-    assert st["path"] == 3                       # short reads on the lane kernels, long ones on the rings
+    assert st["path"] & 1 and st["path"] & 4     # short reads on the lane kernels, long ones through the filter
 
 
 def test_neighbours_of_the_range_and_short_reads_in_one_batch(engine):
@@ -111,19 +113,18 @@ def test_neighbours_of_the_range_and_short_reads_in_one_batch(engine):
     lengths = [1, 31, 32, 33, 150, 255, 256, 257, 512, 513, 514, 600, 1000] * 6
     reads = _reads(target, [max(m, 1) for m in lengths], 73, unrelated_every=5)
     st = _check(engine, reads, target, "distance")
-    assert st["path"] == 1
+    assert st["path"] & 1 and st["path"] & 4
     _check(engine, reads, target, "path")
 
 
 def test_large_batch_through_probe_and_both_passes(engine):
-    """>= 16384 slots per group: the k-doubling probe, pass 1 at a small threshold, and >= 4096 unrelated leftovers
-    whose band is the whole query (scan_reads_full_kernel<12 / 16>)"""
+    """33,200 reads of 257..512 bases, a third of them unrelated (handed back to kernel W over the whole target)"""
     target = synth.random_dna(74, 12_000)
     rng = np.random.default_rng(75)
     lengths = [int(x) for x in rng.integers(257, 385, 16600)] + [int(x) for x in rng.integers(385, 513, 16600)]
     reads = _reads(target, lengths, 76, unrelated_every=3, max_err=0.03)
     st = _check(engine, reads, target, "distance")
-    assert st["path"] == 1
+    assert st["path"] & 4
 
 
 def test_repeats_overflow_the_end_location_lists(engine):
@@ -154,8 +155,7 @@ def test_mixed_lengths_513_to_1024(engine, task):
     lengths = _EDGES_1K + [int(x) for x in rng.integers(513, 1025, n)]
     reads = _reads(target, lengths, 83, unrelated_every=9)
     st = _check(engine, reads, target, task)
-    if task == "distance":
-        assert st["path"] == 1, "a read of 513..1024 bases left the reads-per-lane kernels"
+    assert st["path"] & 4
 
 
 @pytest.mark.parametrize("k", [0, 5, 60, 150, 2000])
@@ -167,30 +167,30 @@ def test_fixed_k_up_to_1024(engine, k):
     _check(engine, reads, target, "distance", k=k)
 
 
-def test_every_group_in_one_batch_and_1025_on_the_pair_path(engine):
+def test_every_length_class_in_one_batch(engine):
     target = synth.random_dna(87, 30_000)
     lengths = [20, 150, 256, 257, 384, 385, 512, 513, 768, 769, 1024, 1025, 1500] * 5
     reads = _reads(target, lengths, 88, unrelated_every=6)
     st = _check(engine, reads, target, "distance")
-    assert st["path"] == 3
+    assert st["path"] == 7
     _check(engine, reads, target, "locations")
 
 
-def test_five_symbols_stop_at_512(engine):
+def test_five_symbols_any_length(engine):
     target = synth.masked_genome(89, 30_000, frac_lower=0.0)
-    reads = _reads(target, [300, 512, 513, 700, 1024] * 8, 90)
+    reads = _reads(target, [300, 512, 513, 700, 1024, 2100] * 8, 90)
     st = _check(engine, reads, target, "distance")
-    assert st["path"] == 3
+    assert st["path"] & 4
 
 
 def test_large_long_batch_through_probe_and_both_passes(engine):
-    """>= 16384 slots in the 24- and 32-word groups: probe, pass 1, and unrelated leftovers on scan_reads_full_kernel"""
+    """33,000 reads of 513..1024 bases, a third of them unrelated"""
     target = synth.random_dna(91, 8_000)
     rng = np.random.default_rng(92)
     lengths = [int(x) for x in rng.integers(513, 769, 16500)] + [int(x) for x in rng.integers(769, 1025, 16500)]
     reads = _reads(target, lengths, 93, unrelated_every=3, max_err=0.02)
     st = _check(engine, reads, target, "distance")
-    assert st["path"] == 1
+    assert st["path"] & 4
 
 
 def test_equalities_with_long_reads(engine):
@@ -199,3 +199,87 @@ def test_equalities_with_long_reads(engine):
     for r in reads[::3]:
         r[::17] = ord("N")
     _check(engine, reads, target, "locations", eq=[("N", "A"), ("N", "C"), ("N", "G"), ("N", "T")])
+
+
+# ------------------------------------------------------------------------------------------ beyond 1024 bases
+
+_EDGES_LONG = [1025, 1026, 1279, 1280, 1281, 2047, 2048, 2049, 3000, 4095, 4096, 4097, 5000, 8191, 8192, 8193, 10000]
+
+
+@pytest.mark.parametrize("task", ["distance", "locations", "path"])
+def test_lengths_1025_to_10000(engine, task):
+    """every length class of the filter's plan (1 .. 40 parts), Illumina-like to ONT-like divergence, a few unrelated"""
+    target = synth.random_dna(101, 120_000)
+    rng = np.random.default_rng(102)
+    n = 120 if task == "distance" else 40
+    lengths = (_EDGES_LONG if task == "distance" else _EDGES_LONG[::3]) + [int(x) for x in rng.integers(1025, 10001, n)]
+    reads = _reads(target, lengths, 103, unrelated_every=11, max_err=0.15)
+    st = _check(engine, reads, target, task)
+    assert st["path"] & 4
+
+
+@pytest.mark.parametrize("k", [0, 7, 64, 300, 1500, 20000])
+def test_fixed_k_long(engine, k):
+    """the ladder is capped by the caller's k: -1 / NULL / 0 above it, the same answers below"""
+    target = synth.random_dna(104, 60_000)
+    rng = np.random.default_rng(105 + k)
+    lengths = [1025, 2048, 4096, 6000] + [int(x) for x in rng.integers(300, 6000, 60)]
+    reads = _reads(target, lengths, 106 + k, unrelated_every=9, max_err=0.12)
+    _check(engine, reads, target, "distance", k=k)
+    _check(engine, reads[:20], target, "locations", k=k)
+
+
+def test_low_complexity_is_handed_back(engine):
+    """homopolymers, short tandem repeats, a read that occurs hundreds of times: the candidate lists overflow or the windows
+    cover the target, the queries go back to kernel W over the whole target -- same answers"""
+    unit = synth.random_dna(107, 40)
+    target = np.concatenate([synth.random_dna(108, 5000), np.tile(unit, 700), np.full(3000, ord("A"), dtype=np.uint8),
+                             synth.random_dna(109, 5000)])
+    reads = [np.full(400, ord("A"), dtype=np.uint8), np.tile(unit, 20)[:777].copy(), np.tile(unit, 40)[3:1503].copy(),
+             np.tile(np.frombuffer(b"AC", dtype=np.uint8), 300), target[4000:5500].copy(), target[32000:33200].copy()]
+    _check(engine, reads, target, "distance")
+    _check(engine, reads, target, "locations")
+
+
+def test_many_copies_many_windows(engine):
+    """a 600-base element planted 50 times with one substitution each: 50 windows per query, all end locations reported"""
+    el = synth.random_dna(110, 600)
+    parts = []
+    for c in range(50):
+        e = el.copy(); e[(37 * c) % 600] = _ACGT[(np.searchsorted(_ACGT, e[(37 * c) % 600]) + 1) % 4]
+        parts += [synth.random_dna(111 + c, 900), e]
+    target = np.concatenate(parts)
+    reads = [el.copy(), el[:500].copy(), el[50:].copy()]
+    _check(engine, reads, target, "locations")
+
+
+def test_match_at_the_target_edges(engine):
+    """windows clipped at column 0 and at the last column; a query longer than the target"""
+    target = synth.random_dna(112, 9000)
+    reads = [target[:1500].copy(), target[-1500:].copy(), target[10:2000].copy(), target[-3000:-5].copy(),
+             np.concatenate([synth.random_dna(113, 300), target[:1200]]), np.concatenate([target[-1200:], synth.random_dna(114, 300)]),
+             np.concatenate([target, synth.random_dna(115, 500)])]
+    for task in ("distance", "locations", "path"):
+        _check(engine, reads, target, task)
+
+
+def test_large_batch_of_long_reads(engine):
+    """enough pieces for several segments per lane and every word-count group of the filter at once"""
+    target = synth.random_dna(116, 200_000)
+    rng = np.random.default_rng(117)
+    lengths = [int(x) for x in rng.integers(257, 3000, 6000)]
+    reads = _reads(target, lengths, 118, unrelated_every=40, max_err=0.08)
+    _check(engine, reads, target, "distance")
+
+
+def test_round2_word_groups_still_agree():
+    """EDLIB_AMD_FILTER=0 (read when the library loads: a fresh interpreter) restores the groups of 12 / 16 / 24 / 32 words"""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, edlib_amd\nfrom edlib_amd import synth\nfrom test_gpu_long_reads import _reads, _check\n"
+            "t = synth.random_dna(119, 30000)\n"
+            "r = _reads(t, [257, 300, 384, 385, 512, 513, 768, 769, 1024] * 8, 120, unrelated_every=9)\n"
+            "st = _check(edlib_amd, r, t, 'distance'); assert st['path'] == 1, st\nprint('ok')\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, EDLIB_AMD_FILTER="0"))
+    assert p.returncode == 0 and "ok" in p.stdout, p.stdout[-800:] + p.stderr[-2000:]
