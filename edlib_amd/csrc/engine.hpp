@@ -166,6 +166,10 @@ private:
     int syms_ = 4;               // Peq rows per word of the reads kernels: target symbols rounded up to 4, 8 or 16
     int packTarget();
     int runReads();                                   // device work only; results stay in HBM
+    int makeGroup(const std::vector<int>& units, int words, std::unique_ptr<ReadGroup>& g);
+    int runGroupScans(ReadGroup& g, bool fullOnly);
+    int runGroupExact(ReadGroup& g);
+    int collectGroup(ReadGroup& g, std::vector<UnitResult>& res);
     // ---- long HW queries: piece filter on the reads-per-lane kernel + window verification on kernel W (long_reads.hip)
     struct Piece { long long off; int len; int thr; };           // rows [off, off + len) of the query pool, threshold of its scan
     int scanPieces(const std::vector<Piece>& pieces, bool filter, std::vector<std::pair<int, int>>* cand,

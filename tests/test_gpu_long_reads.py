@@ -60,8 +60,8 @@ def _check(engine, reads, target, task, k=-1, eq=None):
                        task, k, eq_pairs=eq)
     for f in ("status", "editDistance", "numLocations", "alphabetLength", "locOff", "ends", "alnOff", "alignment"):
         assert np.array_equal(got[f], ref[f]), f
-    if task != "distance":
-        assert np.array_equal(got["starts"], ref["starts"])
+    if task != "distance":          # (no unit with a result: the flat form has no starts array at all)
+        assert np.array_equal(got["starts"], ref["starts"]) or (got["starts"] is None and len(ref["starts"]) == 0)
     return st
 
 
