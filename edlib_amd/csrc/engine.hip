@@ -995,7 +995,7 @@ static int peq_row_stride(long long nb) {
 }
 
 int Batch::solve(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units, SolveOut& out,
-                 int ring)
+                 int ring, int ringH)
 {
     const size_t n = units.size();
     out.score.assign(n, -1); out.count.assign(n, 0); out.last.assign(n, -1);
@@ -1017,14 +1017,14 @@ int Batch::solve(int mode, bool wantPositions, bool wantPath, const std::vector<
             if (b > a && (peqBytes + pb > peqBudget || storeBytes + sb > storeBudget)) break;
             peqBytes += pb; storeBytes += sb; ++b;
         }
-        if (solveChunk(mode, wantPositions, wantPath, units, a, b, out, ring)) return 1;
+        if (solveChunk(mode, wantPositions, wantPath, units, a, b, out, ring, ringH)) return 1;
         a = b;
     }
     return 0;
 }
 
 int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units,
-                      size_t ua, size_t ub, SolveOut& out, int ring)
+                      size_t ua, size_t ub, SolveOut& out, int ring, int ringH)
 {
     const size_t n = ub - ua;
     Lap lap;
@@ -1049,7 +1049,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         d.colOff = -1; d.bandT = 0; d.ring = ring;
         if (wantPath) opsOff[i + 1] = opsOff[i] + (long long)s.qlen + s.tlen;
         // executed work: whole matrix, or one 64-block wave per column inside the band
-        stats.word_steps += ring ? 2LL * ring * ((long long)s.tlen + nb - 1) : 2 * nb * (long long)s.tlen;
+        stats.word_steps += ring ? 2LL * ring * ringH * ((long long)s.tlen + (nb + ringH - 1) / ringH - 1) : 2 * nb * (long long)s.tlen;
     }
     // A handful of units (edlibAlign() is one): the kernels write scores, positions and op strings straight into
     // device-visible pinned host memory -- no download commands behind the launches, one stream synchronisation.
@@ -1112,7 +1112,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p; a.posPool = d_posPool_.p;
     a.colP = nullptr; a.colM = nullptr; a.colS = nullptr;
     scanTimerStart();
-    if (ring) EDLIB_AMD_HIP(launch_scan_pairs_ring(ring, mode, wantPath, a, stream_));
+    if (ring) EDLIB_AMD_HIP(launch_scan_pairs_ring(ring, mode, wantPath, a, stream_, ringH));
     else EDLIB_AMD_HIP(launch_scan_pairs(mode, wantPath, a, stream_));
     scanTimerStop();
     if (wantPath) {
@@ -1557,23 +1557,27 @@ int Batch::solveSemiGlobalUnits(int mode, bool wantPositions, const std::vector<
 {
     const size_t n = units.size();
     const bool ringsOff = getenv("EDLIB_AMD_NWBAND") && getenv("EDLIB_AMD_NWBAND")[0] == '0';
-    static const int rings[3] = {4, 16, 0};
-    std::vector<int> grp(n, 2);
-    size_t cnt[3] = {0, 0, 0};
+    // units of up to 4 / 16 blocks on 4- / 16-lane rings, up to 32 / 64 blocks on 16-lane rings whose lanes hold 2 / 4
+    // blocks (four units per wave, every lane busy: a 1025-base query on the strips uses 17 of a wave's 64 lanes), the
+    // rest on the strips
+    static const int rings[5] = {4, 16, 16, 16, 0}, ringH[5] = {1, 1, 2, 4, 1};
+    const int NG = 5;
+    std::vector<int> grp(n, NG - 1);
+    size_t cnt[NG] = {0, 0, 0, 0, 0};
     for (size_t i = 0; i < n; ++i) {
         const int nb = (units[i].qlen + 63) / 64;
-        if (!ringsOff) grp[i] = nb <= 4 ? 0 : (nb <= 16 ? 1 : 2);
+        if (!ringsOff) grp[i] = nb <= 4 ? 0 : (nb <= 16 ? 1 : (nb <= 32 ? 2 : (nb <= 64 ? 3 : 4)));
         ++cnt[grp[i]];
     }
-    for (int g = 0; g < 3; ++g)
-        if (cnt[g] == n) return solve(mode, wantPositions, false, units, out, rings[g]);   // the usual case: one kind
-    SolveOut part[3];
+    for (int g = 0; g < NG; ++g)
+        if (cnt[g] == n) return solve(mode, wantPositions, false, units, out, rings[g], ringH[g]);   // the usual case: one kind
+    SolveOut part[NG];
     std::vector<size_t> where(n);
-    for (int g = 0; g < 3; ++g) {
+    for (int g = 0; g < NG; ++g) {
         if (!cnt[g]) continue;
         std::vector<UnitSpec> sel; sel.reserve(cnt[g]);
         for (size_t i = 0; i < n; ++i) if (grp[i] == g) { where[i] = sel.size(); sel.push_back(units[i]); }
-        if (solve(mode, wantPositions, false, sel, part[g], rings[g])) return 1;
+        if (solve(mode, wantPositions, false, sel, part[g], rings[g], ringH[g])) return 1;
     }
     out.score.resize(n); out.count.resize(n); out.last.resize(n);
     out.posStart.assign(n + 1, 0); out.posFlat.clear();
@@ -1603,7 +1607,12 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
     score.assign(n, -1);
     if (n == 0) return 0;
     const bool bandOff = getenv("EDLIB_AMD_NWBAND") && getenv("EDLIB_AMD_NWBAND")[0] == '0';
-    static const int ringOf[kNumRings] = {4, 8, 16, 21, 32, 64};
+    // ring levels (lanes, blocks per lane): band limits 128, 384, 896, 1792, 3584, 3968; level nl = unbanded strips.  The
+    // 16-lane rings with 2 / 4 blocks per lane replace round 2's 21- and 32-lane rings here (four units per wave instead
+    // of three / two, the carry on a DPP row rotation, the per-lane glue of a step shared by 2 / 4 block updates)
+    static const int ringOf[kNumRings] = {4, 8, 16, 16, 16, 64}, ringH[kNumRings] = {1, 1, 1, 2, 4, 1};
+    auto cap_of = [&](int l) { return ring_max_k(ringOf[l], ringH[l]); };
+    auto blocks_of = [&](int l) { return ringOf[l] * ringH[l]; };
     const int nl = kNumRings;                                           // ring levels; level nl = unbanded strips
     const int kInf = 0x3fffffff;
     const int kcap = cfg_.k >= 0 ? cfg_.k : kInf;                       // answers above the caller's k are all alike
@@ -1642,7 +1651,7 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
         const double mean = rate * std::min(u.qlen, u.tlen) + std::abs(u.qlen - u.tlen);
         const double est = std::min<double>(kcap, mean + 0.5 * std::sqrt(mean) + 8);
         for (int l = 0; l < nl; ++l)
-            if (blocks(i) <= ringOf[l] || est <= ring_max_k(ringOf[l])) return l;
+            if (blocks(i) <= blocks_of(l) || est <= cap_of(l)) return l;
         return est <= 2.0 * ring_max_k(64) ? nl - 1 : nl;               // far above every band: straight to the strips
     };
     std::vector<int>& lvl = lvlScratch_;
@@ -1658,7 +1667,7 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
             if (units[i].qlen != lastQ || units[i].tlen != lastT) {
                 lastQ = units[i].qlen; lastT = units[i].tlen;
                 lastL = bandOff ? nl : first_level(i);
-                if (!bandOff && fewUnits && lastL < nl - 1 && blocks(i) > ringOf[lastL]) lastL = nl - 1;
+                if (!bandOff && fewUnits && lastL < nl - 1 && blocks(i) > blocks_of(lastL)) lastL = nl - 1;
             }
             lvl[i] = lastL;
             ++atLevel[lastL];
@@ -1672,12 +1681,12 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
         for (size_t i = 0; i < n; ++i) {
             if (lvl[i] != l) continue;
             UnitSpec u = units[i];
-            if (l < nl) u.kinit = std::min(kcap, blocks(i) <= ringOf[l] ? std::max(u.qlen, u.tlen) : ring_max_k(ringOf[l]));
+            if (l < nl) u.kinit = std::min(kcap, blocks(i) <= blocks_of(l) ? std::max(u.qlen, u.tlen) : cap_of(l));
             sel.push_back(u); who.push_back(i);
         }
         if (sel.empty()) continue;
         SolveOut& so = soLevel_;
-        if (solve(EDLIB_MODE_NW, false, false, sel, so, l < nl ? ringOf[l] : 0)) return 1;
+        if (solve(EDLIB_MODE_NW, false, false, sel, so, l < nl ? ringOf[l] : 0, l < nl ? ringH[l] : 1)) return 1;
         for (size_t q = 0; q < sel.size(); ++q) {
             const size_t i = who[q];
             if (l == nl || so.score[q] <= sel[q].kinit) score[i] = so.score[q];         // exact

@@ -194,10 +194,11 @@ private:
     // ring = 0: unbanded strips (any mode).  ring = 4 / 16 / 64: NW inside Ukkonen's band for threshold
     // UnitSpec::kinit on rings of that many lanes (exact iff score <= kinit); the caller guarantees that
     // the band fits (kinit <= ring_max_k(ring), or the unit has at most `ring` blocks)
+    // ringH = 2 / 4 (ring 16, no path): ring lanes of 2 / 4 vertically adjacent blocks, band limit ring_max_k(16, ringH)
     int solve(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units, SolveOut& out,
-              int ring = 0);
+              int ring = 0, int ringH = 1);
     int solveChunk(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units,
-                   size_t a, size_t b, SolveOut& out, int ring);
+                   size_t a, size_t b, SolveOut& out, int ring, int ringH);
     // NW distances by threshold levels on rings of 4, 16, 64 lanes, then unbanded (the reference's
     // k-doubling, edlib.cpp:197-217, with thresholds chosen for the hardware)
     int solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<int>& score);

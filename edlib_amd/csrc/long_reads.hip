@@ -189,7 +189,11 @@ int Batch::solveLongReads(std::vector<UnitResult>& res, std::vector<int>& fallba
     std::vector<int> level(n);                     // current threshold of every query; -1 resolved, -2 handed back
     for (size_t i = 0; i < n; ++i) {
         const int m = qlen(longUnits_[i]);
-        const int k0 = (int)std::ceil(1.5 * rate * m) + 12;
+        // expected distance D = rate * m of a query like the sample's median, two standard deviations of a sum of m
+        // Bernoulli trials above it (a threshold that is too generous costs band height in every piece scan:
+        // about a word per 8 units of the piece threshold)
+        const double D = rate * m;
+        const int k0 = (int)std::ceil(D + 2.0 * std::sqrt(D) + 3.0);
         level[i] = std::min(kmax_of(m), k0);
     }
     std::vector<size_t> pending(n);
@@ -277,7 +281,9 @@ int Batch::solveLongReads(std::vector<UnitResult>& res, std::vector<int>& fallba
                     finalize_semiglobal(res[u], cfg_.k, m, -1, nullptr, 0);
                     level[i] = -1;
                 } else {
-                    level[i] = std::min(kmax_of(m), 2 * k);            // the reference's doubling
+                    // the reference doubles (edlib.cpp:197-217); what fails the first level here is mostly unrelated sequence
+                    // that will fail every level, so the steps are larger
+                    level[i] = std::min(kmax_of(m), 4 * k);
                     next.push_back(i);
                 }
             }

@@ -377,18 +377,28 @@ long long ring_store_entries(int G, int qlen, int tlen) {
 // MODE 0 NW as described; MODE 1 SHW / 2 HW: no band (the launcher only sends units whose blocks all fit
 // the ring), kinit is the end-location threshold as in scan_pairs_kernel, the lane of the last block
 // follows row m-1 and records best / count / positions (edlib.cpp:658-673).
-template <int G, int MODE, bool STORE, int PEQ>
+// H: 64-row blocks per ring lane ("superblock", round 3).  A lane holds H vertically adjacent blocks of the same column
+// and updates them one after the other inside a step (the carry between them never leaves the lane), so everything a
+// step does once per lane -- the carry exchange with the ring neighbour, the countdown, the fetch of the next column's
+// row offset and Peq address, the neutral-carry selects -- is paid once per H blocks: ~20 of the 42 VALU instructions
+// of the H = 1 step are such glue (profiles/README.md), against 22 per block update.  A ring of G lanes then holds
+// bands of up to 64 H (G - 2) rows: 16 lanes x 2 blocks cover what 21- and 32-lane rings did, with four units per wave
+// instead of three or two and the carry on one DPP row rotation instead of ds_bpermute.  Band, block life and the "+1 per
+// row" start are the formulas above with 64 H rows per block.  H > 1: distance scans only (no column store).
+template <int G, int MODE, bool STORE, int PEQ, int H>
 __global__ void __launch_bounds__(64)
 scan_pairs_ring_kernel(const PairScanArgs a)
 {
+    static_assert(H == 1 || !STORE, "the column store is laid out per 64-row block");
     extern __shared__ __attribute__((aligned(16))) u64 s_dyn[];      // Peq words, then the target rings
     constexpr int U = 64 / G;                                         // units per wave (lanes past U * G idle)
+    constexpr int RH = 64 * H;                                        // rows per ring lane
     const int lane = threadIdx.x;
     const int rl = lane % G, uwRaw = lane / G;                        // lane within the ring, ring within the wave
     const bool inRing = uwRaw < U;
     const int uw = inRing ? uwRaw : U - 1;                            // idle lanes alias the last ring's LDS (reads only)
     const int srcAddr = 4 * (lane - rl + (rl == 0 ? G - 1 : rl - 1));
-    const int peqWords = PEQ == 1 ? a.sigmaT * 64 : (PEQ == 2 ? U * a.peqFullStride : 0);
+    const int peqWords = PEQ == 1 ? a.sigmaT * 64 * H : (PEQ == 2 ? U * a.peqFullStride : 0);
     u64* s_peq = s_dyn + (PEQ == 2 ? uw * a.peqFullStride : 0);
     unsigned short* s_tgt = reinterpret_cast<unsigned short*>(s_dyn + peqWords) + uw * 256;
     const int unit = blockIdx.x * U + uwRaw;
@@ -410,7 +420,8 @@ scan_pairs_ring_kernel(const PairScanArgs a)
     auto toff_ = [&]() { return G == 64 ? toffU : dp->toff; };
     auto peqOff_ = [&]() { return G == 64 ? peqOffU : dp->peqOff; };
     const long long storeOff = STORE ? uni64(dp->storeOff) : 0;
-    const int nb = num_blocks(m);
+    const int nb = num_blocks(m);                                     // 64-row blocks
+    const int nsb = (nb + H - 1) / H;                                 // ring-lane blocks of RH rows
     const int D = (bandT ? bandT : T) - m, absD = D < 0 ? -D : D;     // the band is that of the whole problem
     // last-column dump of Hirschberg halves: the packed rings look their slot up when they get there
     const bool dumpCol = a.colP != nullptr && (G != 64 || colOffU >= 0);
@@ -420,14 +431,15 @@ scan_pairs_ring_kernel(const PairScanArgs a)
     const int p = MODE != 0 ? (1 << 28) : (K - absD) >> 1;            // semi-global: the whole matrix
     const int dmin = (D < 0 ? D : 0) - p, dmax = (D > 0 ? D : 0) + p;
     int best = K, cnt = 0, lastCol = -1;                              // MODE != 0: columns scoring <= best qualify
-    const u32 sh = (u32)(m - 1) & 63u;
-    const int lastRows = m - 64 * (nb - 1);                           // query rows in the last block
-    const int nbA = active ? nb : 0;                                  // idle rings own no block
+    const u32 sh = (u32)(m - 1) & 63u;                                // row m-1 inside its 64-row block ...
+    const int hb = (nb - 1) % H;                                      // ... which is this block of the last ring-lane block
+    const int lastRows = m - RH * (nsb - 1);                          // query rows in the last ring-lane block
+    const int nbA = active ? nsb : 0;                                 // idle rings own no block
 
     // ---- target ring: the Peq row offsets of columns [0, loaded) are in s_tgt[col & 255]
     // symbol -> byte offset of its Peq row as seen from the lane's base address (PEQ 0: the symbol itself)
     const int rowStride = PEQ == 2 ? a.peqRowStride : 0;
-    const int symScale = PEQ == 1 ? 512 : (PEQ == 2 ? 8 * rowStride : 1);
+    const int symScale = PEQ == 1 ? 512 * H : (PEQ == 2 ? 8 * rowStride : 1);
     int loaded = 0;
     auto refill = [&]() {                                             // 64 more columns per ring
         const long long toff = toff_(); const int tstep = tstep_();
@@ -444,20 +456,29 @@ scan_pairs_ring_kernel(const PairScanArgs a)
     if (PEQ == 2 && active) {
         const long long peqOff = peqOff_();
         for (int sy = 0; sy < a.sigmaT; ++sy)
-            for (int i = rl; i < nb; i += G) s_peq[sy * rowStride + i] = a.peq[peqOff + (long long)sy * nb + i];
+            for (int i = rl; i < rowStride; i += G) s_peq[sy * rowStride + i] = i < nb ? a.peq[peqOff + (long long)sy * nb + i] : 0ull;
     }
-    int b = rl;                                                       // current (or next) block of this lane
-    // Peq word of the column whose row offset is `off`: one add from the lane's base
-    const char* peqBase = reinterpret_cast<const char*>(s_peq) + (PEQ == 1 ? 8 * lane : 0);
-    auto peq_word = [&](const int off) -> u64 {
-        if (PEQ == 2) return *reinterpret_cast<const u64*>(peqBase + off + 8 * b);
-        if (PEQ == 1) return *reinterpret_cast<const u64*>(peqBase + off);
-        return a.peq[peqOff_() + (long long)off * nb + b];
+    int b = rl;                                                       // current (or next) ring-lane block of this lane
+    // Peq words of the column whose row offset is `off` (the H blocks of this lane): one add from the lane's base
+    const char* peqBase = reinterpret_cast<const char*>(s_peq) + (PEQ == 1 ? 8 * H * lane : 0);
+    auto peq_words = [&](const int off, u64 (&w)[H]) {
+        if (PEQ == 2) {
+            const u64* q = reinterpret_cast<const u64*>(peqBase + off + 8 * H * b);
+#pragma unroll
+            for (int h = 0; h < H; ++h) w[h] = q[h];
+        } else if (PEQ == 1) {
+            const u64* q = reinterpret_cast<const u64*>(peqBase + off);
+#pragma unroll
+            for (int h = 0; h < H; ++h) w[h] = q[h];
+        } else {
+#pragma unroll
+            for (int h = 0; h < H; ++h) w[h] = (b * H + h < nb) ? a.peq[peqOff_() + (long long)off * nb + b * H + h] : 0ull;
+        }
     };
 
     // ---- per-lane block bookkeeping.  Block b is updated at steps tstart .. tstart + span
-    auto first_col = [&](int blk) { const int c = 64 * blk + dmin; return c < 0 ? 0 : c; };
-    auto last_col = [&](int blk) { const int c = 64 * blk + 63 + dmax; return c > T - 1 ? T - 1 : c; };
+    auto first_col = [&](int blk) { const int c = RH * blk + dmin; return c < 0 ? 0 : c; };
+    auto last_col = [&](int blk) { const int c = RH * blk + RH - 1 + dmax; return c > T - 1 ? T - 1 : c; };
     const int never = 0x3fffffff;
     int ev, span = 0;                                                 // steps until this lane's next event; life of its block
     auto arm = [&](const int t) {                                     // countdown to the start of block b
@@ -470,9 +491,11 @@ scan_pairs_ring_kernel(const PairScanArgs a)
     u32 actm = 0u;                                                    // all ones while the lane is inside its block's life
     u32 xmask = (b == 0) ? 0u : ~0u, xfix = (b == 0) ? ((MODE == 2) ? 0u : 1u) : 0u;   // what block 0 takes instead of x
 
-    Block64 B{~0u, ~0u, 0u, 0u};
+    Block64 B[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) B[h] = Block64{~0u, ~0u, 0u, 0u};
     int bscore = 0, sc = 0, carry = 1;
-    int nsteps = active ? T + nb : 0;                                 // one step past the last block's last: its closing event
+    int nsteps = active ? T + nsb : 0;                                // one step past the last block's last: its closing event
     if constexpr (G == 64) nsteps = __builtin_amdgcn_readfirstlane(nsteps);
     else {                                          // the wave runs for its longest unit
         int w = 0;
@@ -481,19 +504,29 @@ scan_pairs_ring_kernel(const PairScanArgs a)
         nsteps = w;
     }
     int cidx = 0;                                                     // column of the NEXT row-offset fetch (col + 2)
+    // vertical deltas summed over the blocks below block h of this lane (score of block h's bottom row = bscore - that)
+    auto below_blocks = [&](const int h) {
+        int d = 0;
+#pragma unroll
+        for (int q = 1; q < H; ++q)
+            if (q > h) d += __popcll(((u64)B[q].p1 << 32) | B[q].p0) - __popcll(((u64)B[q].m1 << 32) | B[q].m0);
+        return d;
+    };
 
     // The rare part of a step: some lane's block has just finished (its last update was step t - 1) or starts now.
-    auto events = [&](const int t, const int x, u64& eqCur, int& offCur) {
+    auto events = [&](const int t, const int x, u64 (&eqCur)[H], int& offCur) {
         const int upScore = ring_ror<G>(bscore, srcAddr);             // upstream's bottom score after step t - 1
         if (ev == 0 && actm) {                                        // ---- closing block b
             const int colLast = t - 1 - b;
             if (colLast == T - 1) {                                   // it was alive at the stop column
-                if (b == nb - 1) {
+                if (b == nsb - 1) {
                     if (MODE == 0) {
-                        // D[m][T] from the block's bottom score and the vertical deltas below row m-1 (edlib.cpp:914-917)
-                        const u64 P = ((u64)B.p1 << 32) | B.p0, M = ((u64)B.m1 << 32) | B.m0;
+                        // D[m][T] from the bottom score of row m-1's block and the vertical deltas below row m-1 (edlib.cpp:914-917)
+                        u64 P = 0, M = 0;
+#pragma unroll
+                        for (int h = 0; h < H; ++h) if (h == hb) { P = ((u64)B[h].p1 << 32) | B[h].p0; M = ((u64)B[h].m1 << 32) | B[h].m0; }
                         const u64 below = (sh == 63u) ? 0ull : (~0ull << (sh + 1));
-                        a.outScore[unit] = bscore - __popcll(P & below) + __popcll(M & below);
+                        a.outScore[unit] = bscore - below_blocks(hb) - __popcll(P & below) + __popcll(M & below);
                         a.outCount[unit] = 1; a.outLast[unit] = T - 1;
                     } else {
                         a.outScore[unit] = cnt > 0 ? best : -1; a.outCount[unit] = cnt; a.outLast[unit] = lastCol;
@@ -502,8 +535,12 @@ scan_pairs_ring_kernel(const PairScanArgs a)
                 if (dumpCol) {                                        // stop column of a Hirschberg half
                     const long long co = G == 64 ? colOffU : dp->colOff;
                     if (co >= 0) {
-                        a.colP[co + b] = ((u64)B.p1 << 32) | B.p0; a.colM[co + b] = ((u64)B.m1 << 32) | B.m0;
-                        a.colS[co + b] = bscore;
+#pragma unroll
+                        for (int h = 0; h < H; ++h)
+                            if (b * H + h < nb) {
+                                a.colP[co + b * H + h] = ((u64)B[h].p1 << 32) | B[h].p0; a.colM[co + b * H + h] = ((u64)B[h].m1 << 32) | B[h].m0;
+                                a.colS[co + b * H + h] = bscore - below_blocks(h);
+                            }
                     }
                 }
             }
@@ -516,15 +553,19 @@ scan_pairs_ring_kernel(const PairScanArgs a)
             const int col = t - b;
             if (PEQ == 1) {
                 const long long peqOff = peqOff_();
-                for (int sy = 0; sy < a.sigmaT; ++sy) s_peq[sy * 64 + lane] = a.peq[peqOff + (long long)sy * nb + b];
+                for (int sy = 0; sy < a.sigmaT; ++sy)
+#pragma unroll
+                    for (int h = 0; h < H; ++h)
+                        s_peq[(sy * 64 + lane) * H + h] = (b * H + h < nb) ? a.peq[peqOff + (long long)sy * nb + b * H + h] : 0ull;
             }
-            B = Block64{~0u, ~0u, 0u, 0u};                            // "+1 per row" (edlib.cpp:759-763, 803-808)
+#pragma unroll
+            for (int h = 0; h < H; ++h) B[h] = Block64{~0u, ~0u, 0u, 0u};    // "+1 per row" (edlib.cpp:759-763, 803-808)
             // bottom of the block above at column col - 1: upstream's bottom after its step minus its delta at `col`
             // (a sender outside its block's life extrapolates by +1 per column, the value its receivers assume)
-            const int above = (col == 0) ? 64 * b : upScore - ((x & 1) - ((x >> 1) & 1));
-            bscore = above + 64;
-            if (MODE != 0 && b == nb - 1) sc = above + lastRows;
-            eqCur = peq_word(s_tgt[col & 255]);
+            const int above = (col == 0) ? RH * b : upScore - ((x & 1) - ((x >> 1) & 1));
+            bscore = above + RH;
+            if (MODE != 0 && b == nsb - 1) sc = above + lastRows;
+            peq_words(s_tgt[col & 255], eqCur);
             offCur = s_tgt[(col + 1) & 255];
             cidx = col + 2;
             actm = ~0u;
@@ -532,35 +573,41 @@ scan_pairs_ring_kernel(const PairScanArgs a)
         }
     };
 
-    // One step.  eqCur / offCur: Peq word of this step's column and row offset of the next column (fetched by
+    // One step.  eqCur / offCur: Peq words of this step's column and row offset of the next column (fetched by
     // the previous step); eqNxt / offNxt are fetched here for the next step -- the caller swaps the two
     // register sets every step instead of moving them.
-    auto step = [&](const int t, u64& eqCur, u64& eqNxt, int& offCur, int& offNxt) {
+    auto step = [&](const int t, u64 (&eqCur)[H], u64 (&eqNxt)[H], int& offCur, int& offNxt) {
         const int x = ring_ror<G>(carry, srcAddr);
         if (__builtin_amdgcn_ballot_w64(ev == 0) != 0ull) events(t, x, eqCur, offCur);
         --ev;
-        eqNxt = peq_word(offCur);
+        peq_words(offCur, eqNxt);
         offNxt = s_tgt[cidx & 255];
         ++cidx;
-        u32 ph0, ph1, mh0, mh1;
         // block 0 takes row -1 (+1 per column, 0 for HW: edlib.cpp:584, 779) whatever its ring neighbour sends (in a
         // ring that holds all blocks of its unit the last block's lane feeds lane 0); every other block takes what
         // arrives: its upstream's delta, or the +1 a sender outside its block's life emits
         const u32 xx = __builtin_amdgcn_bitop3_b32((u32)x, xmask, xfix, 0xea /* (a & b) | c */);
-        advance_block64(B, (u32)eqCur, (u32)(eqCur >> 32), xx & 1u, xx >> 1, ph0, ph1, mh0, mh1);
-        const u32 hp = ph1 >> 31, hn = mh1 >> 31;
+        u32 hp = xx & 1u, hn = xx >> 1;
+        u32 phT0 = 0, phT1 = 0, mhT0 = 0, mhT1 = 0;                   // horizontal deltas of row m-1's block (MODE != 0)
+#pragma unroll
+        for (int h = 0; h < H; ++h) {                                 // top to bottom: the carry stays in the lane
+            u32 ph0, ph1, mh0, mh1;
+            advance_block64(B[h], (u32)eqCur[h], (u32)(eqCur[h] >> 32), hp, hn, ph0, ph1, mh0, mh1);
+            hp = ph1 >> 31; hn = mh1 >> 31;
+            if (MODE != 0) { const bool tr = h == hb; phT0 = tr ? ph0 : phT0; phT1 = tr ? ph1 : phT1; mhT0 = tr ? mh0 : mhT0; mhT1 = tr ? mh1 : mhT1; }
+        }
         // carry and block score of a lane outside its block's life: +1 per step
         carry = (int)__builtin_amdgcn_bitop3_b32(hp | (hn << 1), 1u, actm, 0xe4 /* c ? a : b */);
         bscore += (int)__builtin_amdgcn_bitop3_b32(hp - hn, 1u, actm, 0xe4);
         if (STORE || MODE != 0) {
             if (actm) {
                 const int col = t - b;
-                if (STORE) {
+                if constexpr (STORE) {
                     a.store[storeOff + (long long)rl * T + col] =
-                        StoreEntry{((u64)B.p1 << 32) | B.p0, ((u64)B.m1 << 32) | B.m0, bscore, {0, 0, 0}};
+                        StoreEntry{((u64)B[0].p1 << 32) | B[0].p0, ((u64)B[0].m1 << 32) | B[0].m0, bscore, {0, 0, 0}};
                 }
-                if (MODE != 0 && b == nb - 1) {
-                    const u64 ph = ((u64)ph1 << 32) | ph0, mh = ((u64)mh1 << 32) | mh0;
+                if (MODE != 0 && b == nsb - 1) {
+                    const u64 ph = ((u64)phT1 << 32) | phT0, mh = ((u64)mhT1 << 32) | mhT0;
                     sc += (int)((ph >> sh) & 1ull) - (int)((mh >> sh) & 1ull);
                     if (sc <= best && col >= dp->skip) {              // edlib.cpp:658-673
                         if (sc < best) { best = sc; cnt = 0; }
@@ -573,11 +620,13 @@ scan_pairs_ring_kernel(const PairScanArgs a)
         }
     };
 
-    u64 eqA = 0, eqB = 0;
+    u64 eqA[H], eqB[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) { eqA[h] = 0; eqB[h] = 0; }
     int offA = 0, offB = 0;
     for (int t = 0; t <= nsteps; t += 2) {
         if ((t & 63) == 0) {                                          // pace the ring by the largest column in use
-            int bt = t - 63 - dmax; bt = bt <= 0 ? 0 : (bt + 64) / 65;
+            int bt = t - (RH - 1) - dmax; bt = bt <= 0 ? 0 : (bt + RH) / (RH + 1);
             if (t - T + 1 > bt) bt = t - T + 1;
             const int jmax = t - bt;
             while (active && loaded < T && loaded < jmax + 64 + 67) refill();
@@ -587,7 +636,7 @@ scan_pairs_ring_kernel(const PairScanArgs a)
     }
 }
 
-template <int G, int MODE, bool STORE>
+template <int G, int MODE, bool STORE, int H = 1>
 static hipError_t launch_scan_pairs_ring_t(const PairScanArgs& a, hipStream_t stream)
 {
     constexpr int U = 64 / G;
@@ -596,20 +645,32 @@ static hipError_t launch_scan_pairs_ring_t(const PairScanArgs& a, hipStream_t st
     const size_t tgt = 512 * U;                                       // 256 row offsets (u16) per unit
     // the whole-Peq mode saves the refills of packed rings, but only pays while LDS does not cap the
     // occupancy (measured: 10 KB per wave costs config 4 a third of its rate); row offsets are 16 bits
-    if (G < 64 && a.peqFullStride > 0 && full + tgt <= 8192 && 8LL * a.peqRowStride * a.sigmaT < 65536) {
-        hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 2>), grid, dim3(64), full + tgt, stream, a);
+    if (G < 64 && a.peqFullStride > 0 && full + tgt <= 8192 && 8LL * a.peqRowStride * a.sigmaT < 65536 && a.peqRowStride % H == 0) {
+        hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 2, H>), grid, dim3(64), full + tgt, stream, a);
     } else if (a.sigmaT <= 32) {
-        const size_t lds = (size_t)a.sigmaT * 64 * sizeof(u64) + tgt;
-        hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 1>), grid, dim3(64), lds, stream, a);
+        const size_t lds = (size_t)a.sigmaT * 64 * H * sizeof(u64) + tgt;
+        hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 1, H>), grid, dim3(64), lds, stream, a);
     } else {
-        hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 0>), grid, dim3(64), tgt, stream, a);
+        hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 0, H>), grid, dim3(64), tgt, stream, a);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_scan_pairs_ring(int G, int mode, bool store, const PairScanArgs& a, hipStream_t stream)
+hipError_t launch_scan_pairs_ring(int G, int mode, bool store, const PairScanArgs& a, hipStream_t stream, int H)
 {
     if (a.numUnits == 0) return hipSuccess;
+    if (H != 1) {                                                     // ring-lane blocks of 128 / 256 rows: 16-lane rings, distance only
+        if (G != 16 || store || (H != 2 && H != 4)) return hipErrorInvalidValue;
+        switch (mode * 8 + H) {
+            case 2: return launch_scan_pairs_ring_t<16, 0, false, 2>(a, stream);
+            case 4: return launch_scan_pairs_ring_t<16, 0, false, 4>(a, stream);
+            case 10: return launch_scan_pairs_ring_t<16, 1, false, 2>(a, stream);
+            case 12: return launch_scan_pairs_ring_t<16, 1, false, 4>(a, stream);
+            case 18: return launch_scan_pairs_ring_t<16, 2, false, 2>(a, stream);
+            case 20: return launch_scan_pairs_ring_t<16, 2, false, 4>(a, stream);
+        }
+        return hipErrorInvalidValue;
+    }
     if (mode != 0 && (store || (G != 4 && G != 16))) return hipErrorInvalidValue;   // semi-global rings: 4 or 16 lanes, distance only
     switch (G * 8 + mode * 2 + (store ? 1 : 0)) {
         case 32: return launch_scan_pairs_ring_t<4, 0, false>(a, stream);

@@ -73,12 +73,15 @@ hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStr
 // kinit); a wave carries 64 / G units, whatever the query length (no strips).  Writes outScore and, when
 // colP is set, the (P, M, score) of the blocks alive at the last processed column (the caller pre-fills
 // the dump with "invalid").  store: also the column store in ring layout (ring_store_entries per unit).
-constexpr int ring_max_k(int G) { return 64 * G - 128; }
+constexpr int ring_max_k(int G, int H = 1) { return 64 * H * (G - 2); }      // H: 64-row blocks per ring lane (1, 2 or 4)
 constexpr int kNumRings = 6;           // ring sizes 4, 8, 16, 21, 32, 64 (units per wave: 16, 8, 4, 3, 2, 1)
 constexpr int kMaxBandK = ring_max_k(64);
 // mode 1 (SHW) / 2 (HW): packed rings only (ringLanes 4 or 16), every unit must have numBlocks <= ringLanes;
 // no band, kinit is the end-location threshold, outputs as launch_scan_pairs.
-hipError_t launch_scan_pairs_ring(int ringLanes, int mode, bool store, const PairScanArgs& a, hipStream_t stream);
+// blocksPerLane H = 2 / 4 (16-lane rings, no store): a ring lane holds H vertically adjacent blocks ("superblock"); the band
+// limit is ring_max_k(16, H), modes 1 / 2 take units of up to 16 H blocks.
+hipError_t launch_scan_pairs_ring(int ringLanes, int mode, bool store, const PairScanArgs& a, hipStream_t stream,
+                                  int blocksPerLane = 1);
 long long ring_store_entries(int ringLanes, int qlen, int tlen);
 
 // reference buildPeq (edlib.cpp:358-384) for every unit: Peq[sym][block] from the
