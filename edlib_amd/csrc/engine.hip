@@ -593,6 +593,9 @@ int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, i
     a.posOff = posOff; a.posCap = posCap;
     a.kcap = kcap; a.wordSteps = wordSteps ? wordSteps : d_wordSteps_.p;
     a.filter = filterScan_ ? 1 : 0;
+    a.chainIn = chain_.in; a.chainOut = chain_.out; a.chainSrc = chain_.src; a.chainInLanes = chain_.inLanes;
+    a.chainBlocks = chain_.blocks; a.rowBase = chain_.rowBase;
+    const bool chained = chain_.in != nullptr || chain_.out != nullptr;
     static const bool dbg = getenv("EDLIB_AMD_DEBUG") != nullptr;
     if (dbg) {
         EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
@@ -605,7 +608,7 @@ int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, i
     // 2 = the banded kernel at full height (325 ms).  Default: 0 for four symbols, 1 above.
     static const int pass2Kernel = getenv("EDLIB_AMD_PASS2") ? atoi(getenv("EDLIB_AMD_PASS2")) : 0;
     const bool longGroup = g.nwords > kMaxReadWords;                  // no plain kernel for 12 / 16 words
-    const bool fullHeight = banded_ && mode == EDLIB_MODE_HW && unbanded && (pass2Kernel == 1 || syms_ > 4 || longGroup) && pass2Kernel != 2;
+    const bool fullHeight = banded_ && mode == EDLIB_MODE_HW && unbanded && (chained || ((pass2Kernel == 1 || syms_ > 4 || longGroup) && pass2Kernel != 2));
     if (fullHeight) {
         EDLIB_AMD_HIP(launch_scan_reads_full(g.nwords, syms_, a, stream_));
         stats.word_steps += (long long)((nlanes + 63) / 64 * 64) * g.nwords *
@@ -1607,10 +1610,16 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
     score.assign(n, -1);
     if (n == 0) return 0;
     const bool bandOff = getenv("EDLIB_AMD_NWBAND") && getenv("EDLIB_AMD_NWBAND")[0] == '0';
-    // ring levels (lanes, blocks per lane): band limits 128, 384, 896, 1792, 3584, 3968; level nl = unbanded strips.  The
-    // 16-lane rings with 2 / 4 blocks per lane replace round 2's 21- and 32-lane rings here (four units per wave instead
-    // of three / two, the carry on a DPP row rotation, the per-lane glue of a step shared by 2 / 4 block updates)
-    static const int ringOf[kNumRings] = {4, 8, 16, 16, 16, 64}, ringH[kNumRings] = {1, 1, 1, 2, 4, 1};
+    // ring levels (lanes, blocks per lane); level nl = unbanded strips.  Rings whose lanes hold 2 / 4 blocks (16 x 2: four
+    // units per wave, DPP carry) were measured here in round 3 and lost: a ring computes ALL its rows every step, and
+    // 16 x 2 = 2048 rows for a band that needs ~1300 is 52 % more block updates than the 21-lane ring's 1344, which the
+    // cheaper step (105 against 119 SIMD cycles per block) does not pay back: config 4 24.7 ms of scans against 20.7.
+    // They serve the semi-global units of 17..64 blocks instead (solveSemiGlobalUnits), where the alternative is a strip
+    // that uses 17 of 64 lanes.  EDLIB_AMD_NWRINGS=tall selects them for experiments.
+    static const bool tall = getenv("EDLIB_AMD_NWRINGS") && !strcmp(getenv("EDLIB_AMD_NWRINGS"), "tall");
+    static const int ringOfA[kNumRings] = {4, 8, 16, 21, 32, 64}, ringHA[kNumRings] = {1, 1, 1, 1, 1, 1};
+    static const int ringOfB[kNumRings] = {4, 8, 16, 16, 16, 64}, ringHB[kNumRings] = {1, 1, 1, 2, 4, 1};
+    const int* ringOf = tall ? ringOfB : ringOfA; const int* ringH = tall ? ringHB : ringHA;
     auto cap_of = [&](int l) { return ring_max_k(ringOf[l], ringH[l]); };
     auto blocks_of = [&](int l) { return ringOf[l] * ringH[l]; };
     const int nl = kNumRings;                                           // ring levels; level nl = unbanded strips
@@ -1762,8 +1771,10 @@ int Batch::run()
         // column with every lane busy; longer queries take kernel W's strips.
         const int fullMax = syms_ == 4 ? 32 * kMaxLongReadWords4 : (syms_ == 8 ? 32 * kMaxLongReadWords : 0);
         std::vector<std::vector<int>> byWords(kMaxLongReadWords4 + 1);
+        std::vector<int> tall;
         for (int u : fb) {
             if (qlen(u) <= fullMax) byWords[read_group_words(qlen(u))].push_back(u);
+            else if (fullMax > 0) tall.push_back(u);
             else pairNow_.push_back(u);
         }
         for (int w = 1; w <= kMaxLongReadWords4; ++w) {
@@ -1772,6 +1783,13 @@ int Batch::run()
             if (makeGroup(byWords[w], w, g)) return 1;
             stats.path |= 1;
             if (runGroupScans(*g, true) || runGroupExact(*g) || collectGroup(*g, res)) return 1;
+        }
+        if (!tall.empty()) {                    // taller: strips of fullMax rows on the same kernel, chained through HBM
+            static const bool tallOn = !(getenv("EDLIB_AMD_TALL") && getenv("EDLIB_AMD_TALL")[0] == '0');
+            std::vector<int> back;
+            if (!tallOn) back = tall;
+            else if (solveTallFull(tall, res, back)) return 1;
+            pairNow_.insert(pairNow_.end(), back.begin(), back.end());
         }
         lap("run: handed back (full height)");
     }

@@ -176,6 +176,10 @@ private:
                    std::vector<uint8_t>* overflow, std::vector<int>* best);
     int solveLongReads(std::vector<UnitResult>& res, std::vector<int>& fallback);
     bool filterScan_ = false;
+    // strips of taller queries on the full-height lane kernel, chained through HBM (long_reads.hip: solveTallFull)
+    struct ChainArgs { const uint32_t* in = nullptr; uint32_t* out = nullptr; const int* src = nullptr; int inLanes = 0, blocks = 0; const int* rowBase = nullptr; };
+    ChainArgs chain_;
+    int solveTallFull(const std::vector<int>& units, std::vector<UnitResult>& res, std::vector<int>& handBack);
     int collectReads(std::vector<UnitResult>& res);   // D2H + result semantics (lazy for TASK_DISTANCE)
     bool readsCollected_ = true;
     int scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, int kcap, const int* d_kinit,

@@ -298,3 +298,123 @@ int Batch::solveLongReads(std::vector<UnitResult>& res, std::vector<int>& fallba
 }
 
 }  // namespace edlib_amd
+
+namespace edlib_amd {
+
+// Queries the piece filter handed back (mostly unrelated sequence: every row of every column is needed) that are taller
+// than the lane kernel's 32 words: cut into strips of `stripRows` rows, one launch of scan_reads_full_kernel per strip
+// level, the horizontal deltas of a strip's bottom row handed to the strip below through HBM (two bits per column).
+// Queries with the same number of strips share the target segmentation; the last strip of a query follows row m - 1
+// and records best / count / positions like any read.  Queries whose end-location list overflows go on to kernel W.
+int Batch::solveTallFull(const std::vector<int>& units, std::vector<UnitResult>& res, std::vector<int>& handBack)
+{
+    handBack.clear();
+    const int T = tlen(0);
+    const int kNoCap = 0x3fffffff;
+    const int stripWords = syms_ == 4 ? kMaxLongReadWords4 : kMaxLongReadWords, stripRows = 32 * stripWords;
+    std::vector<std::vector<int>> byStrips;                       // units by number of strips
+    for (int u : units) {
+        const size_t ns = (size_t)((qlen(u) + stripRows - 1) / stripRows);
+        if (byStrips.size() <= ns) byStrips.resize(ns + 1);
+        byStrips[ns].push_back(u);
+    }
+    for (size_t ns = 2; ns < byStrips.size(); ++ns) {
+        const std::vector<int>& set = byStrips[ns];
+        if (set.empty()) continue;
+        const int nl = (int)set.size();
+        int mmax = 0;
+        for (int u : set) mmax = std::max(mmax, qlen(u));
+        // one segmentation for every launch of the set: warm-up 2m - 1 of its tallest query, segments of at least 8 warm-ups
+        const int warm = 2 * mmax - 1;
+        const long long nrblk = (nl + 63) / 64;
+        long long S = (65536 + nrblk - 1) / nrblk;
+        S = std::max<long long>(1, std::min<long long>(S, std::min<long long>(std::min(65535, std::max(1, T / 4096)), std::max(1, T / (8 * warm)))));
+        // The strip levels of a set run one after the other, and a segment cannot be shorter than a few warm-ups (2m - 1
+        // columns each): a handful of very tall queries does not fill the chip this way (335 queries of 10 kb: 6 x 31
+        // waves).  Those stay on kernel W, which cuts the target of each unit on its own.
+        const char* mw = getenv("EDLIB_AMD_TALL_MIN_WAVES");          // (read per call: the tests lower it)
+        if (nrblk * S < (mw ? atoll(mw) : 2048)) { handBack.insert(handBack.end(), set.begin(), set.end()); continue; }
+        const int segLen = roundup((int)((T + S - 1) / S), 16);
+        const int numSegments = (T + segLen - 1) / segLen;
+        const int chainBlocks = (segLen + warm) / 16 + 3;
+        const size_t streamWords = (size_t)numSegments * chainBlocks * nl;
+        DevBuf<uint32_t> streamA, streamB;
+        EDLIB_AMD_HIP(streamA.alloc(streamWords));
+        if (ns > 2) EDLIB_AMD_HIP(streamB.alloc(streamWords));
+        // lane of a unit in the launches of the full strips: its index in the set
+        PinBuf srcPin; EDLIB_AMD_HIP(srcPin.alloc((size_t)nl * sizeof(int)));
+        DevBuf<int> d_src;
+        EDLIB_AMD_HIP(d_src.alloc(nl));
+        for (size_t level = 0; level < ns; ++level) {
+            const bool last = level + 1 == ns;
+            // pieces of this level, by word count (full strips: one group)
+            std::vector<std::vector<int>> byWords(kMaxLongReadWords4 + 1);
+            for (int i = 0; i < nl; ++i) {
+                const int rows = last ? qlen(set[i]) - (int)level * stripRows : stripRows;
+                byWords[read_group_words(rows)].push_back(i);
+            }
+            uint32_t* out = last ? nullptr : ((level & 1) ? streamB.p : streamA.p);
+            const uint32_t* in = level == 0 ? nullptr : (((level - 1) & 1) ? streamB.p : streamA.p);
+            for (int w = 1; w <= kMaxLongReadWords4; ++w) {
+                const std::vector<int>& who = byWords[w];
+                if (who.empty()) continue;
+                ReadGroup g;
+                g.nwords = w; g.nslots = roundup((int)who.size(), 64);
+                const size_t nsl = (size_t)g.nslots, nreal = who.size();
+                PinBuf pin;                                   // bounds (2 long long per slot) | perm | thr | rowBase | src
+                EDLIB_AMD_HIP(pin.alloc(nsl * (2 * sizeof(long long) + 4 * sizeof(int))));
+                long long* pb = reinterpret_cast<long long*>(pin.p);
+                int* perm = reinterpret_cast<int*>(pb + 2 * nsl); int* thr = perm + nsl; int* rowBase = thr + nsl; int* src = rowBase + nsl;
+                for (size_t sl = 0; sl < nsl; ++sl) {
+                    const bool real = sl < nreal;
+                    const int u = real ? set[who[sl]] : 0, m = real ? qlen(u) : 0;
+                    const int r0 = (int)level * stripRows, rows = real ? (last ? m - r0 : stripRows) : 0;
+                    pb[2 * sl] = real ? qoff_[u] + r0 : 0; pb[2 * sl + 1] = pb[2 * sl] + rows;
+                    perm[sl] = real ? (int)(2 * sl) : -1;
+                    thr[sl] = (real && last) ? ((cfg_.k < 0 || cfg_.k > m) ? m : cfg_.k) : -1;       // strips above the last follow no score
+                    rowBase[sl] = r0; src[sl] = real ? who[sl] : 0;
+                }
+                DevBuf<long long> d_pb; DevBuf<int> d_meta;      // d_meta: perm | thr | rowBase | src
+                EDLIB_AMD_HIP(d_pb.alloc(2 * nsl)); EDLIB_AMD_HIP(d_meta.alloc(4 * nsl));
+                EDLIB_AMD_HIP(hipMemcpyAsync(d_pb.p, pb, 2 * nsl * sizeof(long long), hipMemcpyHostToDevice, stream_));
+                EDLIB_AMD_HIP(hipMemcpyAsync(d_meta.p, perm, 4 * nsl * sizeof(int), hipMemcpyHostToDevice, stream_));
+                g.d_perm.alias(d_meta.p, nsl);
+                EDLIB_AMD_HIP(g.d_qlen.alloc(nsl)); EDLIB_AMD_HIP(g.d_kinit.alloc(nsl)); EDLIB_AMD_HIP(g.d_alphaExtra.alloc(nsl));
+                EDLIB_AMD_HIP(g.d_peq.alloc(nsl * (size_t)syms_ * w));
+                const size_t S2 = (size_t)numSegments;
+                EDLIB_AMD_HIP(g.d_segBest.alloc(nsl * S2)); EDLIB_AMD_HIP(g.d_segCnt.alloc(nsl * S2));
+                EDLIB_AMD_HIP(g.d_segPos.alloc(last ? nsl * S2 * 8 : 1));
+                EDLIB_AMD_HIP(launch_build_peq_reads(w, syms_, d_qpool_.p, d_pb.p, g.d_perm.p, g.nslots, d_eqtbl_.p, d_presence_.p,
+                                                     -1, g.d_peq.p, g.d_qlen.p, g.d_kinit.p, g.d_alphaExtra.p, stream_));
+                // a full strip's launch has the set's lanes in set order (who[sl] == sl): its stream is indexed by that lane
+                chain_ = ChainArgs{in, out, d_meta.p + 3 * nsl, nl, chainBlocks, d_meta.p + 2 * nsl};
+                const int rc = scanGroup(g, EDLIB_MODE_HW, nullptr, (int)nreal, kNoCap, d_meta.p + nsl, numSegments, segLen, warm,
+                                         g.d_segBest.p, g.d_segCnt.p, g.d_segPos.p, last ? 8 : 0, nullptr, nullptr, /*unbanded=*/true);
+                chain_ = ChainArgs{};
+                if (rc) return 1;
+                if (last) {
+                    DevBuf<int> d_best, d_total, d_pos, d_flags;
+                    EDLIB_AMD_HIP(d_best.alloc(nsl)); EDLIB_AMD_HIP(d_total.alloc(nsl)); EDLIB_AMD_HIP(d_pos.alloc(nsl * 16)); EDLIB_AMD_HIP(d_flags.alloc(nsl + 1));
+                    EDLIB_AMD_HIP(launch_merge_segments(g.d_segBest.p, g.d_segCnt.p, g.d_segPos.p, numSegments, 8, (int)nreal, nullptr, 16,
+                                                        d_best.p, d_total.p, d_pos.p, d_flags.p, stream_));
+                    PinBuf outPin; EDLIB_AMD_HIP(outPin.alloc(nsl * 19 * sizeof(int)));
+                    int* h = reinterpret_cast<int*>(outPin.p);
+                    EDLIB_AMD_HIP(hipMemcpyAsync(h, d_best.p, nreal * sizeof(int), hipMemcpyDeviceToHost, stream_));
+                    EDLIB_AMD_HIP(hipMemcpyAsync(h + nsl, d_total.p, nreal * sizeof(int), hipMemcpyDeviceToHost, stream_));
+                    EDLIB_AMD_HIP(hipMemcpyAsync(h + 2 * nsl, d_flags.p, nreal * sizeof(int), hipMemcpyDeviceToHost, stream_));
+                    EDLIB_AMD_HIP(hipMemcpyAsync(h + 3 * nsl, d_pos.p, nreal * 16 * sizeof(int), hipMemcpyDeviceToHost, stream_));
+                    EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+                    for (size_t sl = 0; sl < nreal; ++sl) {
+                        const int u = set[who[sl]];
+                        if (h[2 * nsl + sl]) { handBack.push_back(u); continue; }      // more end locations than a slot keeps
+                        finalize_semiglobal(res[u], cfg_.k, qlen(u), h[sl], h + 3 * nsl + sl * 16, h[sl] < 0 ? 0 : h[nsl + sl]);
+                    }
+                }
+                EDLIB_AMD_HIP(hipStreamSynchronize(stream_));            // the group's buffers die here
+            }
+        }
+    }
+    return 0;
+}
+
+}  // namespace edlib_amd

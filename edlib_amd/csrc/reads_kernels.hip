@@ -577,21 +577,33 @@ __device__ __forceinline__ void quad_one_word(u32 (&c)[4], u32& Pv, u32& Mv, con
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
 
-template <int NA, int NWD>
+// CHAIN (scan_reads_full_kernel of a strip of a taller query): the strip's row -1 is the bottom row of the strip above, whose
+// horizontal delta of this column arrives in the two low bits of `cin` (bit 0: +1, bit 1: -1; consumed), and the
+// delta of the strip's own bottom row (bit 31 of its last word) is shifted into `cout` from the top: after 16 columns
+// cout holds them in column order.  These are the hin / hout terms of calculateBlock (edlib.cpp:412-447) that the top
+// strip does without (HW row -1: hin = 0).
+template <int NA, int NWD, bool CHAIN = false>
 __device__ __forceinline__ void column_step_hw(const u32 (&Eq)[NA], u32 (&Pv)[NWD], u32 (&Mv)[NWD],
-                                               int& e, int& flag, const u32 sh)
+                                               int& e, int& flag, const u32 sh, u32& cin, u32& cout)
 {
     u32 Ph[NA], Mh[NA];
     u32 carry = 0;
+    u32 hpos = 0, hneg = 0;
+    if constexpr (CHAIN) { hpos = cin & 1u; hneg = (cin >> 1) & 1u; cin >>= 2; }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const u32 t = Eq[i] & Pv[i];
-        u32 cout;
-        const u32 s = __builtin_addc(t, Pv[i], carry, &cout);
-        carry = cout;
-        const u32 Xh = (s ^ Pv[i]) | Eq[i];
+        const u32 eq = (CHAIN && i == 0) ? (Eq[0] | hneg) : Eq[i];      // Eq |= hinIsNeg (:423)
+        const u32 t = eq & Pv[i];
+        u32 cout_;
+        const u32 s = __builtin_addc(t, Pv[i], carry, &cout_);
+        carry = cout_;
+        const u32 Xh = (s ^ Pv[i]) | eq;
         Ph[i] = Mv[i] | ~(Xh | Pv[i]);
         Mh[i] = Pv[i] & Xh;
+    }
+    if constexpr (CHAIN) {
+        const u32 x2 = (Ph[NA - 1] >> 31) | ((Mh[NA - 1] >> 30) & 2u);
+        cout = __builtin_amdgcn_alignbit(x2, cout, 2);                  // (x2 << 30) | (cout >> 2)
     }
     if (NA == NWD) {                                   // bottom row is in the band: follow its score
         if constexpr (NWD <= 8) {
@@ -619,6 +631,9 @@ __device__ __forceinline__ void column_step_hw(const u32 (&Eq)[NA], u32 (&Pv)[NW
         if (i > 0) {
             ph = __builtin_amdgcn_alignbit(Ph[i], Ph[i - 1], 31);
             mh = __builtin_amdgcn_alignbit(Mh[i], Mh[i - 1], 31);
+        } else if constexpr (CHAIN) {                   // << 1 with the delta of the row above shifted in (:435-441)
+            ph = (Ph[0] << 1) | hpos;
+            mh = (Mh[0] << 1) | hneg;
         } else {                                        // << 1 with a zero shifted in (HW row -1)
             asm("v_add_u32 %0, %1, %1" : "=v"(ph) : "v"(Ph[0]));
             asm("v_add_u32 %0, %1, %1" : "=v"(mh) : "v"(Mh[0]));
@@ -673,10 +688,11 @@ typedef u32 QuadRows[4];
 // S <= k + c; the one unit matters: against unrelated sequence the score 32 rows down hovers around 13, and with
 // k = 6 a wave meets S <= 10 at 0.5 % of its checkpoints but S <= 9 at 0.06 %.)  A new word enters as "+1 per row"
 // like the reference's new block (edlib.cpp:605-608).
-template <int NA, int NWD, int Q, int S, bool CHECK = true>
+template <int NA, int NWD, int Q, int S, bool CHECK = true, bool CHAIN = false>
 __device__ __forceinline__ int band_quad(const u32 lo, const u32 hi, const u32 nlo, const u32 nhi, QuadRows& qr,
                                          const int colBase, const int colEnd, const bool track, u32 (&Pv)[NWD],
-                                         u32 (&Mv)[NWD], int& e, int& flag, HwTrack& tr, const u32 sh, const int lastRows)
+                                         u32 (&Mv)[NWD], int& e, int& flag, HwTrack& tr, const u32 sh, const int lastRows,
+                                         u32& cin, u32& cout)
 {
     int eh[4];
     if constexpr (NA == 1 && NWD > 1) {
@@ -696,7 +712,7 @@ __device__ __forceinline__ int band_quad(const u32 lo, const u32 hi, const u32 n
             if (j == 1) lds_rows_request<NA, 2, S>(nx, lo, hi);
             if (j == 2) lds_rows_request<NA, 3, S>(nx, lo, hi);
             if constexpr (NA == 2 && NWD > 2) column_step_eq2<NWD>(eq[0], eq[1], Pv, Mv);   // bottom row outside: nothing tracked
-            else column_step_hw<NA, NWD>(eq, Pv, Mv, e, flag, sh);
+            else column_step_hw<NA, NWD, CHAIN>(eq, Pv, Mv, e, flag, sh, cin, cout);
             eh[j] = e;
         }
     }
@@ -859,6 +875,7 @@ scan_reads_banded_kernel(const ReadScanArgs a)
     typedef const u32x8 __attribute__((address_space(4))) * TargetBlocks;
     const TargetBlocks tx = (TargetBlocks)(unsigned long long)a.trows;
     int nw = NWD;
+    u32 noChain = 0;                                                  // (the chain of strips is scan_reads_full_kernel's)
     unsigned int bandWork = 0;                                        // sum of nw over the quads (wave-uniform)
     // One inner loop per band height: a quad that leaves the height unchanged falls into the next quad of the same
     // code with every live value where it was.  The 16 columns of a block are four unrolled quads of straight-line
@@ -874,7 +891,7 @@ scan_reads_banded_kernel(const ReadScanArgs a)
             nw = band_quad<(NA <= NWD ? NA : NWD), NWD, Q, S>(cur[2 * Q], cur[2 * Q + 1],                          \
                      Q < 3 ? cur[(2 * Q + 2) & 7] : nxt[0], Q < 3 ? cur[(2 * Q + 3) & 7] : nxt[1], qr,          \
                      b * 16 + Q * 4, c1, b >= bmain /* warm-up columns record nothing */, Pv, Mv, e, flag, tr,  \
-                     sh, lastRows);
+                     sh, lastRows, noChain, noChain);
 #define ADVANCE { q = 0; ++b; cur = nxt; nxt = tx[b + 1]; }
 #define CASE(NA) case NA:                                                                                       \
             if constexpr (band_height_ok<NWD>(NA)) {                                                            \
@@ -919,7 +936,13 @@ scan_reads_banded_kernel(const ReadScanArgs a)
 // k-doubling run on when a sample shows that their band is the whole query (unrelated reads).  Against
 // scan_reads_kernel (register-resident rows, a scalar 4-way branch per column) it has no symbol dispatch and takes 4, 8 or
 // 16 symbols; against scan_reads_banded_kernel at full height it has no checkpoints and a third of the code.
-template <int NWD, int S>
+// CHAIN: the lane is one STRIP of a taller query (rows [1024 s, 1024 s + 32 NWD) of it): the horizontal deltas of the strip
+// above come in through a.chainIn (one dword per 16 columns: two bits per column), those of the strip's own bottom row go
+// out through a.chainOut, both laid out [segment][block of 16 columns][lane of the producing launch].  A query of any
+// length then runs at this kernel's cost per row (10 VALU ops per 32 rows and column, every lane busy) as a sequence of
+// launches, one per strip level, where kernel W spends ~40 instructions per 64-row block in a wave whose lanes are only
+// as busy as the query is tall.  Strips above the last one follow no score (their threshold is -1: nothing qualifies).
+template <int NWD, int S, bool CHAIN = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((S == 4 && NWD <= 5) ? 7 : 1, 8)))
 scan_reads_full_kernel(const ReadScanArgs a)
 {
@@ -953,6 +976,7 @@ scan_reads_full_kernel(const ReadScanArgs a)
         tr.pos = a.segPos + (!live ? 0 : (a.posOff ? a.posOff[item] : item * a.cap));
     }
     int e = m - tr.best - 1, flag = 0;
+    if constexpr (CHAIN) if (a.rowBase) e += a.rowBase[slot];        // column -1: D[i][-1] = i + 1 counts the rows of the strips above
     const int T = a.targetLength;
     const int c0 = blockIdx.y * a.segLen;
     int c1 = c0 + a.segLen; if (c1 > T) c1 = T;
@@ -962,12 +986,22 @@ scan_reads_full_kernel(const ReadScanArgs a)
     const TargetBlocks tx = (TargetBlocks)(unsigned long long)a.trows;
     u32x8 cur = tx[b0];
     QuadRows qr;
+    // chain streams of this (lane, segment): dword (segment * chainBlocks + block - b0) * lanes + lane
+    const u32* cinP = nullptr; u32* coutP = nullptr;
+    if constexpr (CHAIN) {
+        const long long sb = (long long)blockIdx.y * a.chainBlocks;
+        if (a.chainIn && live) cinP = a.chainIn + sb * a.chainInLanes + a.chainSrc[idx];
+        if (a.chainOut && live) coutP = a.chainOut + sb * a.nlanes + idx;
+    }
+    u32 cin = 0, cout = 0;
     for (int b = b0; b < bend; ++b) {
         const u32x8 nxt = tx[b + 1];
-#define QUADF(Q) (void)band_quad<NWD, NWD, Q, S, false>(cur[2 * Q], cur[2 * Q + 1], 0u, 0u, qr, b * 16 + Q * 4, c1, b >= bmain, \
-                                                       Pv, Mv, e, flag, tr, sh, lastRows);
+        if constexpr (CHAIN) cin = cinP ? cinP[(long long)(b - b0) * a.chainInLanes] : 0u;
+#define QUADF(Q) (void)band_quad<NWD, NWD, Q, S, false, CHAIN>(cur[2 * Q], cur[2 * Q + 1], 0u, 0u, qr, b * 16 + Q * 4, c1, b >= bmain, \
+                                                              Pv, Mv, e, flag, tr, sh, lastRows, cin, cout);
         QUADF(0) QUADF(1) QUADF(2) QUADF(3)
 #undef QUADF
+        if constexpr (CHAIN) if (coutP) coutP[(long long)(b - b0) * a.nlanes] = cout;
         cur = nxt;
     }
     if (live) {
@@ -977,17 +1011,17 @@ scan_reads_full_kernel(const ReadScanArgs a)
     }
 }
 
-template <int S>
+template <int S, bool CHAIN>
 static hipError_t launch_scan_reads_full_s(int nwords, const ReadScanArgs& a, hipStream_t stream)
 {
     dim3 grid((a.nlanes + 63) / 64, a.numSegments), block(64);
     switch (nwords) {
-#define CASE(N) case N: hipLaunchKernelGGL((scan_reads_full_kernel<N, S>), grid, block, 0, stream, a); break;
+#define CASE(N) case N: hipLaunchKernelGGL((scan_reads_full_kernel<N, S, CHAIN>), grid, block, 0, stream, a); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
-        case 12: if constexpr (S <= 8) { hipLaunchKernelGGL((scan_reads_full_kernel<12, S>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
-        case 16: if constexpr (S <= 8) { hipLaunchKernelGGL((scan_reads_full_kernel<16, S>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
-        case 24: if constexpr (S == 4) { hipLaunchKernelGGL((scan_reads_full_kernel<24, S>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
-        case 32: if constexpr (S == 4) { hipLaunchKernelGGL((scan_reads_full_kernel<32, S>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
+        case 12: if constexpr (S <= 8) { hipLaunchKernelGGL((scan_reads_full_kernel<12, S, CHAIN>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
+        case 16: if constexpr (S <= 8) { hipLaunchKernelGGL((scan_reads_full_kernel<16, S, CHAIN>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
+        case 24: if constexpr (S == 4) { hipLaunchKernelGGL((scan_reads_full_kernel<24, S, CHAIN>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
+        case 32: if constexpr (S == 4) { hipLaunchKernelGGL((scan_reads_full_kernel<32, S, CHAIN>), grid, block, 0, stream, a); break; } else return hipErrorInvalidValue;
 #undef CASE
         default: return hipErrorInvalidValue;
     }
@@ -997,10 +1031,11 @@ static hipError_t launch_scan_reads_full_s(int nwords, const ReadScanArgs& a, hi
 hipError_t launch_scan_reads_full(int nwords, int syms, const ReadScanArgs& a, hipStream_t stream)
 {
     if (a.nlanes == 0) return hipSuccess;
+    const bool chain = a.chainIn != nullptr || a.chainOut != nullptr;
     switch (syms) {
-        case 4: return launch_scan_reads_full_s<4>(nwords, a, stream);
-        case 8: return launch_scan_reads_full_s<8>(nwords, a, stream);
-        case 16: return launch_scan_reads_full_s<16>(nwords, a, stream);
+        case 4: return chain ? launch_scan_reads_full_s<4, true>(nwords, a, stream) : launch_scan_reads_full_s<4, false>(nwords, a, stream);
+        case 8: return chain ? launch_scan_reads_full_s<8, true>(nwords, a, stream) : launch_scan_reads_full_s<8, false>(nwords, a, stream);
+        case 16: return chain ? launch_scan_reads_full_s<16, true>(nwords, a, stream) : launch_scan_reads_full_s<16, false>(nwords, a, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -37,6 +37,14 @@ struct ReadScanArgs {
     const int* posCap;        // optional [lanes][numSegments] capacity (exact pass)
     int kcap;                 // banded HW kernel: effective threshold = min(kinit[slot], kcap)
     unsigned long long* wordSteps;   // banded HW kernel: += 32-row word-columns actually computed (may be null)
+    // scan_reads_full_kernel, strips of a taller query (null: a whole query per lane).  One dword per 16 columns and lane, two
+    // bits per column (bit 0: +1, bit 1: -1): the horizontal deltas of the bottom row of the strip above (in) / of this strip
+    // (out), laid out [segment][block of 16 columns][lane of the producing launch]
+    const uint32_t* chainIn; uint32_t* chainOut;
+    const int* chainSrc;      // [lanes] lane of the producing launch that holds the strip above
+    int chainInLanes;         // nlanes of the producing launch
+    int chainBlocks;          // blocks of 16 columns per segment in the streams (>= (segLen + warm) / 16 + 2)
+    const int* rowBase;       // [slots] query rows above the strip (its bottom row starts at score rowBase + qlen); null: 0
     int filter;               // banded HW kernel: 1 = fixed threshold, segPos lists the 16-column BLOCKS that hold a column
                               // scoring <= kinit (each once), segCnt their number (piece filter of long reads)
 };

@@ -283,3 +283,27 @@ def test_round2_word_groups_still_agree():
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, EDLIB_AMD_FILTER="0"))
     assert p.returncode == 0 and "ok" in p.stdout, p.stdout[-800:] + p.stderr[-2000:]
+
+
+def test_tall_unrelated_queries_on_chained_strips(engine):
+    """queries the filter hands back that are taller than the lane kernel's 32 words run as strips of 1024 rows chained
+    through HBM (long_reads.hip: solveTallFull); EDLIB_AMD_TALL_MIN_WAVES=1 lets a small batch take that path.  Unrelated
+    queries, low complexity, exact multiples of the strip height, one row more / less, related ones mixed in."""
+    os.environ["EDLIB_AMD_TALL_MIN_WAVES"] = "1"
+    try:
+        target = synth.random_dna(121, 70_000)
+        rng = np.random.default_rng(122)
+        lengths = [1025, 1026, 1055, 1056, 1057, 2047, 2048, 2049, 2050, 3071, 3072, 3073, 3100, 4096, 4097, 5000] * 2
+        reads = [_ACGT[rng.integers(0, 4, m)] for m in lengths]                        # unrelated: distance ~0.45 m
+        reads += _reads(target, [1500, 2048, 2500, 4100], 123, max_err=0.45)           # too divergent for the filter
+        reads += _reads(target, [1100, 2300], 124, max_err=0.05)                       # resolved by the filter
+        reads.append(np.tile(np.frombuffer(b"ACGGT", dtype=np.uint8), 300))            # low complexity
+        for task in ("distance", "locations"):
+            _check(engine, reads, target, task)
+        _check(engine, reads[:12], target, "distance", k=700)
+        # five target symbols: strips of 16 words
+        t5 = synth.masked_genome(125, 40_000, frac_lower=0.0)
+        r5 = [_ACGT[rng.integers(0, 4, m)] for m in (513, 1024, 1025, 1600)]
+        _check(engine, r5, t5, "distance")
+    finally:
+        os.environ.pop("EDLIB_AMD_TALL_MIN_WAVES", None)
