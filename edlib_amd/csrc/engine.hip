@@ -486,12 +486,14 @@ int Batch::makeGroup(const std::vector<int>& units, int w, std::unique_ptr<ReadG
         // enough waves to fill 256 CUs x 4 SIMDs x 8 slots many times over, segments >= 4096 columns
         // ~16 waves per resident slot: the launch ends on a thin tail (65,536 -> 131,072 waves: +1 % at 1M reads)
         static const long long wantWaves = getenv("EDLIB_AMD_WAVES") ? atoll(getenv("EDLIB_AMD_WAVES")) : 131072;
+        g->warm = 2 * 32 * w - 1;                        // 2m-1 columns (SURVEY.md §7)
         long long S = (wantWaves + nrblk - 1) / nrblk;
-        const long long maxS = std::min(65535, std::max(1, T / 4096));     // gridDim.y limit
+        // gridDim.y limit; segments of at least 4096 columns and four warm-ups (the groups of 24 / 32 words warm up
+        // over 1535 / 2047 columns: 4096-column segments were half warm-up)
+        const long long maxS = std::max<long long>(1, std::min<long long>(std::min(65535, std::max(1, T / 4096)), T / (4LL * g->warm)));
         S = std::max(1LL, std::min(S, maxS));
         g->segLen = roundup((int)((T + S - 1) / S), 16);
         g->numSegments = (T + g->segLen - 1) / g->segLen;
-        g->warm = 2 * 32 * w - 1;                        // 2m-1 columns (SURVEY.md §7)
     } else {
         g->numSegments = 1; g->segLen = roundup(T, 16); g->warm = 0;
     }
@@ -636,6 +638,7 @@ void plan_segments(int nlanes, int T, int mode, int warmFull, long long wantWave
     const long long nrblk = ((long long)nlanes + 63) / 64;
     long long want = (wantWaves + nrblk - 1) / nrblk;
     want = std::max(1LL, std::min<long long>(want, std::min(65535, std::max(1, T / 4096))));   // gridDim.y limit
+    if (warmFull > 0) want = std::max(1LL, std::min<long long>(want, std::max<long long>(1, T / (4LL * warmFull))));   // >= four warm-ups per segment
     segLen = roundup((int)((T + want - 1) / want), 16);
     S = (T + segLen - 1) / segLen;
     warm = warmFull;
@@ -1604,10 +1607,11 @@ int Batch::solveSemiGlobalUnits(int mode, bool wantPositions, const std::vector<
 // all fit a ring is exact on it for any distance (threshold max(m, T)).  A failed level is pure waste when the whole
 // batch is divergent, so larger batches first measure the divergence of 64 strided units on their 1 kb prefixes
 // (one small launch) and every unit starts at the level that holds its extrapolated distance.  The estimate only picks the starting level; results never depend on it.
-int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<int>& score)
+int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<int>& score, std::vector<OpsOut>* paths)
 {
     const size_t n = units.size();
     score.assign(n, -1);
+    if (paths) { paths->clear(); paths->resize(n); }
     if (n == 0) return 0;
     const bool bandOff = getenv("EDLIB_AMD_NWBAND") && getenv("EDLIB_AMD_NWBAND")[0] == '0';
     // ring levels (lanes, blocks per lane); level nl = unbanded strips.  Rings whose lanes hold 2 / 4 blocks (16 x 2: four
@@ -1695,9 +1699,12 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
         }
         if (sel.empty()) continue;
         SolveOut& so = soLevel_;
-        if (solve(EDLIB_MODE_NW, false, false, sel, so, l < nl ? ringOf[l] : 0, l < nl ? ringH[l] : 1)) return 1;
+        const bool store = paths != nullptr && (l == nl || ringH[l] == 1);
+        if (solve(EDLIB_MODE_NW, false, store, sel, so, l < nl ? ringOf[l] : 0, l < nl ? ringH[l] : 1)) return 1;
+        if (store) opsKeep_.insert(opsKeep_.end(), so.opsBufs.begin(), so.opsBufs.end());
         for (size_t q = 0; q < sel.size(); ++q) {
             const size_t i = who[q];
+            if (store && (l == nl || so.score[q] <= sel[q].kinit)) { (*paths)[i].p = so.opsPtr[q]; (*paths)[i].len = so.opsLen[q]; }
             if (l == nl || so.score[q] <= sel[q].kinit) score[i] = so.score[q];         // exact
             else if (sel[q].kinit >= kcap) score[i] = kInf;                              // > k: final
             else { lvl[i] = l + 1; ++atLevel[l + 1]; }                                   // next level
@@ -1812,9 +1819,22 @@ int Batch::run()
         SolveOut& so = soMain_;
         if (scanMode == EDLIB_MODE_NW) {
             std::vector<int>& score = scoreMain_;
-            if (solveGlobalDistances(units, score)) return 1;
+            // TASK_PATH over pairs that all stay below the 1 MiB rule (edlib.cpp:1188-1190): the reference scans twice
+            // (distance, then the storing scan with k = distance, :1196-1199); here a unit's first successful level
+            // stores its columns and is traced back right away -- any threshold >= the distance gives the same walk
+            // (every neighbour that could be "one less than here" is <= the distance, hence exact inside the band)
+            static const bool fuseOn = !(getenv("EDLIB_AMD_FUSEPATH") && getenv("EDLIB_AMD_FUSEPATH")[0] == '0');
+            bool fuse = fuseOn && cfg_.task == EDLIB_TASK_PATH && mode == EDLIB_MODE_NW;
+            for (size_t i = 0; fuse && i < units.size(); ++i) fuse = !needs_hirschberg(units[i].qlen, units[i].tlen);
+            fusedOps_.clear();
+            if (solveGlobalDistances(units, score, fuse ? &fusedOps_ : nullptr)) return 1;
             for (size_t i = 0; i < units.size(); ++i)
                 finalize_global(res[pairUnits_[i]], cfg_.k, mode, units[i].tlen, score[i]);
+            if (fuse)
+                for (size_t i = 0; i < units.size(); ++i) {
+                    UnitResult& r = res[pairUnits_[i]];
+                    if (r.editDistance >= 0 && fusedOps_[i].p) { r.opsView = fusedOps_[i].p; r.opsViewLen = fusedOps_[i].len; r.hasAlignment = true; }
+                }
         } else {
             if (solveSemiGlobal(scanMode, true, units, so)) return 1;
             for (size_t i = 0; i < units.size(); ++i)
@@ -1870,7 +1890,7 @@ int Batch::run()
         jobs.reserve(live.size()); where.reserve(live.size());
         for (int u : live) {
             UnitResult& r = res[u];
-            if (r.ends.empty()) continue;
+            if (r.ends.empty() || r.hasAlignment) continue;         // (hasAlignment: traced back in phase 1)
             const int m = qlen(u);
             const int s = r.starts[0], e = r.ends[0];
             const int len = e - s + 1;

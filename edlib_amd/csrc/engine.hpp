@@ -205,7 +205,9 @@ private:
                    size_t a, size_t b, SolveOut& out, int ring, int ringH);
     // NW distances by threshold levels on rings of 4, 16, 64 lanes, then unbanded (the reference's
     // k-doubling, edlib.cpp:197-217, with thresholds chosen for the hardware)
-    int solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<int>& score);
+    // paths != null (TASK_PATH, every unit below the 1 MiB rule): the levels run with the column store and the traceback, so
+    // that a unit's first successful level is also its path (one scan instead of the distance scan + the storing scan)
+    int solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<int>& score, std::vector<OpsOut>* paths = nullptr);
     // SHW / HW units: short queries packed on 4- and 16-lane rings, the rest on the strips
     int solveSemiGlobal(int mode, bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out);
     int solveSemiGlobalUnits(int mode, bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out);
@@ -240,6 +242,7 @@ private:
     // per-unit scratch of the pair path, kept across runs (fresh multi-megabyte vectors are mmap + page faults + munmap)
     std::vector<UnitSpec> pairSpecs_, selScratch_; std::vector<size_t> whoScratch_; std::vector<int> lvlScratch_, scoreMain_;
     SolveOut soMain_, soLevel_;
+    std::vector<OpsOut> fusedOps_;
 };
 
 // single-pair convenience used by edlibAlign()

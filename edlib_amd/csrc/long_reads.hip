@@ -327,13 +327,15 @@ int Batch::solveTallFull(const std::vector<int>& units, std::vector<UnitResult>&
         // one segmentation for every launch of the set: warm-up 2m - 1 of its tallest query, segments of at least 8 warm-ups
         const int warm = 2 * mmax - 1;
         const long long nrblk = (nl + 63) / 64;
-        long long S = (65536 + nrblk - 1) / nrblk;
-        S = std::max<long long>(1, std::min<long long>(S, std::min<long long>(std::min(65535, std::max(1, T / 4096)), std::max(1, T / (8 * warm)))));
+        // as many segments as it takes to fill the chip (a wave of this kernel holds 32 KB of LDS rows: ~1280 resident
+        // waves), none shorter than four warm-ups
+        const long long maxS = std::max<long long>(1, std::min<long long>(std::min(65535, std::max(1, T / 4096)), T / (4LL * warm)));
+        const long long S = std::max<long long>(1, std::min<long long>((2048 + nrblk - 1) / nrblk, maxS));
         // The strip levels of a set run one after the other, and a segment cannot be shorter than a few warm-ups (2m - 1
-        // columns each): a handful of very tall queries does not fill the chip this way (335 queries of 10 kb: 6 x 31
+        // columns each): a handful of very tall queries does not fill the chip this way (335 queries of 10 kb: 6 x 62
         // waves).  Those stay on kernel W, which cuts the target of each unit on its own.
         const char* mw = getenv("EDLIB_AMD_TALL_MIN_WAVES");          // (read per call: the tests lower it)
-        if (nrblk * S < (mw ? atoll(mw) : 2048)) { handBack.insert(handBack.end(), set.begin(), set.end()); continue; }
+        if (nrblk * S < (mw ? atoll(mw) : 768)) { handBack.insert(handBack.end(), set.begin(), set.end()); continue; }
         const int segLen = roundup((int)((T + S - 1) / S), 16);
         const int numSegments = (T + segLen - 1) / segLen;
         const int chainBlocks = (segLen + warm) / 16 + 3;
