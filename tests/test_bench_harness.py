@@ -107,3 +107,21 @@ def test_config_lines_carry_full_parity(cfg, units):
     if cfg == 2:
         assert all(v is True for k, v in out["invariants"].items() if k != "planted_position_reads_checked")
         assert out["e2e"]["distances_equal_resident"] is True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strong", [False, True])
+def test_eight_ranks_dry_run_on_one_device(strong):
+    """the driver's 8-GPU launch shape on a 1-GPU box: eight ranks (torch.distributed.run, gloo, all on device 0), weak
+    and strong scaling; every rank reports, host pools are sized from the CPU quota divided by the world size, and the
+    run finishes well inside two minutes"""
+    import time
+    args = ["--reads", "64000" if strong else "8000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e",
+            "--gpus", "8", "--share-gpu"] + (["--strong"] if strong else [])
+    t0 = time.time()
+    out = _line(_run(args, timeout=300))
+    wall = time.time() - t0
+    assert out["n_gpus"] == 8 and out["dry_run_shared_gpu"] and len(out["per_rank_ms_per_step"]) == 8
+    assert out["scaling"] == ("strong" if strong else "weak") and out["devices_distinct"] == 1
+    assert out["config"]["units_per_gpu"] == 8000
+    assert wall < 120, wall
