@@ -759,21 +759,25 @@ hipError_t launch_hirschberg_split(const SplitArgs& a, hipStream_t stream)
 // with one WAVE per unit and the walk's window of the store kept on chip were both slower at config 5's shape
 // (10,000 x 1 kb: 0.89 ms here): window in LDS 1.31 ms (three LDS round trips per step), window in registers with
 // the whole walk in the scalar unit 1.66 ms (39 waves per CU share one scalar ALU).
+// Ring layout: the walk is a pointer chase through a store that lives in HBM (128 KB per 1 kb pair at config 5), and with one
+// walk per lane a wave waits for memory whenever ANY of its 64 lanes does.  So the lanes fetch together: every lane loads the
+// window of the store its walk can reach next -- eight columns to the left of where it stands, its block and (near the
+// block's top) the block above: up to 32 independent loads in flight per lane -- into its private slice of LDS, then all
+// lanes walk inside their windows until they leave them, and the wave pays one memory latency per window (~8 columns)
+// instead of one per step.  (Round 2: one dependent 32-byte load per step, 0.88 ms at config 5's shape; a per-lane
+// line cache that missed lane by lane stalled the wave at every step just the same: 1.37 ms.)
+constexpr int kWinCols = 8;
 __global__ void __launch_bounds__(64)
 traceback_kernel(const TracebackArgs a)
 {
-    // Ring layout: four consecutive columns of a block are one 128-byte line of the store.  Each lane keeps the line it
-    // last touched in LDS ([lane][column of the line]: 20 useful bytes per entry) and fetches a line with eight independent
-    // loads in flight at once: the walk, which moves one column to the left per step, waits for memory once per four
-    // columns instead of once per column (round 2: one dependent 32-byte load per step, 0.88 ms at config 5's shape).
-    __shared__ u32 s_line[64][4][5];                 // p (2 dwords), m (2 dwords), s
+    __shared__ u32 s_win[64][2][kWinCols][5];        // [lane][block: 0 = the walk's block, 1 = the one above][column][p lo, p hi, m lo, m hi, s]
     const int unit = blockIdx.x * blockDim.x + threadIdx.x;
-    if (unit >= a.numUnits) return;
-    const PairDesc d = a.descs[unit];
+    const bool have = unit < a.numUnits;
+    const PairDesc d = a.descs[have ? unit : 0];
     const int m = d.qlen, T = d.tlen, nb = num_blocks(m);
-    uint8_t* ops = a.ops + a.opsOff[unit];
+    uint8_t* ops = a.ops + a.opsOff[have ? unit : 0];
     int w = m + T;                                  // next write index is --w
-    int r = m - 1, c = T - 1, cur = a.score[unit];
+    int r = m - 1, c = T - 1, cur = have ? a.score[unit] : 0;
     const StoreEntry* S = a.store + d.storeOff;
     // ring layout (scan_pairs_ring_kernel): only the blocks inside the band of threshold kinit exist.
     // The walk stays on cells of optimal paths, which are inside the band and exact; a neighbour outside
@@ -786,74 +790,91 @@ traceback_kernel(const TracebackArgs a)
         dmin = (D < 0 ? D : 0) - p;
     }
     const int kInf = 0x3fffffff;
-    // a unit whose scan ended above its threshold has no exact cells to walk on (it is rescanned at the next level)
-    if (G && cur > d.kinit) { a.opsLen[unit] = 0; return; }
-    u32 (&line)[4][5] = s_line[threadIdx.x];
-    int tagRow = -1, tagLine = -1;                   // ring row (block % G) and column / 4 of the cached line
     struct Ent { u64 p, m; int s; };
+    // a unit whose scan ended above its threshold has no exact cells to walk on (it is rescanned at the next level)
+    const bool skip = !have || (G && cur > d.kinit);
+    if (have && skip) a.opsLen[unit] = 0;
+    bool done = skip;
+    u32 (&win)[2][kWinCols][5] = s_win[threadIdx.x];
+    int wb = -1, wc0 = 0, wc1 = -1; bool wup = false;     // the window: block wb (and wb - 1 if wup), columns wc0 .. wc1
+    auto in_window = [&](int col, int blk) { return col >= wc0 && col <= wc1 && (blk == wb || (wup && blk == wb - 1)); };
     auto entry = [&](int col, int blk) -> Ent {
         if (!G) { const StoreEntry e = S[store_index(T, nb, col, blk)]; return Ent{e.p, e.m, e.s}; }
-        const int row = blk % G, ln = col >> 2;
-        if (row != tagRow || ln != tagLine) {
-            const StoreEntry* base = S + (long long)row * T + 4 * ln;
-            uint4 pm[4]; int sc[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {            // all loads first: one memory latency for the line
-                const bool in = 4 * ln + q < T;
-                pm[q] = in ? *reinterpret_cast<const uint4*>(&base[q].p) : uint4{0, 0, 0, 0};
-                sc[q] = in ? base[q].s : 0;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { line[q][0] = pm[q].x; line[q][1] = pm[q].y; line[q][2] = pm[q].z; line[q][3] = pm[q].w; line[q][4] = (u32)sc[q]; }
-            tagRow = row; tagLine = ln;
-        }
-        const u32 (&e)[5] = line[col & 3];
+        const u32 (&e)[5] = win[blk == wb ? 0 : 1][col - wc0];
         return Ent{((u64)e[1] << 32) | e[0], ((u64)e[3] << 32) | e[2], (int)e[4]};
     };
     // the walk keeps the block of the current column and of the column to its left in registers: a step
     // to the left or along the diagonal inside a block shifts them and fetches one new entry
     int hb = -1, hc = -2;                            // block / column the registers describe (hc = current column)
     u64 Pc = 0, Mc = 0, Pl = 0, Ml = 0; int Sl = 0; bool leftIn = false;
-    for (;;) {
-        const int b = r >> 6, bit = r & 63;
-        if (b != hb || c != hc) {
-            if (b == hb && c == hc - 1 && leftIn) { Pc = Pl; Mc = Ml; }
-            else { const Ent e = entry(c, b); Pc = e.p; Mc = e.m; }
-            leftIn = c > 0 && (!G || c - 1 >= 64 * b + dmin);          // block b exists in column c-1
-            if (leftIn) { const Ent e = entry(c - 1, b); Pl = e.p; Ml = e.m; Sl = e.s; }
-            hb = b; hc = c;
+    while (__builtin_amdgcn_ballot_w64(!done) != 0ull) {
+        if (G && !done) {                            // ---- fetch the window anchored where the walk stands
+            wb = r >> 6; wc1 = c; wc0 = c - (kWinCols - 1) < 0 ? 0 : c - (kWinCols - 1);
+            wup = wb > 0 && (r & 63) < kWinCols;     // a step moves up one row at most: the block above matters near the top
+            uint4 pm[2][kWinCols]; int sc[2][kWinCols];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const StoreEntry* row = S + (long long)((wb - q + G) % G) * T + wc0;
+#pragma unroll
+                for (int i = 0; i < kWinCols; ++i) {
+                    const bool in = wc0 + i <= wc1 && (q == 0 || wup);
+                    pm[q][i] = in ? *reinterpret_cast<const uint4*>(&row[i].p) : uint4{0, 0, 0, 0};
+                    sc[q][i] = in ? row[i].s : 0;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < kWinCols; ++i) {
+                    win[q][i][0] = pm[q][i].x; win[q][i][1] = pm[q][i].y; win[q][i][2] = pm[q][i].z; win[q][i][3] = pm[q][i].w; win[q][i][4] = (u32)sc[q][i];
+                }
+            hb = -1; hc = -2;                        // registers are reloaded from the new window
         }
-        const int u = cur - ((int)((Pc >> bit) & 1ull) - (int)((Mc >> bit) & 1ull));
-        int l, ul;
-        if (c == 0) { l = r + 1; ul = r; }          // column -1 boundary (:976-980)
-        else if (leftIn) {
-            const u64 above = (bit == 63) ? 0ull : (~0ull << (bit + 1));   // rows below r in the block
-            l = Sl - __popcll(Pl & above) + __popcll(Ml & above);
-            ul = l - ((int)((Pl >> bit) & 1ull) - (int)((Ml >> bit) & 1ull));
-        } else {                                     // left edge of the band: only the diagonal neighbour may
-            l = kInf;                                // exist, as the bottom cell of the block above
-            ul = (bit == 0 && b > 0) ? (G ? S[ring_index(G, T, c - 1, b - 1)].s : S[store_index(T, nb, c - 1, b - 1)].s) : kInf;
-        }
-        if (u + 1 == cur) {                          // up: INSERT
-            cur = u;
-            ops[--w] = 1;
-            if (r == 0) { for (int i = 0; i < c + 1; ++i) ops[--w] = 2; break; }
-            --r;
-        } else if (l + 1 == cur) {                   // left: DELETE
-            cur = l;
-            ops[--w] = 2;
-            --c;
-            if (c == -1) { for (int i = 0; i < r + 1; ++i) ops[--w] = 1; break; }
-        } else {                                     // diagonal: MATCH / MISMATCH
-            ops[--w] = (ul == cur) ? 0 : 3;
-            cur = ul;
-            --c;
-            if (c == -1) { for (int i = 0; i < r; ++i) ops[--w] = 1; break; }
-            if (r == 0) { for (int i = 0; i < c + 1; ++i) ops[--w] = 2; break; }
-            --r;
+        // ---- walk while everything a step needs is inside the window
+        while (!done) {
+            const int b = r >> 6, bit = r & 63;
+            const bool leftHere = c > 0 && (!G || c - 1 >= 64 * b + dmin);          // block b exists in column c-1
+            const bool cornerAbove = c > 0 && !leftHere && bit == 0 && b > 0;       // left edge of the band: the diagonal neighbour is above
+            if (G && !(in_window(c, b) && (!leftHere || in_window(c - 1, b)) && (!cornerAbove || in_window(c - 1, b - 1)))) break;
+            if (b != hb || c != hc) {
+                if (b == hb && c == hc - 1 && leftIn) { Pc = Pl; Mc = Ml; }
+                else { const Ent e = entry(c, b); Pc = e.p; Mc = e.m; }
+                leftIn = leftHere;
+                if (leftIn) { const Ent e = entry(c - 1, b); Pl = e.p; Ml = e.m; Sl = e.s; }
+                hb = b; hc = c;
+            }
+            const int u = cur - ((int)((Pc >> bit) & 1ull) - (int)((Mc >> bit) & 1ull));
+            int l, ul;
+            if (c == 0) { l = r + 1; ul = r; }          // column -1 boundary (:976-980)
+            else if (leftIn) {
+                const u64 above = (bit == 63) ? 0ull : (~0ull << (bit + 1));   // rows below r in the block
+                l = Sl - __popcll(Pl & above) + __popcll(Ml & above);
+                ul = l - ((int)((Pl >> bit) & 1ull) - (int)((Ml >> bit) & 1ull));
+            } else {                                     // left edge of the band: only the diagonal neighbour may
+                l = kInf;                                // exist, as the bottom cell of the block above
+                ul = cornerAbove ? entry(c - 1, b - 1).s : kInf;
+            }
+            if (u + 1 == cur) {                          // up: INSERT
+                cur = u;
+                ops[--w] = 1;
+                if (r == 0) { for (int i = 0; i < c + 1; ++i) ops[--w] = 2; done = true; break; }
+                --r;
+            } else if (l + 1 == cur) {                   // left: DELETE
+                cur = l;
+                ops[--w] = 2;
+                --c;
+                if (c == -1) { for (int i = 0; i < r + 1; ++i) ops[--w] = 1; done = true; break; }
+            } else {                                     // diagonal: MATCH / MISMATCH
+                ops[--w] = (ul == cur) ? 0 : 3;
+                cur = ul;
+                --c;
+                if (c == -1) { for (int i = 0; i < r; ++i) ops[--w] = 1; done = true; break; }
+                if (r == 0) { for (int i = 0; i < c + 1; ++i) ops[--w] = 2; done = true; break; }
+                --r;
+            }
         }
     }
-    a.opsLen[unit] = m + T - w;
+    if (!skip) a.opsLen[unit] = m + T - w;
 }
 
 hipError_t launch_traceback(const TracebackArgs& a, hipStream_t stream)
