@@ -72,7 +72,10 @@ EDLIB_API EdlibAlignResult edlibAlign(const char* query, int queryLength, const 
                                       int targetLength, const EdlibAlignConfig config) {
     EdlibAlignResult r = blank_result(EDLIB_STATUS_OK);
     if (queryLength < 0 || targetLength < 0) { r.status = EDLIB_STATUS_ERROR; return r; }
-    const int rc = guarded("edlibAlign", 1, [&] { return align_one(query, queryLength, target, targetLength, config, &r); });
+    const int rc = guarded("edlibAlign", 1, [&] {
+        const int f = align_one_fused(query, queryLength, target, targetLength, config, &r);     // small pairs: one launch
+        return f == 2 ? align_one(query, queryLength, target, targetLength, config, &r) : f;
+    });
     if (rc) {
         fail_loudly("edlibAlign");
         return blank_result(EDLIB_STATUS_ERROR);

@@ -247,6 +247,8 @@ private:
 
 // single-pair convenience used by edlibAlign()
 int align_one(const char* q, int qn, const char* t, int tn, EdlibAlignConfig cfg, EdlibAlignResult* out);
+// one small pair in one kernel launch (one_pair.hip): 0 = answered, 1 = error, 2 = not handled here (take align_one)
+int align_one_fused(const char* q, int qn, const char* t, int tn, EdlibAlignConfig cfg, EdlibAlignResult* out);
 
 // helpers shared by engine.hip and long_reads.hip
 int roundup(int x, int q);

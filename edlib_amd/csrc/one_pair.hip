@@ -1,0 +1,368 @@
+// one_pair.hip -- edlibAlign() on one small pair in ONE kernel launch.
+//
+// A call of edlibAlign() (edlib.cpp:146-301) is transform -> Peq -> scan -> (start locations) -> (path).  As a batch
+// of one (engine.hip) that is several launches, an upload and host decisions between the phases: 90..900 us for pairs the
+// reference's README quotes at 3.6 / 47 us (bindings/python/README-tmpl.rst:194-205).  For queries of up to 1024 rows
+// against targets of up to 4096 columns (identity equality) the whole call runs here in one wave:
+//
+//   * the caller's bytes go into a pinned, device-visible mailbox (cached per host thread together with a stream); the
+//     kernel reads them from there -- no upload command, no staging of tables;
+//   * buildPeq (edlib.cpp:358-384): a 256-row table in LDS indexed by the raw target byte, filled with 64-bit LDS atomics
+//     by the lanes walking the query (no alphabet transform at all: alphabetLength is counted on the host);
+//   * the scan (myersCalcEditDistanceNW / SemiGlobal, :550-928) is the anti-diagonal schedule of kernel W on the first
+//     ceil(m / 64) lanes, every row of every column (a pair this small needs no band; the user's k filters the answer),
+//     target bytes and Peq words fetched from LDS one step ahead;
+//   * HW start locations (:228-272): one reverse SHW scan per end location inside the same launch (the reversed query's
+//     Peq is rebuilt in LDS);
+//   * PATH (:276-289, 942-1141): the storing scan keeps (P, M, block score) of every block-step in LDS when the matrix of
+//     the alignment window fits (ceil(m / 64) x T' x 20 bytes), lane 0 walks back with the reference's candidate order
+//     up > left > diagonal, the ops leave through the mailbox.
+//
+// What does not fit (more than 64 end locations, a store beyond the LDS budget, additional equalities, unknown modes)
+// answers "not handled" and the call takes the general path; results are the same function of the DP matrix either way
+// (tests/test_gpu_one_pair.py compares both paths with the reference).
+#include "engine.hpp"
+#include "block64.hpp"
+
+#include <cstring>
+
+namespace edlib_amd {
+
+namespace {
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+
+const int kOneMaxQ = 1024, kOneMaxT = 4096, kOneMaxLoc = 64;
+const int kOneLdsBudget = 150 * 1024;
+
+struct OneHeader {            // mailbox, host -> device (followed by the query bytes, then the target bytes)
+    int m, T, mode, task, k;
+    int storeCap;             // entries the LDS column store may hold (0: PATH not requested)
+    int pad[2];
+};
+struct OneResult {            // mailbox, device -> host (followed by kOneMaxLoc + 1 ends, as many starts, then the ops)
+    int code;                 // 0 = done, 2 = not handled here
+    int editDistance, numLocations, hasEnds, hasStarts, hasAlignment, alignmentLength, pad;
+};
+
+struct ScanOut { int best, cnt, last, score; };
+
+// One scan of the query (Peq table in LDS) against tgt[toff + i * tstep], i < Tn: MODE 0 NW, 1 SHW, 2 HW.
+// Lane l < nb owns block l; at step t it updates column t - l; {hout} moves one lane down per step by DPP.
+template <bool STORE>
+__device__ void scan_small(const u64* s_peq, const int nb, const uint8_t* s_t, const int toff, const int tstep, const int Tn,
+                           const int m, const int mode, const int kthr, int* s_pos, u32* s_store, ScanOut& o)
+{
+    const int lane = threadIdx.x;
+    const bool on = lane < nb;
+    const u32 sh = (u32)(m - 1) & 63u;
+    const bool tracker = lane == nb - 1;
+    Block64 B{~0u, ~0u, 0u, 0u};                                     // column -1 (edlib.cpp:575-579)
+    int bscore = (lane + 1) * 64, sc = m, carry = 0;
+    int best = kthr, cnt = 0, last = -1;
+    const int top = mode == 2 ? 0 : 1;                               // row -1: HW 0, SHW / NW +1 (edlib.cpp:584, 779)
+    const int nsteps = Tn + nb - 1;
+    // Peq word of this lane's next column, fetched a step ahead
+    auto eq_of = [&](int col) -> u64 {
+        if (!on || col < 0 || col >= Tn) return 0ull;
+        return s_peq[(int)s_t[toff + col * tstep] * nb + lane];
+    };
+    u64 eq = eq_of(-lane);
+    for (int t = 0; t < nsteps; ++t) {
+        const int col = t - lane;
+        const u64 eqN = eq_of(col + 1);
+        const int x = __builtin_amdgcn_update_dpp(top, carry, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+        if (on && col >= 0 && col < Tn) {
+            u32 ph0, ph1, mh0, mh1;
+            advance_block64(B, (u32)eq, (u32)(eq >> 32), (u32)x & 1u, ((u32)x >> 1) & 1u, ph0, ph1, mh0, mh1);
+            const u32 hp = ph1 >> 31, hn = mh1 >> 31;
+            bscore += (int)hp - (int)hn;
+            carry = (int)(hp | (hn << 1));
+            if (STORE) {
+                u32* e = s_store + (size_t)(col * nb + lane) * 5;
+                e[0] = B.p0; e[1] = B.p1; e[2] = B.m0; e[3] = B.m1; e[4] = (u32)bscore;
+            }
+            if (tracker) {
+                const u64 ph = ((u64)ph1 << 32) | ph0, mh = ((u64)mh1 << 32) | mh0;
+                sc += (int)((ph >> sh) & 1ull) - (int)((mh >> sh) & 1ull);
+                if (mode != 0 && sc <= best) {                       // edlib.cpp:658-673
+                    if (sc < best) { best = sc; cnt = 0; }
+                    if (cnt < kOneMaxLoc) s_pos[cnt] = col;
+                    ++cnt;
+                    last = col;
+                }
+            }
+        }
+        eq = eqN;
+    }
+    const int src = nb - 1;                                          // wave-uniform
+    o.best = __builtin_amdgcn_readlane(cnt > 0 ? best : -1, src);
+    o.cnt = __builtin_amdgcn_readlane(cnt, src);
+    o.last = __builtin_amdgcn_readlane(last, src);
+    o.score = __builtin_amdgcn_readlane(sc, src);
+    __syncthreads();                                                 // positions / store visible to every lane
+}
+
+// reference buildPeq (edlib.cpp:358-384) keyed by the raw target byte: bit r of row[byte][block] = query[64 block + r] == byte
+__device__ void build_peq_small(u64* s_peq, const int nb, const uint8_t* s_q, const int m, const bool reversed)
+{
+    for (int i = threadIdx.x; i < 256 * nb; i += 64) s_peq[i] = 0ull;
+    __syncthreads();
+    for (int i = threadIdx.x; i < m; i += 64) {
+        const int c = s_q[reversed ? m - 1 - i : i];
+        atomicOr(&s_peq[c * nb + (i >> 6)], 1ull << (i & 63));
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(64)
+one_pair_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
+    const OneHeader h = *reinterpret_cast<const OneHeader*>(in);
+    const int m = h.m, T = h.T, nb = (m + 63) >> 6, lane = threadIdx.x;
+    // ---- LDS: Peq table | query | target | end positions | ops | column store
+    u64* s_peq = reinterpret_cast<u64*>(s_mem);
+    uint8_t* s_q = s_mem + (size_t)256 * nb * 8;
+    uint8_t* s_t = s_q + ((m + 15) & ~15);
+    int* s_pos = reinterpret_cast<int*>(s_t + ((T + 15) & ~15));
+    uint8_t* s_ops = reinterpret_cast<uint8_t*>(s_pos + kOneMaxLoc);
+    u32* s_store = reinterpret_cast<u32*>(s_ops + ((m + T + 15) & ~15));
+    {   // the caller's bytes: pinned host memory -> LDS, dwords (the mailbox pads to 16 bytes)
+        const u32* qs = reinterpret_cast<const u32*>(in + sizeof(OneHeader));
+        const u32* ts = reinterpret_cast<const u32*>(in + sizeof(OneHeader) + ((m + 15) & ~15));
+        for (int i = lane; i < (m + 3) / 4; i += 64) reinterpret_cast<u32*>(s_q)[i] = qs[i];
+        for (int i = lane; i < (T + 3) / 4; i += 64) reinterpret_cast<u32*>(s_t)[i] = ts[i];
+    }
+    __syncthreads();
+    OneResult* res = reinterpret_cast<OneResult*>(out);
+    int* ends = reinterpret_cast<int*>(out + sizeof(OneResult));
+    int* starts = ends + kOneMaxLoc + 1;
+    uint8_t* opsOut = reinterpret_cast<uint8_t*>(starts + kOneMaxLoc + 1);
+    auto give_up = [&]() { if (lane == 0) { res->code = 2; __threadfence_system(); } };
+
+    const int mode = h.mode, task = h.task, k = h.k;
+    const int kthr = (k < 0 || k > m) ? m : k;                       // HW clamps k to m (edlib.cpp:566-568); SHW's best never exceeds m
+    build_peq_small(s_peq, nb, s_q, m, false);
+    // ---- phase 1: distance + end locations (NW with PATH: the storing scan right away)
+    const bool nwStore = mode == 0 && task == 2 && nb * T <= h.storeCap;
+    if (mode == 0 && task == 2 && !nwStore) { give_up(); return; }
+    ScanOut o;
+    if (nwStore) scan_small<true>(s_peq, nb, s_t, 0, 1, T, m, mode, kthr, s_pos, s_store, o);
+    else scan_small<false>(s_peq, nb, s_t, 0, 1, T, m, mode, kthr, s_pos, s_store, o);
+    int ed, nloc = 0; bool hasEnds = false;
+    int first = -2;                                                   // (wave-uniform copy of the first end location)
+    if (mode == 0) {
+        const bool over = k >= 0 && o.score > k;                      // edlib.cpp:744-747, 917
+        ed = over ? -1 : o.score;
+        if (!over) { hasEnds = true; nloc = 1; first = T - 1; if (lane == 0) ends[0] = T - 1; }
+    } else {
+        // the empty prefix (position -1, score m) takes part exactly when the padded last block of the
+        // reference would see it: W = 64 ceil(m / 64) - m > 0 (edlib.cpp:661, 670, 681-693)
+        const int W = 64 * nb - m;
+        const bool kAllowsM = k < 0 || k >= m;
+        if (o.best < 0) {
+            if (W > 0 && kAllowsM) { ed = m; hasEnds = true; nloc = 1; first = -1; if (lane == 0) ends[0] = -1; }
+            else ed = -1;
+        } else {
+            if (o.cnt > kOneMaxLoc) { give_up(); return; }
+            ed = o.best; hasEnds = true;
+            const int lead = (W > 0 && o.best == m) ? 1 : 0;
+            if (lead && lane == 0) ends[0] = -1;
+            for (int i = lane; i < o.cnt; i += 64) ends[lead + i] = s_pos[i];
+            nloc = lead + o.cnt;
+            first = lead ? -1 : s_pos[0];
+        }
+    }
+    bool hasStarts = false, hasAln = false; int alen = 0;
+    int start0 = 0;
+    if (ed >= 0 && task >= 1) {
+        // ---- phase 2: start locations (edlib.cpp:228-272): 0 for NW / SHW; HW: reverse SHW per end location with k = ed
+        hasStarts = true;
+        if (mode != 2) { for (int i = lane; i < nloc; i += 64) starts[i] = 0; }
+        else {
+            __syncthreads();
+            // the end locations are needed after s_pos is reused by the reverse scans: keep them in registers (lane i holds location i)
+            int myEnd = -2;
+            if (lane < nloc) myEnd = (lane == 0 && first == -1) ? -1 : s_pos[lane - ((first == -1) ? 1 : 0)];
+            build_peq_small(s_peq, nb, s_q, m, true);
+            for (int j = 0; j < nloc; ++j) {
+                const int e = __builtin_amdgcn_readlane(myEnd, j);
+                int st = 0;
+                if (e != -1) {                                        // :237-249
+                    // reverse query against the reversed prefix target[0..e], prefix mode, k = distance (:253-257); columns
+                    // past m + distance cannot score <= distance, so the window stops there
+                    const int win = (e + 1 < m + ed) ? e + 1 : m + ed;
+                    ScanOut r;
+                    scan_small<false>(s_peq, nb, s_t, e, -1, win, m, 1, ed, s_pos, s_store, r);
+                    st = e - r.last;                                  // last reported position of the reverse scan (:260)
+                }
+                if (lane == 0) starts[j] = st;
+                if (j == 0) start0 = st;
+            }
+            if (task == 2) build_peq_small(s_peq, nb, s_q, m, false);
+        }
+        // ---- phase 3: alignment path of the first location (edlib.cpp:276-289, 1161-1213)
+        if (task == 2 && nloc > 0) {
+            const int s0 = mode == 2 ? start0 : 0, e0 = first;
+            const int len = e0 - s0 + 1;
+            hasAln = true;
+            if (len <= 0) {                                           // :1168-1175
+                for (int i = lane; i < m; i += 64) s_ops[i] = 1;
+                alen = m;
+                __syncthreads();
+                for (int i = lane; i < alen; i += 64) opsOut[i] = s_ops[i];
+            } else {
+                if (!nwStore) {
+                    if (nb * len > h.storeCap) { give_up(); return; }
+                    ScanOut r;
+                    scan_small<true>(s_peq, nb, s_t, s0, 1, len, m, 0, m + len, s_pos, s_store, r);
+                }
+                // reference obtainAlignmentTraceback (edlib.cpp:942-1141): lane 0 walks from (m-1, len-1) to the origin on the
+                // stored columns; ops are written back to front
+                int wpos = m + len;
+                if (lane == 0) {
+                    int r = m - 1, c = len - 1, cur = ed;
+                    auto P = [&](int col, int blk) { const u32* e = s_store + (size_t)(col * nb + blk) * 5; return ((u64)e[1] << 32) | e[0]; };
+                    auto M = [&](int col, int blk) { const u32* e = s_store + (size_t)(col * nb + blk) * 5; return ((u64)e[3] << 32) | e[2]; };
+                    auto Sc = [&](int col, int blk) { return (int)s_store[(size_t)(col * nb + blk) * 5 + 4]; };
+                    for (;;) {
+                        const int b = r >> 6, bit = r & 63;
+                        const u64 Pc = P(c, b), Mc = M(c, b);
+                        const int u = cur - ((int)((Pc >> bit) & 1ull) - (int)((Mc >> bit) & 1ull));
+                        int l, ul;
+                        if (c == 0) { l = r + 1; ul = r; }            // column -1 boundary (:976-980)
+                        else {
+                            const u64 Pl = P(c - 1, b), Ml = M(c - 1, b);
+                            const u64 above = (bit == 63) ? 0ull : (~0ull << (bit + 1));
+                            l = Sc(c - 1, b) - __popcll(Pl & above) + __popcll(Ml & above);
+                            ul = l - ((int)((Pl >> bit) & 1ull) - (int)((Ml >> bit) & 1ull));
+                        }
+                        if (u + 1 == cur) {                           // up: INSERT
+                            cur = u; s_ops[--wpos] = 1;
+                            if (r == 0) { for (int i = 0; i < c + 1; ++i) s_ops[--wpos] = 2; break; }
+                            --r;
+                        } else if (l + 1 == cur) {                    // left: DELETE
+                            cur = l; s_ops[--wpos] = 2; --c;
+                            if (c == -1) { for (int i = 0; i < r + 1; ++i) s_ops[--wpos] = 1; break; }
+                        } else {                                      // diagonal: MATCH / MISMATCH
+                            s_ops[--wpos] = (ul == cur) ? 0 : 3; cur = ul; --c;
+                            if (c == -1) { for (int i = 0; i < r; ++i) s_ops[--wpos] = 1; break; }
+                            if (r == 0) { for (int i = 0; i < c + 1; ++i) s_ops[--wpos] = 2; break; }
+                            --r;
+                        }
+                    }
+                }
+                wpos = __builtin_amdgcn_readfirstlane(wpos);
+                alen = m + len - wpos;
+                __syncthreads();
+                for (int i = lane; i < alen; i += 64) opsOut[i] = s_ops[wpos + i];
+            }
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        res->editDistance = ed; res->numLocations = nloc; res->hasEnds = hasEnds ? 1 : 0; res->hasStarts = hasStarts ? 1 : 0;
+        res->hasAlignment = hasAln ? 1 : 0; res->alignmentLength = alen;
+        res->code = 0;
+        __threadfence_system();
+    }
+}
+
+// per-thread context: stream + mailboxes (cached for the life of the thread)
+struct OneCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    PinBuf in, out;
+    bool attr = false;
+    ~OneCtx() { if (stream) { DeviceGuard g(device); (void)hipStreamSynchronize(stream); pool_stream_release(stream); } }
+};
+
+}  // namespace
+
+// 0 = answered in *out, 1 = error (last_error set), 2 = not handled here (the caller takes the general path)
+int align_one_fused(const char* q, int m, const char* t, int T, EdlibAlignConfig cfg, EdlibAlignResult* out)
+{
+    static const bool enabled = !(getenv("EDLIB_AMD_ONEPAIR") && getenv("EDLIB_AMD_ONEPAIR")[0] == '0');
+    if (!enabled || m < 1 || T < 1 || m > kOneMaxQ || T > kOneMaxT) return 2;
+    if (cfg.additionalEqualities && cfg.additionalEqualitiesLength > 0) return 2;
+    const int mode = (int)cfg.mode, task = (int)cfg.task;
+    if (mode < 0 || mode > 2 || task < 0 || task > 2) return 2;
+    const int nb = (m + 63) / 64;
+    // LDS: Peq table + sequences + positions + ops, the rest is the column store of a PATH call
+    const size_t fixed = (size_t)256 * nb * 8 + ((m + 15) & ~15) + ((T + 15) & ~15) + kOneMaxLoc * sizeof(int) + ((m + T + 15) & ~15);
+    if (fixed > (size_t)kOneLdsBudget) return 2;
+    size_t storeCap = 0;
+    if (task == 2) {
+        storeCap = ((size_t)kOneLdsBudget - fixed) / 20;
+        // the window of the alignment: the whole target (NW), at most m + distance <= 2m columns (SHW / HW)
+        const long long cols = mode == 0 ? T : std::min<long long>(T, 2LL * m);
+        if ((long long)nb * cols > (long long)storeCap) return 2;
+    }
+    const int dev = default_device();
+    if (device_count() == 0) { set_error("no usable HIP device (this library has no CPU fallback)"); return 1; }
+    static thread_local OneCtx ctx;
+    pool_quarantine(false);
+    DeviceGuard guard(dev);
+    EDLIB_AMD_HIP(guard.status);
+    if (ctx.device != dev) {
+        if (ctx.stream) { (void)hipStreamSynchronize(ctx.stream); pool_stream_release(ctx.stream); ctx.stream = nullptr; }
+        ctx.device = dev;
+        EDLIB_AMD_HIP(pool_stream(&ctx.stream));
+        EDLIB_AMD_HIP(ctx.in.alloc(sizeof(OneHeader) + kOneMaxQ + kOneMaxT + 64));
+        EDLIB_AMD_HIP(ctx.out.alloc(sizeof(OneResult) + 2 * (kOneMaxLoc + 1) * sizeof(int) + kOneMaxQ + kOneMaxT + 64));
+    }
+    if (!ctx.attr) {
+        EDLIB_AMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(one_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kOneLdsBudget + 1024));
+        ctx.attr = true;
+    }
+    OneHeader* h = reinterpret_cast<OneHeader*>(ctx.in.p);
+    h->m = m; h->T = T; h->mode = mode; h->task = task; h->k = cfg.k; h->storeCap = (int)std::min<size_t>(storeCap, 0x7fffffff);
+    memcpy(ctx.in.p + sizeof(OneHeader), q, (size_t)m);
+    memcpy(ctx.in.p + sizeof(OneHeader) + ((m + 15) & ~15), t, (size_t)T);
+    OneResult* r = reinterpret_cast<OneResult*>(ctx.out.p);
+    r->code = -1;
+    const size_t lds = fixed + (task == 2 ? storeCap * 20 : 0) + 64;
+    hipLaunchKernelGGL(one_pair_kernel, dim3(1), dim3(64), lds, ctx.stream, ctx.in.p, ctx.out.p);
+    EDLIB_AMD_HIP(hipGetLastError());
+    // alphabetLength (edlib.cpp:162, transformSequences :1417-1462) while the kernel runs: distinct bytes of query and target
+    int alpha = 0;
+    {
+        bool seen[256] = {false};
+        for (int i = 0; i < m; ++i) if (!seen[(uint8_t)q[i]]) { seen[(uint8_t)q[i]] = true; ++alpha; }
+        for (int i = 0; i < T; ++i) if (!seen[(uint8_t)t[i]]) { seen[(uint8_t)t[i]] = true; ++alpha; }
+    }
+    EDLIB_AMD_HIP(hipStreamSynchronize(ctx.stream));
+    if (r->code == 2) return 2;
+    if (r->code != 0) { set_error("the single-pair kernel did not report (code %d)", r->code); return 1; }
+    const int* ends = reinterpret_cast<const int*>(ctx.out.p + sizeof(OneResult));
+    const int* starts = ends + kOneMaxLoc + 1;
+    const uint8_t* ops = reinterpret_cast<const uint8_t*>(starts + kOneMaxLoc + 1);
+    out->status = EDLIB_STATUS_OK; out->editDistance = r->editDistance; out->alphabetLength = alpha;
+    out->endLocations = nullptr; out->startLocations = nullptr; out->numLocations = 0; out->alignment = nullptr; out->alignmentLength = 0;
+    const size_t n = (size_t)r->numLocations;
+    if (r->hasEnds) {
+        out->endLocations = static_cast<int*>(malloc(sizeof(int) * std::max<size_t>(n, 1)));
+        if (out->endLocations) memcpy(out->endLocations, ends, n * sizeof(int));
+        out->numLocations = (int)n;
+    }
+    if (r->hasStarts) {
+        out->startLocations = static_cast<int*>(malloc(sizeof(int) * std::max<size_t>(n, 1)));
+        if (out->startLocations) memcpy(out->startLocations, starts, n * sizeof(int));
+    }
+    if (r->hasAlignment) {
+        const size_t len = (size_t)r->alignmentLength;
+        out->alignment = static_cast<unsigned char*>(malloc(std::max<size_t>(len, 1)));
+        if (out->alignment) memcpy(out->alignment, ops, len);
+        out->alignmentLength = (int)len;
+    }
+    if ((r->hasEnds && !out->endLocations) || (r->hasStarts && !out->startLocations) || (r->hasAlignment && !out->alignment)) {
+        free(out->endLocations); free(out->startLocations); free(out->alignment);
+        set_error("out of host memory");
+        return 1;
+    }
+    return 0;
+}
+
+}  // namespace edlib_amd

@@ -30,6 +30,7 @@
 //     order ([step][lane], one coalesced line per step); a second kernel walks
 //     back with the reference's candidate order up > left > diagonal.
 #include "pair_kernels.hpp"
+#include "block64.hpp"
 
 namespace edlib_amd {
 
@@ -143,38 +144,6 @@ hipError_t launch_build_peq_pairs(const PairDesc* descs, int numUnits, const uin
 }
 
 // ------------------------------------------------------------------- the scan
-
-// v_bitop3_b32 truth tables: bit i of the immediate is f(a,b,c) with i = a*4 + b*2 + c
-#define BITOP3_XOR_OR(a, b, c)   __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xde)   /* (a ^ c) | b   */
-#define BITOP3_OR_NOR(a, b, c)   __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xf1)   /* a | ~(b | c)  */
-
-// reference calculateBlock (edlib.cpp:412-447) on one 64-row block held as two 32-bit halves.
-// hpos / hneg are the two bits of hin (+1 / -1).  The booleans are written per half so that each
-// 3-input function is one v_bitop3_b32; the add and the two shifts use the 64-bit pair
-// (v_lshl_add_u64 / v_lshlrev_b64: 4 cycles per 64 bits, tools/valu_ubench.hip).  ph/mh return the
-// un-shifted horizontal delta vectors (bit r = row r of the block).
-struct Block64 { u32 p0, p1, m0, m1; };
-__device__ __forceinline__ void advance_block64(Block64& B, const u32 e0, const u32 e1,
-                                                const u32 hpos, const u32 hneg,
-                                                u32& ph0, u32& ph1, u32& mh0, u32& mh1)
-{
-    const u32 xv0 = e0 | B.m0, xv1 = e1 | B.m1;                 // Xv = Eq | Mv        (:421)
-    const u32 q0 = e0 | hneg;                                   // Eq |= hinIsNeg      (:423)
-    const u32 t0 = q0 & B.p0, t1 = e1 & B.p1;
-    u64 s;
-    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(s) : "v"(((u64)t1 << 32) | t0), "v"(((u64)B.p1 << 32) | B.p0));
-    const u32 xh0 = BITOP3_XOR_OR((u32)s, q0, B.p0), xh1 = BITOP3_XOR_OR((u32)(s >> 32), e1, B.p1);   // (:424)
-    ph0 = BITOP3_OR_NOR(B.m0, xh0, B.p0); ph1 = BITOP3_OR_NOR(B.m1, xh1, B.p1);                        // (:426)
-    mh0 = B.p0 & xh0; mh1 = B.p1 & xh1;                                                                // (:427)
-    u64 phs, mhs;
-    asm("v_lshlrev_b64 %0, 1, %1" : "=v"(phs) : "v"(((u64)ph1 << 32) | ph0));
-    asm("v_lshlrev_b64 %0, 1, %1" : "=v"(mhs) : "v"(((u64)mh1 << 32) | mh0));
-    const u32 a0 = (u32)phs | hpos, b0 = (u32)mhs | hneg;       // (:435-441)
-    B.p0 = BITOP3_OR_NOR(b0, xv0, a0);
-    B.p1 = BITOP3_OR_NOR((u32)(mhs >> 32), xv1, (u32)(phs >> 32));
-    B.m0 = a0 & xv0;
-    B.m1 = (u32)(phs >> 32) & xv1;
-}
 
 // MODE 0 NW, 1 SHW, 2 HW.  STORE: keep the column store.  LDSPEQ: Peq slice in LDS
 // (sigmaT <= 32), else gathered from the HBM pool.
@@ -759,25 +728,20 @@ hipError_t launch_hirschberg_split(const SplitArgs& a, hipStream_t stream)
 // with one WAVE per unit and the walk's window of the store kept on chip were both slower at config 5's shape
 // (10,000 x 1 kb: 0.89 ms here): window in LDS 1.31 ms (three LDS round trips per step), window in registers with
 // the whole walk in the scalar unit 1.66 ms (39 waves per CU share one scalar ALU).
-// Ring layout: the walk is a pointer chase through a store that lives in HBM (128 KB per 1 kb pair at config 5), and with one
-// walk per lane a wave waits for memory whenever ANY of its 64 lanes does.  So the lanes fetch together: every lane loads the
-// window of the store its walk can reach next -- eight columns to the left of where it stands, its block and (near the
-// block's top) the block above: up to 32 independent loads in flight per lane -- into its private slice of LDS, then all
-// lanes walk inside their windows until they leave them, and the wave pays one memory latency per window (~8 columns)
-// instead of one per step.  (Round 2: one dependent 32-byte load per step, 0.88 ms at config 5's shape; a per-lane
-// line cache that missed lane by lane stalled the wave at every step just the same: 1.37 ms.)
-constexpr int kWinCols = 8;
+// Round 3 measured two ways of paying fewer memory latencies per walk, both slower than this plain version (0.88 ms at
+// config 5's shape): a per-lane line cache in LDS (four columns per fetch) misses lane by lane, so the wave still stalls at
+// every step (1.37 ms); fetching an 8-column x 2-block window per lane all together removes the stalls but costs 32
+// scattered loads per lane and window -- the address path, not the latency, then bounds it (1.18 ms).
 __global__ void __launch_bounds__(64)
 traceback_kernel(const TracebackArgs a)
 {
-    __shared__ u32 s_win[64][2][kWinCols][5];        // [lane][block: 0 = the walk's block, 1 = the one above][column][p lo, p hi, m lo, m hi, s]
     const int unit = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool have = unit < a.numUnits;
-    const PairDesc d = a.descs[have ? unit : 0];
+    if (unit >= a.numUnits) return;
+    const PairDesc d = a.descs[unit];
     const int m = d.qlen, T = d.tlen, nb = num_blocks(m);
-    uint8_t* ops = a.ops + a.opsOff[have ? unit : 0];
+    uint8_t* ops = a.ops + a.opsOff[unit];
     int w = m + T;                                  // next write index is --w
-    int r = m - 1, c = T - 1, cur = have ? a.score[unit] : 0;
+    int r = m - 1, c = T - 1, cur = a.score[unit];
     const StoreEntry* S = a.store + d.storeOff;
     // ring layout (scan_pairs_ring_kernel): only the blocks inside the band of threshold kinit exist.
     // The walk stays on cells of optimal paths, which are inside the band and exact; a neighbour outside
@@ -790,91 +754,55 @@ traceback_kernel(const TracebackArgs a)
         dmin = (D < 0 ? D : 0) - p;
     }
     const int kInf = 0x3fffffff;
-    struct Ent { u64 p, m; int s; };
     // a unit whose scan ended above its threshold has no exact cells to walk on (it is rescanned at the next level)
-    const bool skip = !have || (G && cur > d.kinit);
-    if (have && skip) a.opsLen[unit] = 0;
-    bool done = skip;
-    u32 (&win)[2][kWinCols][5] = s_win[threadIdx.x];
-    int wb = -1, wc0 = 0, wc1 = -1; bool wup = false;     // the window: block wb (and wb - 1 if wup), columns wc0 .. wc1
-    auto in_window = [&](int col, int blk) { return col >= wc0 && col <= wc1 && (blk == wb || (wup && blk == wb - 1)); };
-    auto entry = [&](int col, int blk) -> Ent {
-        if (!G) { const StoreEntry e = S[store_index(T, nb, col, blk)]; return Ent{e.p, e.m, e.s}; }
-        const u32 (&e)[5] = win[blk == wb ? 0 : 1][col - wc0];
-        return Ent{((u64)e[1] << 32) | e[0], ((u64)e[3] << 32) | e[2], (int)e[4]};
+    if (G && cur > d.kinit) { a.opsLen[unit] = 0; return; }
+    auto entry = [&](int col, int blk) -> const StoreEntry& {
+        return S[G ? ring_index(G, T, col, blk) : store_index(T, nb, col, blk)];
     };
     // the walk keeps the block of the current column and of the column to its left in registers: a step
     // to the left or along the diagonal inside a block shifts them and fetches one new entry
     int hb = -1, hc = -2;                            // block / column the registers describe (hc = current column)
     u64 Pc = 0, Mc = 0, Pl = 0, Ml = 0; int Sl = 0; bool leftIn = false;
-    while (__builtin_amdgcn_ballot_w64(!done) != 0ull) {
-        if (G && !done) {                            // ---- fetch the window anchored where the walk stands
-            wb = r >> 6; wc1 = c; wc0 = c - (kWinCols - 1) < 0 ? 0 : c - (kWinCols - 1);
-            wup = wb > 0 && (r & 63) < kWinCols;     // a step moves up one row at most: the block above matters near the top
-            uint4 pm[2][kWinCols]; int sc[2][kWinCols];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const StoreEntry* row = S + (long long)((wb - q + G) % G) * T + wc0;
-#pragma unroll
-                for (int i = 0; i < kWinCols; ++i) {
-                    const bool in = wc0 + i <= wc1 && (q == 0 || wup);
-                    pm[q][i] = in ? *reinterpret_cast<const uint4*>(&row[i].p) : uint4{0, 0, 0, 0};
-                    sc[q][i] = in ? row[i].s : 0;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int i = 0; i < kWinCols; ++i) {
-                    win[q][i][0] = pm[q][i].x; win[q][i][1] = pm[q][i].y; win[q][i][2] = pm[q][i].z; win[q][i][3] = pm[q][i].w; win[q][i][4] = (u32)sc[q][i];
-                }
-            hb = -1; hc = -2;                        // registers are reloaded from the new window
+    for (;;) {
+        const int b = r >> 6, bit = r & 63;
+        if (b != hb || c != hc) {
+            if (b == hb && c == hc - 1 && leftIn) { Pc = Pl; Mc = Ml; }
+            else { const StoreEntry e = entry(c, b); Pc = e.p; Mc = e.m; }
+            leftIn = c > 0 && (!G || c - 1 >= 64 * b + dmin);          // block b exists in column c-1
+            if (leftIn) { const StoreEntry e = entry(c - 1, b); Pl = e.p; Ml = e.m; Sl = e.s; }
+            hb = b; hc = c;
         }
-        // ---- walk while everything a step needs is inside the window
-        while (!done) {
-            const int b = r >> 6, bit = r & 63;
-            const bool leftHere = c > 0 && (!G || c - 1 >= 64 * b + dmin);          // block b exists in column c-1
-            const bool cornerAbove = c > 0 && !leftHere && bit == 0 && b > 0;       // left edge of the band: the diagonal neighbour is above
-            if (G && !(in_window(c, b) && (!leftHere || in_window(c - 1, b)) && (!cornerAbove || in_window(c - 1, b - 1)))) break;
-            if (b != hb || c != hc) {
-                if (b == hb && c == hc - 1 && leftIn) { Pc = Pl; Mc = Ml; }
-                else { const Ent e = entry(c, b); Pc = e.p; Mc = e.m; }
-                leftIn = leftHere;
-                if (leftIn) { const Ent e = entry(c - 1, b); Pl = e.p; Ml = e.m; Sl = e.s; }
-                hb = b; hc = c;
-            }
-            const int u = cur - ((int)((Pc >> bit) & 1ull) - (int)((Mc >> bit) & 1ull));
-            int l, ul;
-            if (c == 0) { l = r + 1; ul = r; }          // column -1 boundary (:976-980)
-            else if (leftIn) {
-                const u64 above = (bit == 63) ? 0ull : (~0ull << (bit + 1));   // rows below r in the block
-                l = Sl - __popcll(Pl & above) + __popcll(Ml & above);
-                ul = l - ((int)((Pl >> bit) & 1ull) - (int)((Ml >> bit) & 1ull));
-            } else {                                     // left edge of the band: only the diagonal neighbour may
-                l = kInf;                                // exist, as the bottom cell of the block above
-                ul = cornerAbove ? entry(c - 1, b - 1).s : kInf;
-            }
-            if (u + 1 == cur) {                          // up: INSERT
-                cur = u;
-                ops[--w] = 1;
-                if (r == 0) { for (int i = 0; i < c + 1; ++i) ops[--w] = 2; done = true; break; }
-                --r;
-            } else if (l + 1 == cur) {                   // left: DELETE
-                cur = l;
-                ops[--w] = 2;
-                --c;
-                if (c == -1) { for (int i = 0; i < r + 1; ++i) ops[--w] = 1; done = true; break; }
-            } else {                                     // diagonal: MATCH / MISMATCH
-                ops[--w] = (ul == cur) ? 0 : 3;
-                cur = ul;
-                --c;
-                if (c == -1) { for (int i = 0; i < r; ++i) ops[--w] = 1; done = true; break; }
-                if (r == 0) { for (int i = 0; i < c + 1; ++i) ops[--w] = 2; done = true; break; }
-                --r;
-            }
+        const int u = cur - ((int)((Pc >> bit) & 1ull) - (int)((Mc >> bit) & 1ull));
+        int l, ul;
+        if (c == 0) { l = r + 1; ul = r; }          // column -1 boundary (:976-980)
+        else if (leftIn) {
+            const u64 above = (bit == 63) ? 0ull : (~0ull << (bit + 1));   // rows below r in the block
+            l = Sl - __popcll(Pl & above) + __popcll(Ml & above);
+            ul = l - ((int)((Pl >> bit) & 1ull) - (int)((Ml >> bit) & 1ull));
+        } else {                                     // left edge of the band: only the diagonal neighbour may
+            l = kInf;                                // exist, as the bottom cell of the block above
+            ul = (bit == 0 && b > 0) ? entry(c - 1, b - 1).s : kInf;
+        }
+        if (u + 1 == cur) {                          // up: INSERT
+            cur = u;
+            ops[--w] = 1;
+            if (r == 0) { for (int i = 0; i < c + 1; ++i) ops[--w] = 2; break; }
+            --r;
+        } else if (l + 1 == cur) {                   // left: DELETE
+            cur = l;
+            ops[--w] = 2;
+            --c;
+            if (c == -1) { for (int i = 0; i < r + 1; ++i) ops[--w] = 1; break; }
+        } else {                                     // diagonal: MATCH / MISMATCH
+            ops[--w] = (ul == cur) ? 0 : 3;
+            cur = ul;
+            --c;
+            if (c == -1) { for (int i = 0; i < r; ++i) ops[--w] = 1; break; }
+            if (r == 0) { for (int i = 0; i < c + 1; ++i) ops[--w] = 2; break; }
+            --r;
         }
     }
-    if (!skip) a.opsLen[unit] = m + T - w;
+    a.opsLen[unit] = m + T - w;
 }
 
 hipError_t launch_traceback(const TracebackArgs& a, hipStream_t stream)
