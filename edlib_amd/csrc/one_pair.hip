@@ -63,15 +63,17 @@ __device__ void scan_small(const u64* s_peq, const int nb, const uint8_t* s_t, c
     int best = kthr, cnt = 0, last = -1;
     const int top = mode == 2 ? 0 : 1;                               // row -1: HW 0, SHW / NW +1 (edlib.cpp:584, 779)
     const int nsteps = Tn + nb - 1;
-    // Peq word of this lane's next column, fetched a step ahead
-    auto eq_of = [&](int col) -> u64 {
-        if (!on || col < 0 || col >= Tn) return 0ull;
-        return s_peq[(int)s_t[toff + col * tstep] * nb + lane];
-    };
-    u64 eq = eq_of(-lane);
+    // The target byte of a column is fetched two steps ahead and its Peq word one step ahead: the two LDS reads a column needs
+    // are then in different iterations, and neither sits on the step's dependent chain (a single wave has nobody to hide an
+    // LDS round trip behind)
+    auto byte_of = [&](int col) -> int { return (on && col >= 0 && col < Tn) ? (int)s_t[toff + col * tstep] : 0; };
+    auto word_of = [&](int byte, int col) -> u64 { return (on && col >= 0 && col < Tn) ? s_peq[byte * nb + lane] : 0ull; };
+    u64 eq = word_of(byte_of(-lane), -lane);
+    int tbN = byte_of(1 - lane);
     for (int t = 0; t < nsteps; ++t) {
         const int col = t - lane;
-        const u64 eqN = eq_of(col + 1);
+        const u64 eqN = word_of(tbN, col + 1);
+        const int tbNN = byte_of(col + 2);
         const int x = __builtin_amdgcn_update_dpp(top, carry, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
         if (on && col >= 0 && col < Tn) {
             u32 ph0, ph1, mh0, mh1;
@@ -94,7 +96,7 @@ __device__ void scan_small(const u64* s_peq, const int nb, const uint8_t* s_t, c
                 }
             }
         }
-        eq = eqN;
+        eq = eqN; tbN = tbNN;
     }
     const int src = nb - 1;                                          // wave-uniform
     o.best = __builtin_amdgcn_readlane(cnt > 0 ? best : -1, src);
@@ -166,9 +168,9 @@ one_pair_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out)
             if (W > 0 && kAllowsM) { ed = m; hasEnds = true; nloc = 1; first = -1; if (lane == 0) ends[0] = -1; }
             else ed = -1;
         } else {
-            if (o.cnt > kOneMaxLoc) { give_up(); return; }
-            ed = o.best; hasEnds = true;
             const int lead = (W > 0 && o.best == m) ? 1 : 0;
+            if (lead + o.cnt > kOneMaxLoc) { give_up(); return; }       // (lane i keeps location i for the reverse scans)
+            ed = o.best; hasEnds = true;
             if (lead && lane == 0) ends[0] = -1;
             for (int i = lane; i < o.cnt; i += 64) ends[lead + i] = s_pos[i];
             nloc = lead + o.cnt;
