@@ -292,6 +292,10 @@ int align_one_fused(const char* q, int m, const char* t, int T, EdlibAlignConfig
     const int mode = (int)cfg.mode, task = (int)cfg.task;
     if (mode < 0 || mode > 2 || task < 0 || task > 2) return 2;
     const int nb = (m + 63) / 64;
+    // One wave walks T + nb dependent steps of ~0.2 us here; beyond ~400 steps the batch-of-one path (ring kernel: ~0.12 us
+    // per step behind ~45 us of launches and copies) is the faster one for distances.  PATH is faster here whenever its
+    // store fits (1 k x 1 k: the general path takes 900 us).
+    if (task != 2 && T + nb > 400) return 2;
     // LDS: Peq table + sequences + positions + ops, the rest is the column store of a PATH call
     const size_t fixed = (size_t)256 * nb * 8 + ((m + 15) & ~15) + ((T + 15) & ~15) + kOneMaxLoc * sizeof(int) + ((m + T + 15) & ~15);
     if (fixed > (size_t)kOneLdsBudget) return 2;
