@@ -321,6 +321,14 @@ count_flags_kernel(const int* __restrict__ flags, int n, int* __restrict__ count
     if (i < n && flags[i]) atomicAdd(counter, 1);
 }
 
+// flat pair path: how many units have more end locations than their list keeps (they need the exact second pass)
+__global__ void __launch_bounds__(256)
+count_over_kernel(const int* __restrict__ count, int n, int cap, int* __restrict__ counter)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && count[i] > cap) atomicAdd(counter, 1);
+}
+
 // --------------------------------------------------------------- Batch: init
 
 Batch::~Batch() {
@@ -460,6 +468,7 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
         if (makeGroup(byWords[w], w, g)) return 1;
         groups_.push_back(std::move(g));
     }
+    if (initFlatPairs()) return 1;
     const int T = shared_ ? tlen(0) : 0;
     if (!groups_.empty() || !longUnits_.empty()) {
         EDLIB_AMD_HIP(d_tpk_.alloc((size_t)(T + 15) / 16 + 4));
@@ -1277,6 +1286,123 @@ int Batch::alphabetLengthsEnd(std::vector<UnitResult>& res)
     return 0;
 }
 
+
+// ------------------------------------------------------------ flat pair path
+
+static const int kFlatPosCap = 16;
+
+// Batches of short independent pairs (the verification step of a seed-and-extend mapper: 262,144 x 150 bp in 400 bp
+// windows) were host-bound: every run rebuilt 88-byte descriptors for every unit, uploaded them, downloaded 16 end
+// positions per unit and walked 160-byte records five times (22..28 ns per pair with the kernels a fifth of it).  When
+// every unit is a pair of at most 16 blocks and only distances are asked for, nothing about the descriptors depends on a
+// run: they are built once, here, and stay resident; a run is Peq build + one ring scan (whole matrix on a 4- or 16-lane
+// ring: exact for any distance, no levels) + a census of overflowing end-location lists, and the results stay in HBM until
+// results() asks for them -- the lazy form the reads path has had since round 1.
+int Batch::initFlatPairs()
+{
+    static const bool on = !(getenv("EDLIB_AMD_FLATPAIRS") && getenv("EDLIB_AMD_FLATPAIRS")[0] == '0');
+    flatPairs_ = false;
+    if (!on || cfg_.task != EDLIB_TASK_DISTANCE || !emptyUnits_.empty() || !groups_.empty() || !longUnits_.empty()) return 0;
+    if ((int)pairUnits_.size() != n_ || n_ < 1024) return 0;       // (a handful of units: the zero-copy path of solveChunk)
+    const int mode = (int)cfg_.mode;
+    const int scanMode = (mode == EDLIB_MODE_HW || mode == EDLIB_MODE_SHW) ? mode : EDLIB_MODE_NW;
+    int maxBlocks = 0;
+    for (int u = 0; u < n_; ++u) maxBlocks = std::max(maxBlocks, (qlen(u) + 63) / 64);
+    if (maxBlocks > 16) return 0;
+    flatRing_ = maxBlocks <= 4 ? 4 : 16;
+    PinBuf pin;
+    EDLIB_AMD_HIP(pin.alloc((size_t)n_ * sizeof(PairDesc)));
+    PairDesc* d = reinterpret_cast<PairDesc*>(pin.p);
+    long long peqWords = 0;
+    flatWordSteps_ = 0;
+    for (int u = 0; u < n_; ++u) {
+        const int m = qlen(u), T = tlen(u);
+        const long long nb = (m + 63) / 64;
+        PairDesc& x = d[u];
+        x.qoff = qoff_[u]; x.toff = tbase(u); x.qlen = m; x.tlen = T; x.qstep = 1; x.tstep = 1;
+        // NW: the ring holds every block of the unit, so the band is the whole matrix (threshold max(m, T)); SHW / HW:
+        // columns scoring <= min(k, m) are end-location candidates
+        x.kinit = scanMode == EDLIB_MODE_NW ? std::max(m, T) : ((cfg_.k < 0 || cfg_.k > m) ? m : cfg_.k);
+        x.peqOff = peqWords; peqWords += nb * tab_.sigmaT;
+        x.storeOff = 0; x.auxOff = 0; x.posCap = scanMode == EDLIB_MODE_NW ? 0 : kFlatPosCap; x.posOff = (long long)u * kFlatPosCap;
+        x.colOff = -1; x.bandT = 0; x.skip = 0; x.ring = flatRing_;
+        flatWordSteps_ += 2LL * flatRing_ * ((long long)T + nb - 1);
+    }
+    EDLIB_AMD_HIP(d_flatDescs_.alloc((size_t)n_));
+    EDLIB_AMD_HIP(hipMemcpyAsync(d_flatDescs_.p, d, (size_t)n_ * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
+    EDLIB_AMD_HIP(d_peq64_.ensure((size_t)peqWords));
+    EDLIB_AMD_HIP(d_flatOut3_.alloc(3 * (size_t)n_));
+    EDLIB_AMD_HIP(d_flatPos_.alloc(scanMode == EDLIB_MODE_NW ? 1 : (size_t)n_ * kFlatPosCap));
+    EDLIB_AMD_HIP(d_flatCensus_.alloc(1));
+    EDLIB_AMD_HIP(h_flatCensus_.alloc(sizeof(int)));
+    EDLIB_AMD_HIP(hipStreamSynchronize(stream_));                // `pin` dies here
+    flatPairs_ = true;
+    return 0;
+}
+
+int Batch::runPairsFlat(bool& overflowed)
+{
+    const int mode = (int)cfg_.mode;
+    const int scanMode = (mode == EDLIB_MODE_HW || mode == EDLIB_MODE_SHW) ? mode : EDLIB_MODE_NW;
+    stats.path |= 2;
+    EDLIB_AMD_HIP(uploadEq8());
+    EDLIB_AMD_HIP(launch_build_peq_pairs(d_flatDescs_.p, n_, d_qpool_.p, d_eq8_.p, d_idToByte_.p, tab_.sigmaT, d_peq64_.p, stream_));
+    PairScanArgs a{};
+    a.descs = d_flatDescs_.p; a.numUnits = n_; a.qpool = d_qpool_.p; a.tpool = d_tpool_.p;
+    a.tlut = d_tlut_.p; a.sigmaT = tab_.sigmaT; a.peq = d_peq64_.p; a.aux = nullptr;
+    a.peqRowStride = peq_row_stride(flatRing_);
+    a.peqFullStride = (int)std::min<long long>((long long)a.peqRowStride * tab_.sigmaT, 1 << 20);
+    a.store = nullptr;
+    a.outScore = d_flatOut3_.p; a.outCount = d_flatOut3_.p + n_; a.outLast = d_flatOut3_.p + 2 * (size_t)n_; a.posPool = d_flatPos_.p;
+    scanTimerStart();
+    EDLIB_AMD_HIP(launch_scan_pairs_ring(flatRing_, scanMode, false, a, stream_));
+    scanTimerStop();
+    stats.word_steps += flatWordSteps_;
+    overflowed = false;
+    if (scanMode != EDLIB_MODE_NW) {
+        EDLIB_AMD_HIP(hipMemsetAsync(d_flatCensus_.p, 0, sizeof(int), stream_));
+        hipLaunchKernelGGL(count_over_kernel, dim3((n_ + 255) / 256), dim3(256), 0, stream_, d_flatOut3_.p + n_, n_, kFlatPosCap, d_flatCensus_.p);
+        EDLIB_AMD_HIP(hipMemcpyAsync(h_flatCensus_.p, d_flatCensus_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
+        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+        overflowed = *reinterpret_cast<const int*>(h_flatCensus_.p) > 0;
+    }
+    return 0;
+}
+
+int Batch::collectPairsFlat(std::vector<UnitResult>& res)
+{
+    const int mode = (int)cfg_.mode;
+    const int scanMode = (mode == EDLIB_MODE_HW || mode == EDLIB_MODE_SHW) ? mode : EDLIB_MODE_NW;
+    const size_t n = (size_t)n_, npos = scanMode == EDLIB_MODE_NW ? 0 : n * kFlatPosCap;
+    PinBuf stage;
+    EDLIB_AMD_HIP(stage.alloc((3 * n + npos) * sizeof(int)));
+    int* h = reinterpret_cast<int*>(stage.p);
+    EDLIB_AMD_HIP(hipMemcpyAsync(h, d_flatOut3_.p, 3 * n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    if (npos) EDLIB_AMD_HIP(hipMemcpyAsync(h + 3 * n, d_flatPos_.p, npos * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+    const int* score = h; const int* count = h + n; const int* pos = h + 3 * n;
+    for (size_t u = 0; u < n; ++u) {
+        UnitResult& r = res[u];
+        r.status = EDLIB_STATUS_OK; r.hasStarts = r.hasAlignment = false;
+        if (scanMode == EDLIB_MODE_NW) finalize_global(r, cfg_.k, mode, tlen((int)u), score[u]);
+        else finalize_semiglobal(r, cfg_.k, qlen((int)u), score[u], pos + u * kFlatPosCap, score[u] < 0 ? 0 : std::max(count[u], 0));
+    }
+    if (alphabetLengthsEnd(res)) return 1;
+    pairsCollected_ = true;
+    return 0;
+}
+
+int Batch::ensureCollected()
+{
+    if (readsCollected_ && pairsCollected_) return 0;
+    DeviceGuard guard(device_);
+    EDLIB_AMD_HIP(guard.status);
+    if (results_.size() != (size_t)n_) results_.assign((size_t)n_, UnitResult{});
+    if (!readsCollected_ && collectReads(results_)) return 1;
+    if (!pairsCollected_ && collectPairsFlat(results_)) return 1;
+    return 0;
+}
+
 // ------------------------------------------------------------- Hirschberg
 
 static bool needs_hirschberg(int m, int T) {
@@ -1729,7 +1855,8 @@ int Batch::run()
     opsOwned_.clear();
     // TASK_DISTANCE over reads-path units only: nothing is assembled on the host until results() asks for it, so
     // the per-unit records (160 bytes each) are not even allocated in the timed run
-    const bool lazy = cfg_.task == EDLIB_TASK_DISTANCE && pairUnits_.empty() && longUnits_.empty() && emptyUnits_.empty() && !groups_.empty();
+    bool lazy = (cfg_.task == EDLIB_TASK_DISTANCE && pairUnits_.empty() && longUnits_.empty() && emptyUnits_.empty() && !groups_.empty()) || flatPairs_;
+    pairsCollected_ = true;
     // the records of the run before last are recycled (no 160-byte-per-unit allocation + page faults per run)
     std::vector<UnitResult>& res = work_;
     if (lazy) res.clear();
@@ -1758,6 +1885,17 @@ int Batch::run()
         else r.status = EDLIB_STATUS_ERROR;
     }
     if (alphabetLengthsBegin()) return 1;
+    bool flatDone = false;
+    if (flatPairs_) {                                   // ---- phase 1 of a flat pair batch: everything stays on the device
+        bool over = false;
+        if (runPairsFlat(over)) return 1;
+        if (over) {
+            // an end-location list did not fit: this batch takes the general path (exact second pass) from now on
+            flatPairs_ = false; lazy = false;
+            res.assign((size_t)n_, UnitResult{});
+        } else { flatDone = true; pairsCollected_ = false; }
+        lap("run: flat pairs");
+    }
     // ---- phase 1: distance + end locations
     if (packTarget()) return 1;
     if (runReads()) return 1;
@@ -1805,6 +1943,7 @@ int Batch::run()
         EDLIB_AMD_HIP(hipMemcpyAsync(h_wordSteps_.p, d_wordSteps_.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
         wordStepsPending_ = true;
     }
+    if (flatDone) pairNow_.clear();
     const std::vector<int>& pairUnits_ = pairNow_;          // (shadows the member: the units of THIS run's pair phase)
     if (!pairUnits_.empty()) {
         // scratch that a run needs per unit lives in the batch: a fresh 10 MB std::vector is an mmap, its page faults
@@ -1842,7 +1981,7 @@ int Batch::run()
                                     so.posFlat.data() + so.posStart[i], so.posStart[i + 1] - so.posStart[i]);
         }
     }
-    if (alphabetLengthsEnd(res)) return 1;      // alphabetLength for everything the reads path did not cover
+    if (!flatDone && alphabetLengthsEnd(res)) return 1;      // alphabetLength for everything the reads path did not cover (flat pairs: at collection)
     lap("run: phase 1 (distance)");
     std::vector<int>& live = live_;            // non-empty units with a solution (only the later phases want them)
     live.clear();
@@ -1929,8 +2068,8 @@ int Batch::run()
         stats.scan_ms += t;
     }
     // algorithmic bytes: target + query + Peq + result header + end locations
-    if (!readsCollected_ && pairUnits_.empty() && longUnits_.empty() && emptyUnits_.empty()) {
-        // everything is still resident on the device (reads path, TASK_DISTANCE): every unit is priced with
+    if ((!readsCollected_ && pairUnits_.empty() && longUnits_.empty() && emptyUnits_.empty()) || flatDone) {
+        // everything is still resident on the device (reads path or flat pairs, TASK_DISTANCE): every unit is priced with
         // sigma = |target alphabet| and one end location -- a constant of the batch, summed once
         if (algoBase_ < 0) {
             algoBase_ = 0;
@@ -1953,12 +2092,7 @@ int Batch::run()
 void Batch::finishStats()
 {
     if (!algoDirty_) return;
-    if (haveResults_ && !readsCollected_) {        // a DISTANCE batch that mixes reads-path and pair units: the read units' records are still on the device
-        DeviceGuard guard(device_);
-        if (guard.status != hipSuccess) return;
-        if (results_.size() != (size_t)n_) results_.resize((size_t)n_);
-        if (collectReads(results_)) return;
-    }
+    if (haveResults_ && ensureCollected()) return;   // (a DISTANCE batch that mixes reads-path and pair units: the read units' records are still on the device)
     algoDirty_ = false;
     const std::vector<UnitResult>& res = results_;
     stats.algo_bytes = 0;
@@ -1987,12 +2121,7 @@ int Batch::results(EdlibAlignResult* out)
         o.numLocations = 0; o.alignment = nullptr; o.alignmentLength = 0; o.alphabetLength = 0;
     }
     if (!haveResults_) { set_error("results() before a successful run()"); return 1; }
-    if (!readsCollected_) {
-        DeviceGuard guard(device_);
-        EDLIB_AMD_HIP(guard.status);
-        if (results_.size() != (size_t)n_) results_.assign((size_t)n_, UnitResult{});
-        if (collectReads(results_)) return 1;
-    }
+    if (ensureCollected()) return 1;
     std::atomic<int> oom(0);                      // a failed malloc: the unit reports EDLIB_STATUS_ERROR, the call fails
     auto marshal = [&](int lo, int hi) {
         for (int u = lo; u < hi; ++u) {
@@ -2061,12 +2190,7 @@ int Batch::resultsFlat(int* status, int* editDistance, int* numLocations, int* a
     if (startLocations) *startLocations = nullptr;
     if (alignment) *alignment = nullptr;
     if (!haveResults_) { set_error("results() before a successful run()"); return 1; }
-    if (!readsCollected_) {
-        DeviceGuard guard(device_);
-        EDLIB_AMD_HIP(guard.status);
-        if (results_.size() != (size_t)n_) results_.assign((size_t)n_, UnitResult{});
-        if (collectReads(results_)) return 1;
-    }
+    if (ensureCollected()) return 1;
     long long nloc = 0, naln = 0;
     for (int u = 0; u < n_; ++u) {
         const UnitResult& r = results_[u];

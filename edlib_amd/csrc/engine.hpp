@@ -243,6 +243,18 @@ private:
     std::vector<UnitSpec> pairSpecs_, selScratch_; std::vector<size_t> whoScratch_; std::vector<int> lvlScratch_, scoreMain_;
     SolveOut soMain_, soLevel_;
     std::vector<OpsOut> fusedOps_;
+    // ---- flat pair path (TASK_DISTANCE, every unit a pair of at most 16 blocks): descriptors built once and resident, a
+    // run is Peq build + ONE ring scan + an overflow census, results stay in HBM until results() (like the reads path)
+    bool flatPairs_ = false, pairsCollected_ = true;
+    int flatRing_ = 0;
+    long long flatWordSteps_ = 0;
+    DevBuf<PairDesc> d_flatDescs_;
+    DevBuf<int> d_flatOut3_, d_flatPos_, d_flatCensus_;
+    PinBuf h_flatCensus_;
+    int initFlatPairs();
+    int runPairsFlat(bool& overflowed);
+    int collectPairsFlat(std::vector<UnitResult>& res);
+    int ensureCollected();                       // results of the last run that are still on the device -> results_
 };
 
 // single-pair convenience used by edlibAlign()
