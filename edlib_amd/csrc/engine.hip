@@ -1298,6 +1298,22 @@ static const int kFlatPosCap = 16;
 // run: they are built once, here, and stay resident; a run is Peq build + one ring scan (whole matrix on a 4- or 16-lane
 // ring: exact for any distance, no levels) + a census of overflowing end-location lists, and the results stay in HBM until
 // results() asks for them -- the lazy form the reads path has had since round 1.
+PairDesc Batch::flatDesc(int u) const
+{
+    const int mode = (int)cfg_.mode;
+    const int scanMode = (mode == EDLIB_MODE_HW || mode == EDLIB_MODE_SHW) ? mode : EDLIB_MODE_NW;
+    const int m = qlen(u), T = tlen(u);
+    PairDesc x{};
+    x.qoff = qoff_[u]; x.toff = tbase(u); x.qlen = m; x.tlen = T; x.qstep = 1; x.tstep = 1;
+    // NW: the ring holds every block of the unit, so the band is the whole matrix (threshold max(m, T)); SHW / HW:
+    // columns scoring <= min(k, m) are end-location candidates
+    x.kinit = scanMode == EDLIB_MODE_NW ? std::max(m, T) : ((cfg_.k < 0 || cfg_.k > m) ? m : cfg_.k);
+    x.peqOff = flatPeqOff_[u];
+    x.storeOff = 0; x.auxOff = 0; x.posCap = scanMode == EDLIB_MODE_NW ? 0 : kFlatPosCap; x.posOff = (long long)u * kFlatPosCap;
+    x.colOff = -1; x.bandT = 0; x.skip = 0; x.ring = flatRing_;
+    return x;
+}
+
 int Batch::initFlatPairs()
 {
     static const bool on = !(getenv("EDLIB_AMD_FLATPAIRS") && getenv("EDLIB_AMD_FLATPAIRS")[0] == '0');
@@ -1315,18 +1331,12 @@ int Batch::initFlatPairs()
     PairDesc* d = reinterpret_cast<PairDesc*>(pin.p);
     long long peqWords = 0;
     flatWordSteps_ = 0;
+    flatPeqOff_.resize((size_t)n_);
     for (int u = 0; u < n_; ++u) {
-        const int m = qlen(u), T = tlen(u);
-        const long long nb = (m + 63) / 64;
-        PairDesc& x = d[u];
-        x.qoff = qoff_[u]; x.toff = tbase(u); x.qlen = m; x.tlen = T; x.qstep = 1; x.tstep = 1;
-        // NW: the ring holds every block of the unit, so the band is the whole matrix (threshold max(m, T)); SHW / HW:
-        // columns scoring <= min(k, m) are end-location candidates
-        x.kinit = scanMode == EDLIB_MODE_NW ? std::max(m, T) : ((cfg_.k < 0 || cfg_.k > m) ? m : cfg_.k);
-        x.peqOff = peqWords; peqWords += nb * tab_.sigmaT;
-        x.storeOff = 0; x.auxOff = 0; x.posCap = scanMode == EDLIB_MODE_NW ? 0 : kFlatPosCap; x.posOff = (long long)u * kFlatPosCap;
-        x.colOff = -1; x.bandT = 0; x.skip = 0; x.ring = flatRing_;
-        flatWordSteps_ += 2LL * flatRing_ * ((long long)T + nb - 1);
+        const long long nb = (qlen(u) + 63) / 64;
+        flatPeqOff_[u] = peqWords; peqWords += nb * tab_.sigmaT;
+        d[u] = flatDesc(u);
+        flatWordSteps_ += 2LL * flatRing_ * ((long long)tlen(u) + nb - 1);
     }
     EDLIB_AMD_HIP(d_flatDescs_.alloc((size_t)n_));
     EDLIB_AMD_HIP(hipMemcpyAsync(d_flatDescs_.p, d, (size_t)n_ * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
@@ -1364,7 +1374,38 @@ int Batch::runPairsFlat(bool& overflowed)
         hipLaunchKernelGGL(count_over_kernel, dim3((n_ + 255) / 256), dim3(256), 0, stream_, d_flatOut3_.p + n_, n_, kFlatPosCap, d_flatCensus_.p);
         EDLIB_AMD_HIP(hipMemcpyAsync(h_flatCensus_.p, d_flatCensus_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
         EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-        overflowed = *reinterpret_cast<const int*>(h_flatCensus_.p) > 0;
+        const int novf = *reinterpret_cast<const int*>(h_flatCensus_.p);
+        flatOvfUnit_.clear(); flatOvfOff_.assign(1, 0); flatOvfPos_.clear();
+        if (novf > 0) {
+            // exact second pass for the (rare) units with more end locations than a list keeps: their best score is already
+            // exact, so a scan with threshold = best and a list of the right size finds every location (strip kernel)
+            const size_t n = (size_t)n_;
+            PinBuf sc; EDLIB_AMD_HIP(sc.alloc(2 * n * sizeof(int)));
+            EDLIB_AMD_HIP(hipMemcpyAsync(sc.p, d_flatOut3_.p, 2 * n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+            EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+            const int* score = reinterpret_cast<const int*>(sc.p); const int* count = score + n;
+            std::vector<PairDesc> d2;
+            for (int u = 0; u < n_; ++u)
+                if (count[u] > kFlatPosCap) {
+                    PairDesc x = flatDesc(u);
+                    x.kinit = score[u]; x.posCap = count[u]; x.posOff = flatOvfOff_.back(); x.ring = 0;
+                    d2.push_back(x); flatOvfUnit_.push_back(u); flatOvfOff_.push_back(flatOvfOff_.back() + count[u]);
+                }
+            DevBuf<PairDesc> dd; DevBuf<int> pool2, s2;
+            EDLIB_AMD_HIP(dd.alloc(d2.size())); EDLIB_AMD_HIP(pool2.alloc((size_t)flatOvfOff_.back())); EDLIB_AMD_HIP(s2.alloc(3 * d2.size()));
+            EDLIB_AMD_HIP(hipMemcpyAsync(dd.p, d2.data(), d2.size() * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
+            PairScanArgs a2 = a;
+            a2.descs = dd.p; a2.numUnits = (int)d2.size(); a2.posPool = pool2.p;
+            a2.outScore = s2.p; a2.outCount = s2.p + d2.size(); a2.outLast = s2.p + 2 * d2.size();
+            scanTimerStart();
+            EDLIB_AMD_HIP(launch_scan_pairs(scanMode, false, a2, stream_));
+            scanTimerStop();
+            flatOvfPos_.resize((size_t)flatOvfOff_.back());
+            EDLIB_AMD_HIP(hipMemcpyAsync(flatOvfPos_.data(), pool2.p, flatOvfPos_.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
+            EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+            stats.overflow_units += (int)d2.size();
+            for (const PairDesc& x : d2) stats.word_steps += 2LL * ((x.qlen + 63) / 64) * x.tlen;
+        }
     }
     return 0;
 }
@@ -1381,11 +1422,15 @@ int Batch::collectPairsFlat(std::vector<UnitResult>& res)
     if (npos) EDLIB_AMD_HIP(hipMemcpyAsync(h + 3 * n, d_flatPos_.p, npos * sizeof(int), hipMemcpyDeviceToHost, stream_));
     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
     const int* score = h; const int* count = h + n; const int* pos = h + 3 * n;
+    size_t oi = 0;
     for (size_t u = 0; u < n; ++u) {
         UnitResult& r = res[u];
         r.status = EDLIB_STATUS_OK; r.hasStarts = r.hasAlignment = false;
         if (scanMode == EDLIB_MODE_NW) finalize_global(r, cfg_.k, mode, tlen((int)u), score[u]);
-        else finalize_semiglobal(r, cfg_.k, qlen((int)u), score[u], pos + u * kFlatPosCap, score[u] < 0 ? 0 : std::max(count[u], 0));
+        else if (oi < flatOvfUnit_.size() && flatOvfUnit_[oi] == (int)u) {
+            finalize_semiglobal(r, cfg_.k, qlen((int)u), score[u], flatOvfPos_.data() + flatOvfOff_[oi], flatOvfOff_[oi + 1] - flatOvfOff_[oi]);
+            ++oi;
+        } else finalize_semiglobal(r, cfg_.k, qlen((int)u), score[u], pos + u * kFlatPosCap, score[u] < 0 ? 0 : std::max(count[u], 0));
     }
     if (alphabetLengthsEnd(res)) return 1;
     pairsCollected_ = true;
@@ -1855,7 +1900,7 @@ int Batch::run()
     opsOwned_.clear();
     // TASK_DISTANCE over reads-path units only: nothing is assembled on the host until results() asks for it, so
     // the per-unit records (160 bytes each) are not even allocated in the timed run
-    bool lazy = (cfg_.task == EDLIB_TASK_DISTANCE && pairUnits_.empty() && longUnits_.empty() && emptyUnits_.empty() && !groups_.empty()) || flatPairs_;
+    const bool lazy = (cfg_.task == EDLIB_TASK_DISTANCE && pairUnits_.empty() && longUnits_.empty() && emptyUnits_.empty() && !groups_.empty()) || flatPairs_;
     pairsCollected_ = true;
     // the records of the run before last are recycled (no 160-byte-per-unit allocation + page faults per run)
     std::vector<UnitResult>& res = work_;
@@ -1889,11 +1934,7 @@ int Batch::run()
     if (flatPairs_) {                                   // ---- phase 1 of a flat pair batch: everything stays on the device
         bool over = false;
         if (runPairsFlat(over)) return 1;
-        if (over) {
-            // an end-location list did not fit: this batch takes the general path (exact second pass) from now on
-            flatPairs_ = false; lazy = false;
-            res.assign((size_t)n_, UnitResult{});
-        } else { flatDone = true; pairsCollected_ = false; }
+        flatDone = true; pairsCollected_ = false;
         lap("run: flat pairs");
     }
     // ---- phase 1: distance + end locations

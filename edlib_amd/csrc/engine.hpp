@@ -251,6 +251,9 @@ private:
     DevBuf<PairDesc> d_flatDescs_;
     DevBuf<int> d_flatOut3_, d_flatPos_, d_flatCensus_;
     PinBuf h_flatCensus_;
+    std::vector<long long> flatPeqOff_;
+    std::vector<int> flatOvfUnit_; std::vector<long long> flatOvfOff_; std::vector<int> flatOvfPos_;   // exact lists of the last run's overflowing units
+    PairDesc flatDesc(int u) const;
     int initFlatPairs();
     int runPairsFlat(bool& overflowed);
     int collectPairsFlat(std::vector<UnitResult>& res);

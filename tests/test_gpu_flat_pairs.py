@@ -1,6 +1,6 @@
 """-m gpu: batches of >= 1024 short independent pairs asked for distances take the flat pair path (engine.hip: descriptors
 built once and resident, one ring scan per run, results left in HBM until results()); a batch with an end-location list
-longer than 16 falls back to the general path.  Every field against the reference (native pool), every mode."""
+longer than 16 gets the exact second pass for that unit.  Every field against the reference (native pool), every mode."""
 import numpy as np
 import pytest
 
@@ -26,7 +26,7 @@ def _pairs(n, seed, maxq, repeats=False):
         else:
             q = _ACGT[rng.integers(0, 4, m)]
         qs.append(q); ts.append(t)
-    if repeats:                                           # more than 16 end locations: the whole batch takes the general path
+    if repeats:                                           # more than 16 end locations: that unit gets the exact second pass
         qs[7] = np.frombuffer(b"ACAC", dtype=np.uint8); ts[7] = np.tile(np.frombuffer(b"AC", dtype=np.uint8), 60)
     return qs, ts
 
@@ -56,7 +56,7 @@ def test_flat_pairs_every_mode(engine, mode, maxq):
     _check(engine, qs[:1500], ts[:1500], mode, k=6)
 
 
-def test_overflowing_lists_fall_back(engine):
+def test_overflowing_lists_get_the_exact_second_pass(engine):
     qs, ts = _pairs(2000, 5, 200, repeats=True)
     for mode in ("HW", "SHW"):
         _check(engine, qs, ts, mode)
