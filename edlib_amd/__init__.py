@@ -18,7 +18,8 @@ import re
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libedlib.so")
+# EDLIB_AMD_LIB: another build of the same C ABI (A/B timing of two builds on one box: tools/gpu_visit.sh ab)
+LIB_PATH = os.environ.get("EDLIB_AMD_LIB") or os.path.join(_HERE, "libedlib.so")
 
 EDLIB_MODE = {"NW": 0, "SHW": 1, "HW": 2}
 EDLIB_TASK = {"distance": 0, "locations": 1, "path": 2}

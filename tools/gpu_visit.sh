@@ -14,6 +14,7 @@
 #   latency      build/latency for the engine and the reference
 #   short|path|hwlong|wide   tools/bench_short_pairs.py, bench_path.py, bench_hw_long.py, bench_wide.py
 #   soak         tools/soak.py for SOAK_SECONDS (default 120)
+#   ab           headline step of this build and of AB_LIB (default build/ab/libedlib_r02.so), alternating, on one box
 #   cmd          run $CMD
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 ROOT=$PWD; R=${R:-r03}; OUT=$ROOT/gpurun_out/visit_$R; mkdir -p $OUT; export TMPDIR=/tmp
@@ -70,6 +71,10 @@ for stage in "$@"; do
     hwlong)  timeout 900 python tools/bench_hw_long.py ${HWLONG_ARGS:-} 2>&1 | tee $OUT/${R}_hw_long.json | cut -c1-2500 ;;
     wide)    timeout 600 python tools/bench_wide.py 2>&1 | tee $OUT/${R}_wide_target.json | cut -c1-1500 ;;
     soak)    timeout $(( ${SOAK_SECONDS:-120} + 120 )) python tools/soak.py --seconds ${SOAK_SECONDS:-120} 2>&1 | tail -5 | tee $OUT/${R}_soak.log ;;
+    ab)      # the headline step of two builds of the library on THIS box, alternating (AB_LIB: the other build)
+             for i in 1 2; do for lib in edlib_amd/libedlib.so ${AB_LIB:-build/ab/libedlib_r02.so}; do
+               EDLIB_AMD_LIB=$ROOT/$lib timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-secondary 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$lib', d['ms_per_step'], d['roofline']['scan_ms_per_step'])"
+             done; done | tee $OUT/${R}_ab.log ;;
     cmd)     timeout ${CMD_TIMEOUT:-900} bash -c "$CMD" 2>&1 | tail -${CMD_TAIL:-40} | tee $OUT/${R}_cmd.log ;;
     *) echo "unknown stage $stage" ;;
   esac
