@@ -667,9 +667,6 @@ static_assert(band_height_down<12>(12) <= 12 - 4 && band_height_down<16>(16) <= 
 struct HwTrack {            // per-lane tracking state of the banded kernel
     int best, cnt, cap;
     int* pos;
-    // filter mode (ReadScanArgs::filter, wave-uniform): the threshold stays where it is and the lane lists the 16-column
-    // blocks that hold a column scoring <= best, each once (the piece filter of long reads, engine.hip)
-    int filter;
 };
 
 // Rows carried from quad to quad by the one-word band (the next quad's rows, already in registers); local to a run
@@ -688,7 +685,9 @@ typedef u32 QuadRows[4];
 // S <= k + c; the one unit matters: against unrelated sequence the score 32 rows down hovers around 13, and with
 // k = 6 a wave meets S <= 10 at 0.5 % of its checkpoints but S <= 9 at 0.06 %.)  A new word enters as "+1 per row"
 // like the reference's new block (edlib.cpp:605-608).
-template <int NA, int NWD, int Q, int S, bool CHECK = true, bool CHAIN = false>
+// FILTER (the piece filter of long reads, long_reads.hip; its own instantiation, so that the scans of whole reads carry none of
+// it): the threshold stays where it is and the lane lists the 16-column blocks that hold a column scoring <= best, each once.
+template <int NA, int NWD, int Q, int S, bool CHECK = true, bool CHAIN = false, bool FILTER = false>
 __device__ __forceinline__ int band_quad(const u32 lo, const u32 hi, const u32 nlo, const u32 nhi, QuadRows& qr,
                                          const int colBase, const int colEnd, const bool track, u32 (&Pv)[NWD],
                                          u32 (&Mv)[NWD], int& e, int& flag, HwTrack& tr, const u32 sh, const int lastRows,
@@ -717,7 +716,7 @@ __device__ __forceinline__ int band_quad(const u32 lo, const u32 hi, const u32 n
         }
     }
     if (NA == NWD) {
-        if (track && __builtin_amdgcn_ballot_w64(flag < 0) != 0ull && tr.filter) {   // wave-uniform
+        if (FILTER && track && __builtin_amdgcn_ballot_w64(flag < 0) != 0ull) {   // wave-uniform
             // the four columns of a quad share their 16-column block
             const int blk = colBase >> 4;
             bool hit = false;
@@ -730,7 +729,7 @@ __device__ __forceinline__ int band_quad(const u32 lo, const u32 hi, const u32 n
             if (fresh && tr.cnt < tr.cap) tr.pos[tr.cnt] = blk;
             tr.cnt += fresh ? 1 : 0;
             flag = 0;                                                   // e stays relative to the fixed threshold
-        } else if (track && __builtin_amdgcn_ballot_w64(flag < 0) != 0ull) {   // wave-uniform
+        } else if (!FILTER && track && __builtin_amdgcn_ballot_w64(flag < 0) != 0ull) {   // wave-uniform
             const int bestIn = tr.best;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -820,7 +819,7 @@ typedef u32 u32x8 __attribute__((ext_vector_type(8)));
 
 // S: Peq rows per word = target symbols rounded up to 4, 8 or 16 (a genome with N, soft-masked lower case, IUPAC
 // codes).  LDS per wave = NWD * S * 256 bytes: 8 waves per SIMD at S = 4 and up to 5 words, 4 at S = 8, 2 at S = 16.
-template <int NWD, int S>
+template <int NWD, int S, bool FILTER = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((S == 4 && NWD <= 5) ? 8 : 1, 8)))
 scan_reads_banded_kernel(const ReadScanArgs a)
 {
@@ -855,7 +854,6 @@ scan_reads_banded_kernel(const ReadScanArgs a)
         tr.best = k0 < a.kcap ? k0 : a.kcap;
     }
     tr.cnt = 0;
-    tr.filter = a.filter;
     {
         // lanes past nlanes (the tail of the last wave) own no record: they must not even read the tables
         const long long item = (long long)idx * a.numSegments + blockIdx.y;   // (lane, segment) record
@@ -888,7 +886,7 @@ scan_reads_banded_kernel(const ReadScanArgs a)
     while (b < bend) {
         switch (nw) {
 #define QUAD(NA, Q)                                                                                             \
-            nw = band_quad<(NA <= NWD ? NA : NWD), NWD, Q, S>(cur[2 * Q], cur[2 * Q + 1],                          \
+            nw = band_quad<(NA <= NWD ? NA : NWD), NWD, Q, S, true, false, FILTER>(cur[2 * Q], cur[2 * Q + 1],     \
                      Q < 3 ? cur[(2 * Q + 2) & 7] : nxt[0], Q < 3 ? cur[(2 * Q + 3) & 7] : nxt[1], qr,          \
                      b * 16 + Q * 4, c1, b >= bmain /* warm-up columns record nothing */, Pv, Mv, e, flag, tr,  \
                      sh, lastRows, noChain, noChain);
@@ -969,7 +967,6 @@ scan_reads_full_kernel(const ReadScanArgs a)
     HwTrack tr;
     tr.best = a.kinit[slot];
     tr.cnt = 0;
-    tr.filter = 0;
     {
         const long long item = (long long)idx * a.numSegments + blockIdx.y;
         tr.cap = live ? (a.posCap ? a.posCap[item] : a.cap) : 0;
@@ -1045,6 +1042,15 @@ static hipError_t launch_scan_reads_banded_s(int nwords, const ReadScanArgs& a, 
 {
     const int nrblk = (a.nlanes + 63) / 64;
     dim3 grid(nrblk, a.numSegments), block(64);
+    if (a.filter) {                                               // pieces of long reads: at most 8 words
+        switch (nwords) {
+#define CASE(N) case N: hipLaunchKernelGGL((scan_reads_banded_kernel<N, S, true>), grid, block, 0, stream, a); break;
+            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (nwords) {
 #define CASE(N) case N: hipLaunchKernelGGL((scan_reads_banded_kernel<N, S>), grid, block, 0, stream, a); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
