@@ -70,7 +70,7 @@ for stage in "$@"; do
     path)    timeout 600 python tools/bench_path.py 2>&1 | tee $OUT/${R}_path.json | cut -c1-2000 ;;
     hwlong)  timeout 900 python tools/bench_hw_long.py ${HWLONG_ARGS:-} 2>&1 | tee $OUT/${R}_hw_long.json | cut -c1-2500 ;;
     wide)    timeout 600 python tools/bench_wide.py 2>&1 | tee $OUT/${R}_wide_target.json | cut -c1-1500 ;;
-    soak)    timeout $(( ${SOAK_SECONDS:-120} + 120 )) python tools/soak.py --seconds ${SOAK_SECONDS:-120} 2>&1 | tail -5 | tee $OUT/${R}_soak.log ;;
+    soak)    timeout $(( ${SOAK_SECONDS:-120} + 120 )) python tools/soak.py ${SOAK_SECONDS:-120} ${SOAK_SEED:-3} 2>&1 | tail -5 | tee $OUT/${R}_soak.log ;;
     ab)      # the headline step of two builds of the library on THIS box, alternating (AB_LIB: the other build)
              for i in 1 2; do for lib in edlib_amd/libedlib.so ${AB_LIB:-build/ab/libedlib_r02.so}; do
                EDLIB_AMD_LIB=$ROOT/$lib timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-secondary 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$lib', d['ms_per_step'], d['roofline']['scan_ms_per_step'])"

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Differential soak of the batch entry points against the oracle (test infrastructure) for a time budget: random
-shared-target batches over every read-length group of the lane-per-read kernels (1 .. 1100 bases), random pair
-batches over the ring sizes; every field of every unit is compared.  usage: soak.py [seconds] [seed] [max cases]"""
+shared-target batches over every read-length group of the lane-per-read kernels and the piece filter / chained strips
+above them (1 .. 6000 bases), random pair batches over the ring sizes and the flat pair path, single edlibAlign() calls
+(fused one-pair kernel); every field of every unit is compared.  usage: soak.py [seconds] [seed] [max cases]"""
 import sys, os, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
@@ -16,7 +17,8 @@ rng = np.random.default_rng(seed)
 ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
 FIELDS = ("status", "editDistance", "numLocations", "alphabetLength", "locOff", "ends", "alnOff", "alignment")
 LENS = [1, 5, 31, 32, 33, 64, 65, 100, 150, 160, 161, 255, 256, 257, 258, 300, 383, 384, 385, 400, 511, 512, 513, 600, 767, 768,
-        769, 900, 1023, 1024, 1025, 1100]
+        769, 900, 1023, 1024, 1025, 1100, 1500, 2047, 2048, 2049, 3000, 4097, 6000]
+os.environ.setdefault("EDLIB_AMD_TALL_MIN_WAVES", "1")        # small batches also take the chained strips
 
 
 def mutate(w, m, rate):
@@ -61,6 +63,7 @@ def shared_case():
         lens = [int(rng.choice(LENS))] * nq
     else:
         lens = [int(rng.choice(LENS)) for _ in range(nq)]
+    if max(lens) > 1100: lens = lens[:65]                 # (the reference needs ~0.1 s per such read)
     reads = []
     for m in lens:
         if rng.random() < 0.8 and tn > m + 80:
@@ -79,12 +82,13 @@ def shared_case():
         b.close()
     qoff = np.zeros(len(reads) + 1, dtype=np.int64); qoff[1:] = np.cumsum([len(r) for r in reads])
     ref = O.pool_align(np.concatenate(reads), qoff, target, np.array([0, len(target)], dtype=np.int64), True, mode, task, k)
-    return len(reads), compare(got, ref, task, "shared mode=%s task=%s k=%d tn=%d nq=%d lens=%s" % (mode, task, k, len(target), nq, sorted(set(lens))[:8]))
+    return len(reads), compare(got, ref, task, "shared mode=%s task=%s k=%d tn=%d nq=%d lens=%s" % (mode, task, k, len(target), len(lens), sorted(set(lens))[:8]))
 
 
 def pair_case():
     nq = int(rng.choice([1, 5, 17, 300, 3000]))
     base = int(rng.choice([20, 150, 400, 1000, 3000]))
+    if nq == 3000 and rng.random() < 0.5: base = int(rng.choice([20, 150, 400]))      # the flat pair path (>= 1024 short pairs, distance)
     qs, ts = [], []
     sig = int(rng.choice([2, 4, 4, 4, 20]))
     alpha = np.frombuffer(b"ACGTDEFHIKLMNPQRSVWY", dtype=np.uint8)[:sig]
@@ -113,9 +117,26 @@ def pair_case():
     return nq, compare(got, ref, task, "pairs mode=%s task=%s k=%d nq=%d base=%d sigma=%d" % (mode, task, k, nq, base, sig))
 
 
+def single_case():
+    """edlibAlign() one pair at a time: the fused one-pair kernel and its hand-over to the general path"""
+    from oracle.oracle import load_ref, load_oracle
+    chk = load_ref() or load_oracle()
+    bad = None
+    for _ in range(40):
+        T = int(rng.choice([1, 30, 64, 100, 300, 1000, 4096, 5000])); m = int(rng.choice([1, 20, 64, 65, 100, 150, 500, 1024, 1030]))
+        t = ACGT[rng.integers(0, 4, T)]
+        q = mutate(t[:m + 64].copy(), m, float(rng.choice([0.0, 0.03, 0.2]))) if rng.random() < 0.7 and T >= m else ACGT[rng.integers(0, 4, m)]
+        mode = str(rng.choice(["NW", "HW", "SHW"])); task = str(rng.choice(["distance", "locations", "path"])); k = int(rng.choice([-1, -1, 3, 60]))
+        g = edlib_amd.align_raw(q.tobytes(), t.tobytes(), mode, task, k); w = chk.align(q.tobytes(), t.tobytes(), mode, task, k)
+        if w["status"] != 2 and any(g[f] != w[f] for f in ("status", "editDistance", "endLocations", "startLocations", "numLocations", "alignment", "alphabetLength")):
+            bad = "single mode=%s task=%s k=%d m=%d T=%d" % (mode, task, k, m, T)
+    return 40, bad
+
+
 t0 = time.time(); cases = units = 0; failures = []
 while time.time() - t0 < budget and cases < max_cases:
-    n, err = shared_case() if rng.random() < 0.6 else pair_case()
+    x = rng.random()
+    n, err = shared_case() if x < 0.55 else (pair_case() if x < 0.9 else single_case())
     cases += 1; units += n
     if err:
         failures.append(err); print("MISMATCH", err, file=sys.stderr)
