@@ -367,9 +367,16 @@ scan_pairs_ring_kernel(const PairScanArgs a)
     const bool inRing = uwRaw < U;
     const int uw = inRing ? uwRaw : U - 1;                            // idle lanes alias the last ring's LDS (reads only)
     const int srcAddr = 4 * (lane - rl + (rl == 0 ? G - 1 : rl - 1));
-    const int peqWords = PEQ == 1 ? a.sigmaT * 64 * H : (PEQ == 2 ? U * a.peqFullStride : 0);
+    const int peqWords = PEQ == 1 ? a.sigmaT * 64 * H : (PEQ == 2 ? ((U * a.peqFullStride + 63) & ~63) : 0);   // (a multiple of 512 bytes)
     u64* s_peq = s_dyn + (PEQ == 2 ? uw * a.peqFullStride : 0);
     unsigned short* s_tgt = reinterpret_cast<unsigned short*>(s_dyn + peqWords) + uw * 256;
+    // LDS byte address of the unit's target ring: 512-byte aligned, so that slot (c & 255) is tbase | (2 c & 511) -- one
+    // v_and_or_b32 from a counter that advances by 2 per step
+    const u32 tbase = (u32)(size_t)(__attribute__((address_space(3))) unsigned short*)s_tgt;
+    if (tbase & 511u) __builtin_trap();
+    auto tgt_at = [&](const u32 c2) -> int {
+        return *(const __attribute__((address_space(3))) unsigned short*)(size_t)(tbase | (c2 & 511u));
+    };
     const int unit = blockIdx.x * U + uwRaw;
     const bool have = inRing && unit < a.numUnits;
     const PairDesc* dp = a.descs + (have ? unit : 0);
@@ -463,7 +470,11 @@ scan_pairs_ring_kernel(const PairScanArgs a)
     Block64 B[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) B[h] = Block64{~0u, ~0u, 0u, 0u};
+    // carry word: bit 0 = hout is +1, bit 16 = hout is -1.  The block's bottom score is bscore + (low half of csum) - (high
+    // half): csum simply adds up the carries the lane sends (one add per step), folded into bscore where it is read
     int bscore = 0, sc = 0, carry = 1;
+    u32 csum = 0;
+    auto fold = [&]() { bscore += (int)(csum & 0xffffu) - (int)(csum >> 16); csum = 0; };
     int nsteps = active ? T + nsb : 0;                                // one step past the last block's last: its closing event
     if constexpr (G == 64) nsteps = __builtin_amdgcn_readfirstlane(nsteps);
     else {                                          // the wave runs for its longest unit
@@ -472,7 +483,8 @@ scan_pairs_ring_kernel(const PairScanArgs a)
         for (int u = 0; u < U; ++u) { const int v = __builtin_amdgcn_readlane(nsteps, u * G); w = v > w ? v : w; }
         nsteps = w;
     }
-    int cidx = 0;                                                     // column of the NEXT row-offset fetch (col + 2)
+    const int nstepsU = __builtin_amdgcn_readfirstlane(nsteps);       // (the loop bound in an SGPR)
+    u32 c2 = 0;                                                       // twice the column of the NEXT row-offset fetch (col + 2)
     // vertical deltas summed over the blocks below block h of this lane (score of block h's bottom row = bscore - that)
     auto below_blocks = [&](const int h) {
         int d = 0;
@@ -484,6 +496,7 @@ scan_pairs_ring_kernel(const PairScanArgs a)
 
     // The rare part of a step: some lane's block has just finished (its last update was step t - 1) or starts now.
     auto events = [&](const int t, const int x, u64 (&eqCur)[H], int& offCur) {
+        if constexpr (!STORE) fold();
         const int upScore = ring_ror<G>(bscore, srcAddr);             // upstream's bottom score after step t - 1
         if (ev == 0 && actm) {                                        // ---- closing block b
             const int colLast = t - 1 - b;
@@ -531,12 +544,12 @@ scan_pairs_ring_kernel(const PairScanArgs a)
             for (int h = 0; h < H; ++h) B[h] = Block64{~0u, ~0u, 0u, 0u};    // "+1 per row" (edlib.cpp:759-763, 803-808)
             // bottom of the block above at column col - 1: upstream's bottom after its step minus its delta at `col`
             // (a sender outside its block's life extrapolates by +1 per column, the value its receivers assume)
-            const int above = (col == 0) ? RH * b : upScore - ((x & 1) - ((x >> 1) & 1));
+            const int above = (col == 0) ? RH * b : upScore - ((x & 1) - ((x >> 16) & 1));
             bscore = above + RH;
             if (MODE != 0 && b == nsb - 1) sc = above + lastRows;
             peq_words(s_tgt[col & 255], eqCur);
             offCur = s_tgt[(col + 1) & 255];
-            cidx = col + 2;
+            c2 = 2u * (u32)(col + 2);
             actm = ~0u;
             ev = span + 1;                                            // closes at the top of the step after its last
         }
@@ -550,13 +563,13 @@ scan_pairs_ring_kernel(const PairScanArgs a)
         if (__builtin_amdgcn_ballot_w64(ev == 0) != 0ull) events(t, x, eqCur, offCur);
         --ev;
         peq_words(offCur, eqNxt);
-        offNxt = s_tgt[cidx & 255];
-        ++cidx;
+        offNxt = tgt_at(c2);
+        c2 += 2u;
         // block 0 takes row -1 (+1 per column, 0 for HW: edlib.cpp:584, 779) whatever its ring neighbour sends (in a
         // ring that holds all blocks of its unit the last block's lane feeds lane 0); every other block takes what
         // arrives: its upstream's delta, or the +1 a sender outside its block's life emits
         const u32 xx = __builtin_amdgcn_bitop3_b32((u32)x, xmask, xfix, 0xea /* (a & b) | c */);
-        u32 hp = xx & 1u, hn = xx >> 1;
+        u32 hp = xx & 1u, hn = xx >> 16;
         u32 phT0 = 0, phT1 = 0, mhT0 = 0, mhT1 = 0;                   // horizontal deltas of row m-1's block (MODE != 0)
 #pragma unroll
         for (int h = 0; h < H; ++h) {                                 // top to bottom: the carry stays in the lane
@@ -565,9 +578,10 @@ scan_pairs_ring_kernel(const PairScanArgs a)
             hp = ph1 >> 31; hn = mh1 >> 31;
             if (MODE != 0) { const bool tr = h == hb; phT0 = tr ? ph0 : phT0; phT1 = tr ? ph1 : phT1; mhT0 = tr ? mh0 : mhT0; mhT1 = tr ? mh1 : mhT1; }
         }
-        // carry and block score of a lane outside its block's life: +1 per step
-        carry = (int)__builtin_amdgcn_bitop3_b32(hp | (hn << 1), 1u, actm, 0xe4 /* c ? a : b */);
-        bscore += (int)__builtin_amdgcn_bitop3_b32(hp - hn, 1u, actm, 0xe4);
+        // carry (and with it the block score) of a lane outside its block's life: +1 per step
+        carry = (int)__builtin_amdgcn_bitop3_b32(hp | (hn << 16), 1u, actm, 0xe4 /* c ? a : b */);
+        if constexpr (STORE) bscore += (int)((u32)carry & 1u) - (int)((u32)carry >> 16);
+        else csum += (u32)carry;
         if (STORE || MODE != 0) {
             if (actm) {
                 const int col = t - b;
@@ -593,8 +607,9 @@ scan_pairs_ring_kernel(const PairScanArgs a)
 #pragma unroll
     for (int h = 0; h < H; ++h) { eqA[h] = 0; eqB[h] = 0; }
     int offA = 0, offB = 0;
-    for (int t = 0; t <= nsteps; t += 2) {
+    for (int t = 0; t <= nstepsU; t += 2) {
         if ((t & 63) == 0) {                                          // pace the ring by the largest column in use
+            if constexpr (!STORE) fold();                             // (the halves of csum hold 64 steps with room to spare)
             int bt = t - (RH - 1) - dmax; bt = bt <= 0 ? 0 : (bt + RH) / (RH + 1);
             if (t - T + 1 > bt) bt = t - T + 1;
             const int jmax = t - bt;
@@ -610,7 +625,7 @@ static hipError_t launch_scan_pairs_ring_t(const PairScanArgs& a, hipStream_t st
 {
     constexpr int U = 64 / G;
     const dim3 grid((a.numUnits + U - 1) / U);
-    const size_t full = (size_t)U * a.peqFullStride * sizeof(u64);
+    const size_t full = (((size_t)U * a.peqFullStride + 63) & ~(size_t)63) * sizeof(u64);     // (the target rings start 512-byte aligned)
     const size_t tgt = 512 * U;                                       // 256 row offsets (u16) per unit
     // the whole-Peq mode saves the refills of packed rings, but only pays while LDS does not cap the
     // occupancy (measured: 10 KB per wave costs config 4 a third of its rate); row offsets are 16 bits
