@@ -1009,6 +1009,17 @@ static int peq_row_stride(long long nb) {
     return s;
 }
 
+// the counter the ring kernels of this run add their live word-steps to (zeroed by run(), read back at its end)
+unsigned long long* Batch::ringStepsCounter()
+{
+    if (!d_ringSteps_.p) {
+        if (d_ringSteps_.alloc(1) != hipSuccess || h_ringSteps_.alloc(sizeof(unsigned long long)) != hipSuccess) return nullptr;
+        if (hipMemsetAsync(d_ringSteps_.p, 0, sizeof(unsigned long long), stream_) != hipSuccess) return nullptr;
+    }
+    ringStepsUsed_ = true;
+    return d_ringSteps_.p;
+}
+
 int Batch::solve(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units, SolveOut& out,
                  int ring, int ringH)
 {
@@ -1064,7 +1075,8 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         d.colOff = -1; d.bandT = 0; d.ring = ring;
         if (wantPath) opsOff[i + 1] = opsOff[i] + (long long)s.qlen + s.tlen;
         // executed work: whole matrix, or one 64-block wave per column inside the band
-        stats.word_steps += ring ? 2LL * ring * ringH * ((long long)s.tlen + (nb + ringH - 1) / ringH - 1) : 2 * nb * (long long)s.tlen;
+        // executed work: the strips update every block of every column; the rings count the updates inside the band themselves
+        if (!ring) stats.word_steps += 2 * nb * (long long)s.tlen;
     }
     // A handful of units (edlibAlign() is one): the kernels write scores, positions and op strings straight into
     // device-visible pinned host memory -- no download commands behind the launches, one stream synchronisation.
@@ -1126,6 +1138,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     a.store = d_store_.p;
     a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p; a.posPool = d_posPool_.p;
     a.colP = nullptr; a.colM = nullptr; a.colS = nullptr;
+    a.wordSteps = ring ? ringStepsCounter() : nullptr;
     scanTimerStart();
     if (ring) EDLIB_AMD_HIP(launch_scan_pairs_ring(ring, mode, wantPath, a, stream_, ringH));
     else EDLIB_AMD_HIP(launch_scan_pairs(mode, wantPath, a, stream_));
@@ -1330,13 +1343,11 @@ int Batch::initFlatPairs()
     EDLIB_AMD_HIP(pin.alloc((size_t)n_ * sizeof(PairDesc)));
     PairDesc* d = reinterpret_cast<PairDesc*>(pin.p);
     long long peqWords = 0;
-    flatWordSteps_ = 0;
     flatPeqOff_.resize((size_t)n_);
     for (int u = 0; u < n_; ++u) {
         const long long nb = (qlen(u) + 63) / 64;
         flatPeqOff_[u] = peqWords; peqWords += nb * tab_.sigmaT;
         d[u] = flatDesc(u);
-        flatWordSteps_ += 2LL * flatRing_ * ((long long)tlen(u) + nb - 1);
     }
     EDLIB_AMD_HIP(d_flatDescs_.alloc((size_t)n_));
     EDLIB_AMD_HIP(hipMemcpyAsync(d_flatDescs_.p, d, (size_t)n_ * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
@@ -1364,10 +1375,10 @@ int Batch::runPairsFlat(bool& overflowed)
     a.peqFullStride = (int)std::min<long long>((long long)a.peqRowStride * tab_.sigmaT, 1 << 20);
     a.store = nullptr;
     a.outScore = d_flatOut3_.p; a.outCount = d_flatOut3_.p + n_; a.outLast = d_flatOut3_.p + 2 * (size_t)n_; a.posPool = d_flatPos_.p;
+    a.wordSteps = ringStepsCounter();
     scanTimerStart();
     EDLIB_AMD_HIP(launch_scan_pairs_ring(flatRing_, scanMode, false, a, stream_));
     scanTimerStop();
-    stats.word_steps += flatWordSteps_;
     overflowed = false;
     if (scanMode != EDLIB_MODE_NW) {
         EDLIB_AMD_HIP(hipMemsetAsync(d_flatCensus_.p, 0, sizeof(int), stream_));
@@ -1499,7 +1510,7 @@ int Batch::hirschbergLevel(const std::vector<PathPiece>& big, std::vector<int>& 
             d.peqOff = peqWords; peqWords += nb * tab_.sigmaT;
             d.auxOff = auxInts; if (nb > 64 && !banded) auxInts += d.tlen;
             d.colOff = colBlocks; colBlocks += nb;
-            stats.word_steps += banded ? 2LL * ring * ((long long)d.tlen + nb - 1) : 2 * nb * (long long)d.tlen;
+            if (!banded) stats.word_steps += 2 * nb * (long long)d.tlen;
         }
     }
     const size_t n = descs.size();
@@ -1530,6 +1541,7 @@ int Batch::hirschbergLevel(const std::vector<PathPiece>& big, std::vector<int>& 
         a.peqFullStride = (int)std::min<long long>((long long)a.peqRowStride * tab_.sigmaT, 1 << 20);
     }
     a.colP = colP.p; a.colM = colM.p; a.colS = colS.p;
+    a.wordSteps = ringStepsCounter();
     size_t first = 0;
     for (int g = 0; g <= kNumRings; ++g) {
         if (!groupCount[g]) continue;
@@ -1830,13 +1842,21 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
     // lanes costs G / 64 of a wave per unit, so trying the smaller ring first pays as long as fewer than a quarter
     // to a half of the units fail on it and move up: the estimate is the mean plus half a sigma (10 kb pairs at
     // 11.4 % sit under the 21-lane ring's 1216 -- three units per wave instead of two -- and the 7 % above it rerun).
+    // (est = mean + sqrt(mean) / 2 + 8 <= cap is a bound on the mean: solved once per level, so that a unit costs a
+    // multiply-add and a few compares -- the square root per unit was 2 ms of host time per 100,000 units)
+    double meanCap[kNumRings + 1];
+    auto mean_cap = [](double cap) { if (cap < 8) return -1.0; const double r = (-0.5 + std::sqrt(0.25 + 4.0 * (cap - 8.0))) / 2.0; return r * r; };
+    for (int l = 0; l < nl; ++l) meanCap[l] = mean_cap(std::min<double>(cap_of(l), kcap));
+    meanCap[nl] = mean_cap(2.0 * ring_max_k(64));
+    int levelOfKcap = nl;                                               // est = kcap when the caller's k is the smaller one
+    for (int l = nl - 1; l >= 0; --l) if (kcap <= cap_of(l)) levelOfKcap = l;
     auto first_level = [&](size_t i) {
         const UnitSpec& u = units[i];
         const double mean = rate * std::min(u.qlen, u.tlen) + std::abs(u.qlen - u.tlen);
-        const double est = std::min<double>(kcap, mean + 0.5 * std::sqrt(mean) + 8);
+        const int nbI = blocks(i);
         for (int l = 0; l < nl; ++l)
-            if (blocks(i) <= blocks_of(l) || est <= cap_of(l)) return l;
-        return est <= 2.0 * ring_max_k(64) ? nl - 1 : nl;               // far above every band: straight to the strips
+            if (nbI <= blocks_of(l) || mean <= meanCap[l] || l >= levelOfKcap) return l;
+        return (mean <= meanCap[nl] || kcap <= 2.0 * ring_max_k(64)) ? nl - 1 : nl;   // far above every band: straight to the strips
     };
     std::vector<int>& lvl = lvlScratch_;
     lvl.resize(n);
@@ -1919,6 +1939,8 @@ int Batch::run()
     const int mode = (int)cfg_.mode;
     const int scanMode = (mode == EDLIB_MODE_HW || mode == EDLIB_MODE_SHW) ? mode : EDLIB_MODE_NW;
     EDLIB_AMD_HIP(hipEventRecord(evRun0_.e, stream_));
+    if (d_ringSteps_.p) EDLIB_AMD_HIP(hipMemsetAsync(d_ringSteps_.p, 0, sizeof(unsigned long long), stream_));
+    ringStepsUsed_ = false;
     Lap lap;
 
     // ---- empty sequences: answered without any DP (edlib.cpp:166-184)
@@ -2097,8 +2119,10 @@ int Batch::run()
         }
     }
     lap("run: phase 3 (paths)");
+    if (ringStepsUsed_) EDLIB_AMD_HIP(hipMemcpyAsync(h_ringSteps_.p, d_ringSteps_.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
     EDLIB_AMD_HIP(hipEventRecord(evRun1_.e, stream_));
     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+    if (ringStepsUsed_) stats.word_steps += (long long)*reinterpret_cast<unsigned long long*>(h_ringSteps_.p);
     float ms = 0;
     EDLIB_AMD_HIP(hipEventElapsedTime(&ms, evRun0_.e, evRun1_.e));
     stats.run_ms = ms;

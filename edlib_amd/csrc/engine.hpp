@@ -162,6 +162,8 @@ private:
     DevBuf<uint32_t> d_tpk_, d_trows_;
     DevBuf<unsigned long long> d_wordSteps_;
     PinBuf h_wordSteps_; bool wordStepsPending_ = false;
+    DevBuf<unsigned long long> d_ringSteps_; PinBuf h_ringSteps_; bool ringStepsUsed_ = false;   // live word-steps of the ring kernels of a run
+    unsigned long long* ringStepsCounter();
     bool banded_ = false;        // HW groups use the Ukkonen-banded kernel with k-doubling
     int syms_ = 4;               // Peq rows per word of the reads kernels: target symbols rounded up to 4, 8 or 16
     int packTarget();
@@ -247,7 +249,6 @@ private:
     // run is Peq build + ONE ring scan + an overflow census, results stay in HBM until results() (like the reads path)
     bool flatPairs_ = false, pairsCollected_ = true;
     int flatRing_ = 0;
-    long long flatWordSteps_ = 0;
     DevBuf<PairDesc> d_flatDescs_;
     DevBuf<int> d_flatOut3_, d_flatPos_, d_flatCensus_;
     PinBuf h_flatCensus_;

@@ -485,6 +485,7 @@ scan_pairs_ring_kernel(const PairScanArgs a)
     }
     const int nstepsU = __builtin_amdgcn_readfirstlane(nsteps);       // (the loop bound in an SGPR)
     u32 c2 = 0;                                                       // twice the column of the NEXT row-offset fetch (col + 2)
+    u32 liveSteps = 0;                                                // steps this lane spends inside a block's life
     // vertical deltas summed over the blocks below block h of this lane (score of block h's bottom row = bscore - that)
     auto below_blocks = [&](const int h) {
         int d = 0;
@@ -552,6 +553,7 @@ scan_pairs_ring_kernel(const PairScanArgs a)
             c2 = 2u * (u32)(col + 2);
             actm = ~0u;
             ev = span + 1;                                            // closes at the top of the step after its last
+            liveSteps += (u32)(span + 1);
         }
     };
 
@@ -617,6 +619,12 @@ scan_pairs_ring_kernel(const PairScanArgs a)
         }
         step(t, eqA, eqB, offA, offB);
         step(t + 1, eqB, eqA, offB, offA);
+    }
+    if (a.wordSteps) {                                                // live 32-row word-columns of the wave: one atomic
+        u32 v = liveSteps;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += (u32)__shfl_xor((int)v, off, 64);
+        if (lane == 0 && v) atomicAdd(a.wordSteps, (unsigned long long)v * (2ull * H));
     }
 }
 

@@ -62,6 +62,9 @@ struct PairScanArgs {
     unsigned long long* colP;
     unsigned long long* colM;
     int* colS;
+    // ring kernel: += 32-row word-columns of blocks INSIDE their life (the band), i.e. without the updates a lane runs on
+    // dead state between two blocks (may be null)
+    unsigned long long* wordSteps;
 };
 
 // mode: 0 NW, 1 SHW, 2 HW.  store: also write the column store.
