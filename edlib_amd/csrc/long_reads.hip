@@ -250,7 +250,10 @@ int Batch::solveLongReads(std::vector<UnitResult>& res, std::vector<int>& fallba
                     else w[nw++] = w[q];
                 }
                 w.resize(nw);
-                if (nw > (size_t)kMaxWindows) { level[i] = -2; fallback.push_back(u); continue; }
+                // windows that together cover most of the target cost more than one scan of it (each drags m + k columns of warm-up)
+                long long cover = 0;
+                for (size_t q = 0; q < nw; ++q) cover += (long long)w[q].second - w[q].first + 1 + m + k;
+                if (nw > (size_t)kMaxWindows || cover > (long long)T) { level[i] = -2; fallback.push_back(u); continue; }
                 for (size_t q = 0; q < nw; ++q) {
                     const int start = (int)std::max<long long>(0, (long long)w[q].first - m - k);
                     UnitSpec v{qoff_[u], m, 1, tbase(u) + start, w[q].second - start + 1, 1, k};
