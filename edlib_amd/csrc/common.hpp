@@ -41,6 +41,7 @@ void pool_quarantine(bool on);
 void pool_trim();
 hipError_t pool_stream(hipStream_t* s);
 void pool_stream_release(hipStream_t s);
+void pool_stream_put(int device, hipStream_t s);      // no HIP call: for destructors that may run at process exit
 
 // Device allocation that frees itself.  Never holds host-visible result memory:
 // everything handed to the caller is libc malloc() (reference ownership rules,

@@ -161,6 +161,15 @@ hipError_t pool_stream(hipStream_t* s) {
     return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
 
+// hands a stream of device `dev` back without touching the HIP runtime (destructors of thread-local contexts run at
+// thread / process exit, when the runtime may be on its way out): the stream is cached or simply left to the process
+void pool_stream_put(int dev, hipStream_t s) {
+    if (dev >= 0 && dev < Pool::kMaxDev) {
+        std::lock_guard<std::mutex> g(pool().mu);
+        if (pool().streams[dev].size() < 16) pool().streams[dev].push_back(s);
+    }
+}
+
 void pool_stream_release(hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);

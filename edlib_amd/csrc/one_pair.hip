@@ -278,7 +278,8 @@ struct OneCtx {
     hipStream_t stream = nullptr;
     PinBuf in, out;
     bool attr = false;
-    ~OneCtx() { if (stream) { DeviceGuard g(device); (void)hipStreamSynchronize(stream); pool_stream_release(stream); } }
+    // (runs at thread exit, for the main thread at process exit: no HIP call here; every call ended with a stream synchronisation)
+    ~OneCtx() { if (stream) pool_stream_put(device, stream); }
 };
 
 }  // namespace
