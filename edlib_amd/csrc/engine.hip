@@ -648,6 +648,9 @@ int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, i
     ReadScanArgs a{};
     // peqDense / qlenDense (+ d_kinit): rows rebuilt for exactly the lanes of this launch, in lane order (pass 2)
     a.peq = peqDense ? peqDense : g.d_peq.p; a.tpk = d_tpk_.p; a.trows = d_trows_.p; a.targetLength = tlen(0);
+    // SHW (prefix mode: row -1 is 0, 1, 2, ...): D[m][j] >= j - m, and the best score never exceeds m (the empty prefix), so
+    // no column beyond 2m can tie it -- the scan stops there instead of walking the whole shared target
+    if (mode == EDLIB_MODE_SHW) a.targetLength = (int)std::min<long long>(a.targetLength, 64LL * g.nwords + 1);
     a.qlen = qlenDense ? qlenDense : g.d_qlen.p; a.kinit = d_kinit; a.slotmap = d_slotmap; a.nlanes = nlanes;
     a.numSegments = numSegments; a.segLen = segLen; a.warm = warm;
     a.segBest = segBest; a.segCnt = segCnt; a.segPos = segPos; a.cap = cap;
@@ -1365,7 +1368,8 @@ PairDesc Batch::flatDesc(int u) const
 {
     const int mode = (int)cfg_.mode;
     const int scanMode = (mode == EDLIB_MODE_HW || mode == EDLIB_MODE_SHW) ? mode : EDLIB_MODE_NW;
-    const int m = qlen(u), T = tlen(u);
+    const int m = qlen(u);
+    const int T = scanMode == EDLIB_MODE_SHW ? (int)std::min<long long>(tlen(u), 2LL * m + 1) : tlen(u);   // (SHW: nothing beyond column 2m can tie the best)
     PairDesc x{};
     x.qoff = qoff_[u]; x.toff = tbase(u); x.qlen = m; x.tlen = T; x.qstep = 1; x.tstep = 1;
     // NW: the ring holds every block of the unit, so the band is the whole matrix (threshold max(m, T)); SHW / HW:
@@ -2065,7 +2069,9 @@ int Batch::run()
         units.resize(pairUnits_.size());
         for (size_t i = 0; i < units.size(); ++i) {
             const int u = pairUnits_[i], m = qlen(u);
-            units[i] = UnitSpec{qoff_[u], m, 1, tbase(u), tlen(u), 1,
+            // (SHW: D[m][j] >= j - m > m >= best beyond column 2m: the rest of a long target cannot matter)
+            const int T = scanMode == EDLIB_MODE_SHW ? (int)std::min<long long>(tlen(u), 2LL * m + 1) : tlen(u);
+            units[i] = UnitSpec{qoff_[u], m, 1, tbase(u), T, 1,
                                 (cfg_.k < 0 || cfg_.k > m) ? m : cfg_.k};
         }
         SolveOut& so = soMain_;

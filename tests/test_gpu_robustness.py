@@ -188,3 +188,28 @@ def test_callers_device_and_env_device(engine, oracle, monkeypatch):
     assert current() == 0
     engine.lib().edlibAmdTrim()
     assert engine.align_raw(q, t, "HW", "path", -1) == want          # the cache refills after a trim
+
+
+def test_shw_against_long_targets_stops_at_2m(engine, checker):
+    """prefix mode: D[m][j] >= j - m, so nothing beyond column 2m can tie the best score -- the scans stop there (reads
+    against a long shared target, pairs with long targets, the flat pair path); every field still equals the reference"""
+    import numpy as np
+    from edlib_amd import synth
+    target = synth.random_dna(301, 300_000)
+    rng = np.random.default_rng(302)
+    reads = []
+    for m in (1, 31, 64, 150, 255, 256, 300, 700):
+        reads.append(target[:m].copy())                                   # prefix itself: distance 0, end m - 1
+        r = target[3:3 + m].copy(); r[::7] = ord("A"); reads.append(r)
+        reads.append(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, m)])
+    for task in ("distance", "locations", "path"):
+        got = engine.align_batch([r.tobytes() for r in reads], target.tobytes(), mode="SHW", task=task, raw=True)
+        for r, g in zip(reads, got):
+            want = checker.align(r.tobytes(), target.tobytes(), "SHW", task, -1)
+            assert all(g[f] == want[f] for f in ("status", "editDistance", "endLocations", "startLocations", "numLocations", "alignment", "alphabetLength")), (task, len(r))
+    qs = [r.tobytes() for r in reads] * 150                                # 3600 pairs: the flat pair path
+    ts = [target[:5000 + 13 * i].tobytes() for i in range(len(qs))]
+    got = engine.align_pairs(qs, ts, mode="SHW", task="distance", raw=True)
+    for i in range(0, len(qs), 37):
+        want = checker.align(qs[i], ts[i], "SHW", "distance", -1)
+        assert got[i]["editDistance"] == want["editDistance"] and got[i]["endLocations"] == want["endLocations"], i
