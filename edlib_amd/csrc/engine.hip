@@ -1389,9 +1389,10 @@ int Batch::initFlatPairs()
     if ((int)pairUnits_.size() != n_ || n_ < 1024) return 0;       // (a handful of units: the zero-copy path of solveChunk)
     const int mode = (int)cfg_.mode;
     const int scanMode = (mode == EDLIB_MODE_HW || mode == EDLIB_MODE_SHW) ? mode : EDLIB_MODE_NW;
-    int maxBlocks = 0;
-    for (int u = 0; u < n_; ++u) maxBlocks = std::max(maxBlocks, (qlen(u) + 63) / 64);
-    if (maxBlocks > 16) return 0;
+    int maxBlocks = 0, maxT = 0;
+    for (int u = 0; u < n_; ++u) { maxBlocks = std::max(maxBlocks, (qlen(u) + 63) / 64); maxT = std::max(maxT, tlen(u)); }
+    // (long targets: the general path cuts HW targets into segments when the batch alone does not fill the chip)
+    if (maxBlocks > 16 || maxT > 65536) return 0;
     flatRing_ = maxBlocks <= 4 ? 4 : 16;
     PinBuf pin;
     EDLIB_AMD_HIP(pin.alloc((size_t)n_ * sizeof(PairDesc)));
