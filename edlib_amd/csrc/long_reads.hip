@@ -8,7 +8,7 @@
 // lanes on a short band.  So the scan is split where the band itself splits:
 //
 //   1. FILTER (kernel A, `ReadScanArgs::filter`): the query is cut into p parts and the first <= 256 rows of every part
-//      ("piece") are scanned against the whole target with the fixed threshold kp = floor(k / p).  An alignment of the
+//      ("piece") are scanned against the whole target with the fixed threshold kp = floor(k / p) <= 56.  An alignment of the
 //      whole query with cost <= k spends at most kp on one of the p parts (pigeonhole), hence at most kp on that
 //      part's piece, and the piece's HW score at the column where the alignment leaves the piece's last row is <= kp:
 //      every end column j of the query with D[m][j] <= k lies within k of (candidate column) + (rows below the piece).
@@ -163,7 +163,7 @@ int Batch::solveLongReads(std::vector<UnitResult>& res, std::vector<int>& fallba
     if (!n) return 0;
     stats.path |= 4;
     const int T = tlen(0);
-    static const int kpMax = getenv("EDLIB_AMD_FILTER_KP") ? std::max(1, atoi(getenv("EDLIB_AMD_FILTER_KP"))) : 40;
+    static const int kpMax = getenv("EDLIB_AMD_FILTER_KP") ? std::max(1, atoi(getenv("EDLIB_AMD_FILTER_KP"))) : 56;   // (24 / 40 / 56 measured: 494 / 446 / 427 ms per 2,048 ONT-like 10 kb reads)
     static const bool dbg = getenv("EDLIB_AMD_DEBUG") != nullptr;
     auto kmax_of = [&](int m) { return (cfg_.k < 0 || cfg_.k > m) ? m : cfg_.k; };     // HW clamps k to m (edlib.cpp:566-568)
 

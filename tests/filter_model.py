@@ -13,7 +13,7 @@ bottom_row() is the textbook DP (reference semantics, SURVEY.md §8a-1: D[i][-1]
 import numpy as np
 
 PIECE_ROWS = 256
-KP_MAX = 40
+KP_MAX = 56
 
 
 def bottom_row(q, t, rows=None):

@@ -72,16 +72,16 @@ def test_ladder_answers_equal_the_reference(oracle, seed):
 
 
 def test_plan_with_the_library_constants():
-    """256-row pieces, thresholds up to 40: the fewest parts whose threshold fits, pieces never overlap, handed back when a
+    """256-row pieces, thresholds up to 56: the fewest parts whose threshold fits, pieces never overlap, handed back when a
     quarter of the piece would be errors"""
     for m in (257, 300, 512, 1025, 4096, 10000, 100000):
-        for k in (0, 8, 40, 41, 128, 700, 1500, m // 3, m):
+        for k in (0, 8, 56, 57, 128, 700, 1500, m // 3, m):
             p = F.plan_level(m, k)
-            assert p["kp"] <= 40 and p["p"] * p["part"] <= m and p["rows"] <= min(256, p["part"])
-            assert (p["p"] == 1) or (k // (p["p"] - 1) > 40)          # one part fewer would exceed the threshold cap
+            assert p["kp"] <= 56 and p["p"] * p["part"] <= m and p["rows"] <= min(256, p["part"])
+            assert (p["p"] == 1) or (k // (p["p"] - 1) > 56)          # one part fewer would exceed the threshold cap
             if p["ok"]:
                 assert 4 * p["kp"] <= p["rows"]
-    assert F.plan_level(10000, 128)["p"] == 4 and F.plan_level(10000, 128)["kp"] == 32
+    assert F.plan_level(10000, 128)["p"] == 3 and F.plan_level(10000, 128)["kp"] == 42
     assert not F.plan_level(300, 200)["ok"] and F.plan_level(1025, 16)["p"] == 1
 
 

@@ -76,7 +76,8 @@ def leg_gpu(args):
     np.savez_compressed(args.out, editDistance=f["editDistance"].astype(np.int32), numLocations=f["numLocations"].astype(np.int32),
                         alphabetLength=f["alphabetLength"].astype(np.int32), status=f["status"].astype(np.int32),
                         locOff=f["locOff"].astype(np.int64), ends=f["ends"].astype(np.int32),
-                        sha256=np.frombuffer(digest(target, reads).encode(), dtype=np.uint8))
+                        sha256=np.frombuffer(digest(target, reads).encode(), dtype=np.uint8),
+                        commit=np.frombuffer((open(os.path.join(ROOT, ".visit_commit")).read().strip() if os.path.exists(os.path.join(ROOT, ".visit_commit")) else "unknown").encode(), dtype=np.uint8))
     print("[gpu] %d units written to %s" % (len(reads), args.out))
 
 
@@ -85,7 +86,8 @@ def leg_compare(args):
     g = np.load(args.gpu)
     gsha = bytes(g["sha256"]).decode()
     n = meta["units"]
-    out = {"config": 2, "units": n, "inputs_sha256": meta["sha256"], "inputs_equal": gsha == meta["sha256"],
+    out = {"config": 2, "units": n, "engine_commit": bytes(g["commit"]).decode() if "commit" in g.files else "7486eea (first visit of round 3)",
+           "inputs_sha256": meta["sha256"], "inputs_equal": gsha == meta["sha256"],
            "fields": "status, editDistance, numLocations, alphabetLength, every endLocation", "checked": 0, "bit_exact": 0,
            "failing_units": [], "reference": "oracle/_ref/libedlib_ref.so (unmodified /root/reference/edlib/src/edlib.cpp)"}
     wall = 0.0
