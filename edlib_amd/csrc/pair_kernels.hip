@@ -751,20 +751,26 @@ hipError_t launch_hirschberg_split(const SplitArgs& a, hipStream_t stream)
 // with one WAVE per unit and the walk's window of the store kept on chip were both slower at config 5's shape
 // (10,000 x 1 kb: 0.89 ms here): window in LDS 1.31 ms (three LDS round trips per step), window in registers with
 // the whole walk in the scalar unit 1.66 ms (39 waves per CU share one scalar ALU).
-// Round 3 measured two ways of paying fewer memory latencies per walk, both slower than this plain version (0.88 ms at
-// config 5's shape): a per-lane line cache in LDS (four columns per fetch) misses lane by lane, so the wave still stalls at
-// every step (1.37 ms); fetching an 8-column x 2-block window per lane all together removes the stalls but costs 32
-// scattered loads per lane and window -- the address path, not the latency, then bounds it (1.18 ms).
+// The walk is a pointer chase through a store that lives in HBM: round 2 paid one dependent 32-byte load (~0.9 us) per
+// column.  Two on-chip variants of round 3 lost (a per-lane line cache in LDS misses lane by lane, so the wave still stalls at
+// every step: 1.37 ms against 0.88 at config 5's shape; an 8-column x 2-block window fetched by all lanes together costs
+// 32 scattered loads per lane and window: 1.18 ms).  What works is a SOFTWARE PIPELINE per lane: the walk consumes the
+// columns of a block row strictly from right to left, so the entries of the next kDepth columns are requested ahead into a
+// ring of registers (slot j is consumed in sub-iteration j of an unrolled loop and refilled right away: the hardware's
+// in-order vmcnt lets the wave wait for exactly that load and no younger one); every lane takes its up-moves and then one
+// column per sub-iteration, so all lanes pop the same slot together.  A lane whose walk leaves its block row waits for the
+// top of the loop, where the ring is refilled with kDepth + 2 loads in flight at once.
+constexpr int kDepth = 8;
 __global__ void __launch_bounds__(64)
 traceback_kernel(const TracebackArgs a)
 {
     const int unit = blockIdx.x * blockDim.x + threadIdx.x;
-    if (unit >= a.numUnits) return;
-    const PairDesc d = a.descs[unit];
+    const bool have = unit < a.numUnits;
+    const PairDesc d = a.descs[have ? unit : 0];
     const int m = d.qlen, T = d.tlen, nb = num_blocks(m);
-    uint8_t* ops = a.ops + a.opsOff[unit];
+    uint8_t* ops = a.ops + a.opsOff[have ? unit : 0];
     int w = m + T;                                  // next write index is --w
-    int r = m - 1, c = T - 1, cur = a.score[unit];
+    int r = m - 1, c = T - 1, cur = have ? a.score[unit] : 0;
     const StoreEntry* S = a.store + d.storeOff;
     // ring layout (scan_pairs_ring_kernel): only the blocks inside the band of threshold kinit exist.
     // The walk stays on cells of optimal paths, which are inside the band and exact; a neighbour outside
@@ -778,54 +784,84 @@ traceback_kernel(const TracebackArgs a)
     }
     const int kInf = 0x3fffffff;
     // a unit whose scan ended above its threshold has no exact cells to walk on (it is rescanned at the next level)
-    if (G && cur > d.kinit) { a.opsLen[unit] = 0; return; }
-    auto entry = [&](int col, int blk) -> const StoreEntry& {
-        return S[G ? ring_index(G, T, col, blk) : store_index(T, nb, col, blk)];
+    const bool skip = !have || (G && cur > d.kinit);
+    bool done = skip;
+    auto addr = [&](int col, int blk) -> const StoreEntry* {
+        return S + (G ? ring_index(G, T, col, blk) : store_index(T, nb, col, blk));
     };
-    // the walk keeps the block of the current column and of the column to its left in registers: a step
-    // to the left or along the diagonal inside a block shifts them and fetches one new entry
-    int hb = -1, hc = -2;                            // block / column the registers describe (hc = current column)
+    int hb = -1;                                     // block row the registers and the ring describe
     u64 Pc = 0, Mc = 0, Pl = 0, Ml = 0; int Sl = 0; bool leftIn = false;
-    for (;;) {
-        const int b = r >> 6, bit = r & 63;
-        if (b != hb || c != hc) {
-            if (b == hb && c == hc - 1 && leftIn) { Pc = Pl; Mc = Ml; }
-            else { const StoreEntry e = entry(c, b); Pc = e.p; Mc = e.m; }
+    uint4 fpm[kDepth]; int fs[kDepth];               // the ring: (P, M) and block score of columns fcol, fcol - 1, ...
+    int fcol = -1;                                   // column of the entry the next pop returns
+    bool flush = !skip;
+    while (__builtin_amdgcn_ballot_w64(!done) != 0ull) {
+        if (!done && flush) {                        // ---- (re)fill: current column, its left neighbour, kDepth columns ahead
+            const int b = r >> 6;
+            const StoreEntry* e0 = addr(c, b);
+            const uint4 pm0 = *reinterpret_cast<const uint4*>(&e0->p);
             leftIn = c > 0 && (!G || c - 1 >= 64 * b + dmin);          // block b exists in column c-1
-            if (leftIn) { const StoreEntry e = entry(c - 1, b); Pl = e.p; Ml = e.m; Sl = e.s; }
-            hb = b; hc = c;
+            uint4 pm1 = {0, 0, 0, 0}; int s1 = 0;
+            if (leftIn) { const StoreEntry* e1 = addr(c - 1, b); pm1 = *reinterpret_cast<const uint4*>(&e1->p); s1 = e1->s; }
+#pragma unroll
+            for (int j = 0; j < kDepth; ++j) {
+                const int col = c - 2 - j;
+                if (col >= 0) { const StoreEntry* e = addr(col, b); fpm[j] = *reinterpret_cast<const uint4*>(&e->p); fs[j] = e->s; }
+            }
+            Pc = ((u64)pm0.y << 32) | pm0.x; Mc = ((u64)pm0.w << 32) | pm0.z;
+            Pl = ((u64)pm1.y << 32) | pm1.x; Ml = ((u64)pm1.w << 32) | pm1.z; Sl = s1;
+            fcol = c - 2; hb = b; flush = false;
         }
-        const int u = cur - ((int)((Pc >> bit) & 1ull) - (int)((Mc >> bit) & 1ull));
-        int l, ul;
-        if (c == 0) { l = r + 1; ul = r; }          // column -1 boundary (:976-980)
-        else if (leftIn) {
-            const u64 above = (bit == 63) ? 0ull : (~0ull << (bit + 1));   // rows below r in the block
-            l = Sl - __popcll(Pl & above) + __popcll(Ml & above);
-            ul = l - ((int)((Pl >> bit) & 1ull) - (int)((Ml >> bit) & 1ull));
-        } else {                                     // left edge of the band: only the diagonal neighbour may
-            l = kInf;                                // exist, as the bottom cell of the block above
-            ul = (bit == 0 && b > 0) ? entry(c - 1, b - 1).s : kInf;
-        }
-        if (u + 1 == cur) {                          // up: INSERT
-            cur = u;
-            ops[--w] = 1;
-            if (r == 0) { for (int i = 0; i < c + 1; ++i) ops[--w] = 2; break; }
-            --r;
-        } else if (l + 1 == cur) {                   // left: DELETE
-            cur = l;
-            ops[--w] = 2;
-            --c;
-            if (c == -1) { for (int i = 0; i < r + 1; ++i) ops[--w] = 1; break; }
-        } else {                                     // diagonal: MATCH / MISMATCH
-            ops[--w] = (ul == cur) ? 0 : 3;
-            cur = ul;
-            --c;
-            if (c == -1) { for (int i = 0; i < r; ++i) ops[--w] = 1; break; }
-            if (r == 0) { for (int i = 0; i < c + 1; ++i) ops[--w] = 2; break; }
-            --r;
+#pragma unroll
+        for (int j = 0; j < kDepth; ++j) {
+            bool took = false;                       // this lane consumed a column in this sub-iteration
+            while (!done && !flush) {
+                const int b = r >> 6, bit = r & 63;
+                if (b != hb) { flush = true; break; }                      // the walk left its block row: refill at the top
+                const int u = cur - ((int)((Pc >> bit) & 1ull) - (int)((Mc >> bit) & 1ull));
+                int l, ul;
+                if (c == 0) { l = r + 1; ul = r; }          // column -1 boundary (:976-980)
+                else if (leftIn) {
+                    const u64 above = (bit == 63) ? 0ull : (~0ull << (bit + 1));   // rows below r in the block
+                    l = Sl - __popcll(Pl & above) + __popcll(Ml & above);
+                    ul = l - ((int)((Pl >> bit) & 1ull) - (int)((Ml >> bit) & 1ull));
+                } else {                                     // left edge of the band: only the diagonal neighbour may
+                    l = kInf;                                // exist, as the bottom cell of the block above
+                    ul = (bit == 0 && b > 0) ? addr(c - 1, b - 1)->s : kInf;
+                }
+                if (u + 1 == cur) {                          // up: INSERT (stays in the column)
+                    cur = u;
+                    ops[--w] = 1;
+                    if (r == 0) { for (int i = 0; i < c + 1; ++i) ops[--w] = 2; done = true; break; }
+                    --r;
+                    continue;
+                }
+                if (l + 1 == cur) {                          // left: DELETE
+                    cur = l;
+                    ops[--w] = 2;
+                    --c;
+                    if (c == -1) { for (int i = 0; i < r + 1; ++i) ops[--w] = 1; done = true; break; }
+                } else {                                     // diagonal: MATCH / MISMATCH
+                    ops[--w] = (ul == cur) ? 0 : 3;
+                    cur = ul;
+                    --c;
+                    if (c == -1) { for (int i = 0; i < r; ++i) ops[--w] = 1; done = true; break; }
+                    if (r == 0) { for (int i = 0; i < c + 1; ++i) ops[--w] = 2; done = true; break; }
+                    --r;
+                }
+                took = true;
+                break;
+            }
+            if (took) {                              // the old left column is the current one; the ring's head is its left neighbour
+                Pc = Pl; Mc = Ml;
+                leftIn = c > 0 && (!G || c - 1 >= 64 * hb + dmin);
+                Pl = ((u64)fpm[j].y << 32) | fpm[j].x; Ml = ((u64)fpm[j].w << 32) | fpm[j].z; Sl = fs[j];
+                const int col = fcol - kDepth;       // refill the slot: kDepth columns further left in the same block row
+                if (col >= 0) { const StoreEntry* e = addr(col, hb); fpm[j] = *reinterpret_cast<const uint4*>(&e->p); fs[j] = e->s; }
+                --fcol;
+            }
         }
     }
-    a.opsLen[unit] = m + T - w;
+    if (have) a.opsLen[unit] = skip ? 0 : m + T - w;
 }
 
 hipError_t launch_traceback(const TracebackArgs& a, hipStream_t stream)
