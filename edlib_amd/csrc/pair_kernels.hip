@@ -751,21 +751,28 @@ hipError_t launch_hirschberg_split(const SplitArgs& a, hipStream_t stream)
 // with one WAVE per unit and the walk's window of the store kept on chip were both slower at config 5's shape
 // (10,000 x 1 kb: 0.89 ms here): window in LDS 1.31 ms (three LDS round trips per step), window in registers with
 // the whole walk in the scalar unit 1.66 ms (39 waves per CU share one scalar ALU).
-// The walk is a pointer chase through a store that lives in HBM: round 2 paid one dependent 32-byte load (~0.9 us) per
-// column.  Two on-chip variants of round 3 lost (a per-lane line cache in LDS misses lane by lane, so the wave still stalls at
-// every step: 1.37 ms against 0.88 at config 5's shape; an 8-column x 2-block window fetched by all lanes together costs
-// 32 scattered loads per lane and window: 1.18 ms).  What works is a SOFTWARE PIPELINE per lane: the walk consumes the
-// columns of a block row strictly from right to left, so the entries of the next kDepth columns are requested ahead into a
-// ring of registers (slot j is consumed in sub-iteration j of an unrolled loop and refilled right away: the hardware's
-// in-order vmcnt lets the wave wait for exactly that load and no younger one); every lane takes its up-moves and then one
-// column per sub-iteration, so all lanes pop the same slot together.  A lane whose walk leaves its block row waits for the
-// top of the loop, where the ring is refilled with kDepth + 2 loads in flight at once.
-constexpr int kDepth = 8;
+// The walk through the column store, one unit per lane (reference: obtainAlignmentTraceback, edlib.cpp:930-1100; the
+// move preference is the reference's: up, then left, then diagonal).
+//
+// Round 2 walked cell by cell: a dependent 32-byte load and ~250 issued instructions of divergent control flow per
+// column, 0.9 us per column with one wave per SIMD and nothing to overlap with.  Round 3 found by measurement that the
+// load latency is NOT what bounds it (a per-lane line cache in LDS 1.37 ms, an 8-column x 2-block LDS window 1.18 ms, a
+// cyclic register ring 1.5 ms, and a clean 8-column register batch 0.93 ms, against 0.88 ms for the plain walk at
+// config 5's shape): it is the instruction stream of a lone wave.  So the step itself is rebuilt:
+//   * the columns of a block row are consumed strictly right to left, so each lane fetches the next kBatch columns of
+//     its block row in one go (consecutive entries of the ring layout, all loads in flight together) and finds the left
+//     neighbour of sub-iteration j at the static batch index j;
+//   * a run of up-moves is one count-leading-ones on the current column's Pv word instead of a loop of cell steps;
+//   * left / diagonal is straight-line code; the rare events (band edge, first row / column reached, leaving the block
+//     row) set flags that are resolved outside the hot sequence: the boundary tails are written after the loop, a lane
+//     that left its block row waits for the next batch.
+constexpr int kBatch = 8;
 __global__ void __launch_bounds__(64)
-traceback_kernel(const TracebackArgs a)
+traceback_kernel(const TracebackArgs a, const int lanesPerWave)
 {
-    const int unit = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool have = unit < a.numUnits;
+    const int lane = threadIdx.x;
+    const int unit = blockIdx.x * lanesPerWave + lane;
+    const bool have = lane < lanesPerWave && unit < a.numUnits;
     const PairDesc d = a.descs[have ? unit : 0];
     const int m = d.qlen, T = d.tlen, nb = num_blocks(m);
     uint8_t* ops = a.ops + a.opsOff[have ? unit : 0];
@@ -782,92 +789,112 @@ traceback_kernel(const TracebackArgs a)
         const int D = T - m, absD = D < 0 ? -D : D, p = (d.kinit - absD) >> 1;
         dmin = (D < 0 ? D : 0) - p;
     }
-    const int kInf = 0x3fffffff;
     // a unit whose scan ended above its threshold has no exact cells to walk on (it is rescanned at the next level)
     const bool skip = !have || (G && cur > d.kinit);
     bool done = skip;
-    auto addr = [&](int col, int blk) -> const StoreEntry* {
-        return S + (G ? ring_index(G, T, col, blk) : store_index(T, nb, col, blk));
+    // entries of one block row lie at a fixed stride: index(c, b) = rowBase(b) + c * colStride
+    auto row_base = [&](int blk) -> long long {
+        if (G) return (long long)(blk % G) * T;
+        const int strip = blk >> 6, l = blk & 63;
+        const int nbS = (nb - strip * 64) < 64 ? (nb - strip * 64) : 64;
+        return strip_base(strip, T) + (long long)l * nbS + l;
     };
-    int hb = -1;                                     // block row the registers and the ring describe
-    u64 Pc = 0, Mc = 0, Pl = 0, Ml = 0; int Sl = 0; bool leftIn = false;
-    uint4 fpm[kDepth]; int fs[kDepth];               // the ring: (P, M) and block score of columns fcol, fcol - 1, ...
-    int fcol = -1;                                   // column of the entry the next pop returns
-    bool flush = !skip;
+    const int strideLast = (nb & 63) ? (nb & 63) : 64;      // entries per column of the last strip of the plain layout
+    u64 Pc = 0;                                      // Pv of column c, block r >> 6 (valid unless `fetch`)
+    bool fetch = true;
+    bool edge = false;                               // at the left edge of the band: resolved at the top of the loop
+    int tailOp = 0, tailCnt = 0;                     // the run along the matrix boundary, written after the loop
+    // ops leave through a shift register, eight at a time: a byte store per column would put a store round trip
+    // under every s_waitcnt vmcnt of the walk (gfx9 counts loads and stores in one counter)
+    u64 acc = 0; int cnt = 0;
+    auto push = [&](int op) {
+        acc = (acc << 8) | (u64)op;
+        if (++cnt == 8) { w -= 8; *reinterpret_cast<u64*>(ops + w) = acc; cnt = 0; }
+    };
     while (__builtin_amdgcn_ballot_w64(!done) != 0ull) {
-        if (!done && flush) {                        // ---- (re)fill: current column, its left neighbour, kDepth columns ahead
-            const int b = r >> 6;
-            const StoreEntry* e0 = addr(c, b);
-            const uint4 pm0 = *reinterpret_cast<const uint4*>(&e0->p);
-            leftIn = c > 0 && (!G || c - 1 >= 64 * b + dmin);          // block b exists in column c-1
-            uint4 pm1 = {0, 0, 0, 0}; int s1 = 0;
-            if (leftIn) { const StoreEntry* e1 = addr(c - 1, b); pm1 = *reinterpret_cast<const uint4*>(&e1->p); s1 = e1->s; }
-#pragma unroll
-            for (int j = 0; j < kDepth; ++j) {
-                const int col = c - 2 - j;
-                if (col >= 0) { const StoreEntry* e = addr(col, b); fpm[j] = *reinterpret_cast<const uint4*>(&e->p); fs[j] = e->s; }
-            }
-            Pc = ((u64)pm0.y << 32) | pm0.x; Mc = ((u64)pm0.w << 32) | pm0.z;
-            Pl = ((u64)pm1.y << 32) | pm1.x; Ml = ((u64)pm1.w << 32) | pm1.z; Sl = s1;
-            fcol = c - 2; hb = b; flush = false;
+        if (edge) {      // only the diagonal neighbour can exist: the bottom cell of the block above, one column left
+            const int bit = r & 63, bb = r >> 6;
+            if (bit == 0 && bb > 0) {
+                const int sv = (S + row_base(bb - 1) + (c - 1))->s;                 // ring layout only: stride 1
+                push(sv == cur ? 0 : 3);
+                cur = sv; --c; --r; fetch = true;
+            } else done = true;                      // not on an optimal path (cannot happen for an exact score)
+            edge = false;
         }
+        // ---- the batch: columns c-1 .. c-kBatch of block row b (columns left of 0 read column 0 and are never used)
+        const int b = r >> 6, cb = c;
+        uint4 bpm[kBatch]; int bs[kBatch];
+        const int cs = G ? 1 : ((b >> 6) == ((nb - 1) >> 6) ? strideLast : 64);
+        const StoreEntry* row = S + row_base(b);
+        if (!done) {
 #pragma unroll
-        for (int j = 0; j < kDepth; ++j) {
-            bool took = false;                       // this lane consumed a column in this sub-iteration
-            while (!done && !flush) {
-                const int b = r >> 6, bit = r & 63;
-                if (b != hb) { flush = true; break; }                      // the walk left its block row: refill at the top
-                const int u = cur - ((int)((Pc >> bit) & 1ull) - (int)((Mc >> bit) & 1ull));
-                int l, ul;
-                if (c == 0) { l = r + 1; ul = r; }          // column -1 boundary (:976-980)
-                else if (leftIn) {
-                    const u64 above = (bit == 63) ? 0ull : (~0ull << (bit + 1));   // rows below r in the block
-                    l = Sl - __popcll(Pl & above) + __popcll(Ml & above);
-                    ul = l - ((int)((Pl >> bit) & 1ull) - (int)((Ml >> bit) & 1ull));
-                } else {                                     // left edge of the band: only the diagonal neighbour may
-                    l = kInf;                                // exist, as the bottom cell of the block above
-                    ul = (bit == 0 && b > 0) ? addr(c - 1, b - 1)->s : kInf;
-                }
-                if (u + 1 == cur) {                          // up: INSERT (stays in the column)
-                    cur = u;
-                    ops[--w] = 1;
-                    if (r == 0) { for (int i = 0; i < c + 1; ++i) ops[--w] = 2; done = true; break; }
-                    --r;
-                    continue;
-                }
-                if (l + 1 == cur) {                          // left: DELETE
-                    cur = l;
-                    ops[--w] = 2;
-                    --c;
-                    if (c == -1) { for (int i = 0; i < r + 1; ++i) ops[--w] = 1; done = true; break; }
-                } else {                                     // diagonal: MATCH / MISMATCH
-                    ops[--w] = (ul == cur) ? 0 : 3;
-                    cur = ul;
-                    --c;
-                    if (c == -1) { for (int i = 0; i < r; ++i) ops[--w] = 1; done = true; break; }
-                    if (r == 0) { for (int i = 0; i < c + 1; ++i) ops[--w] = 2; done = true; break; }
-                    --r;
-                }
-                took = true;
-                break;
+            for (int j = 0; j < kBatch; ++j) {
+                const int col = cb - 1 - j;
+                const StoreEntry* e = row + (long long)(col < 0 ? 0 : col) * cs;
+                bpm[j] = *reinterpret_cast<const uint4*>(&e->p); bs[j] = e->s;
             }
-            if (took) {                              // the old left column is the current one; the ring's head is its left neighbour
-                Pc = Pl; Mc = Ml;
-                leftIn = c > 0 && (!G || c - 1 >= 64 * hb + dmin);
-                Pl = ((u64)fpm[j].y << 32) | fpm[j].x; Ml = ((u64)fpm[j].w << 32) | fpm[j].z; Sl = fs[j];
-                const int col = fcol - kDepth;       // refill the slot: kDepth columns further left in the same block row
-                if (col >= 0) { const StoreEntry* e = addr(col, hb); fpm[j] = *reinterpret_cast<const uint4*>(&e->p); fs[j] = e->s; }
-                --fcol;
+            if (fetch) { Pc = (row + (long long)c * cs)->p; fetch = false; }
+        }
+        bool live = !done;                           // still inside block row b with this batch
+        const int bandLeft = G ? 64 * b + dmin : -0x40000000;   // block b exists in column x iff x >= bandLeft
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            // -- up-moves: the set bits of Pv from row r upwards are one INSERT each (vertical delta +1)
+            {
+                const int bit = r & 63;
+                const u64 nx = ~(Pc << (63 - bit));                                // row r at bit 63; the zeros shifted in end the run
+                const int ups = live ? (nx ? __builtin_clzll(nx) : 64) : 0;        // leading ones, <= bit + 1
+                if (ups) { for (int i = 0; i < ups; ++i) push(1); }
+                cur -= ups; r -= ups;
+                const bool top = ups > bit;                                         // ran through the top of the block
+                const bool endRow = top && r < 0;                                   // INSERT taken in row 0 (:1040-1046)
+                tailOp = endRow ? 2 : tailOp; tailCnt = endRow ? c + 1 : tailCnt;
+                done = done || endRow; fetch = fetch || (top && !endRow); live = live && !top;
+            }
+            // -- left or diagonal
+            {
+                const int bit = r & 63;
+                const u64 Pl = ((u64)bpm[j].y << 32) | bpm[j].x, Ml = ((u64)bpm[j].w << 32) | bpm[j].z;   // column c - 1
+                const u64 above = (~0ull << bit) << 1;                              // rows below r in the block
+                int l = bs[j] - __popcll(Pl & above) + __popcll(Ml & above);
+                int ul = l - ((int)((Pl >> bit) & 1ull) - (int)((Ml >> bit) & 1ull));
+                const bool c0 = c == 0;                                             // column -1 boundary (:976-980)
+                l = c0 ? r + 1 : l; ul = c0 ? r : ul;
+                const bool atEdge = live && !c0 && c - 1 < bandLeft;               // block b is not in column c-1
+                edge = edge || atEdge; live = live && !atEdge;
+                const bool left = (l + 1 == cur);
+                if (live) push(left ? 2 : (ul == cur ? 0 : 3));
+                cur = live ? (left ? l : ul) : cur;
+                c -= live ? 1 : 0;
+                Pc = live ? Pl : Pc;                                                // block b of the column the walk is in now
+                const bool endC = live && c < 0;
+                const bool endR = live && !endC && !left && r == 0;
+                tailOp = endC ? 1 : (endR ? 2 : tailOp);
+                tailCnt = endC ? (left ? r + 1 : r) : (endR ? c + 1 : tailCnt);
+                const bool dn = live && !left && !endC && !endR;
+                r -= dn ? 1 : 0;
+                const bool cross = dn && (r & 63) == 63;
+                done = done || endC || endR; fetch = fetch || cross; live = live && !(endC || endR || cross);
             }
         }
+        // a lane that used up its batch inside the block row keeps Pc; one that left it re-reads (fetch)
     }
+    for (int i = 0; i < cnt; ++i) ops[w - cnt + i] = (uint8_t)(acc >> (8 * i));
+    w -= cnt;
+    for (int i = 0; i < tailCnt; ++i) ops[--w] = (uint8_t)tailOp;
     if (have) a.opsLen[unit] = skip ? 0 : m + T - w;
 }
 
 hipError_t launch_traceback(const TracebackArgs& a, hipStream_t stream)
 {
     if (a.numUnits == 0) return hipSuccess;
-    hipLaunchKernelGGL(traceback_kernel, dim3((a.numUnits + 63) / 64), dim3(64), 0, stream, a);
+    // lanes per wave: a wave steps at the pace of its slowest lane (up-moves, block-row changes), and a batch of a few
+    // thousand units leaves most of the 1024 SIMDs idle at 64 units per wave, so small batches spread out
+    static const int forced = [] { const char* e = getenv("EDLIB_AMD_TB_LANES"); return e ? atoi(e) : 0; }();
+    int lanes = 64;
+    while (lanes > 16 && (a.numUnits + lanes - 1) / lanes < 2048) lanes >>= 1;
+    if (forced >= 1 && forced <= 64) lanes = forced;
+    hipLaunchKernelGGL(traceback_kernel, dim3((a.numUnits + lanes - 1) / lanes), dim3(64), 0, stream, a, lanes);
     return hipGetLastError();
 }
 
