@@ -1126,7 +1126,13 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         d.posCap = wantPositions ? kPosCap : 0;
         d.posOff = (long long)i * kPosCap;
         d.colOff = -1; d.bandT = 0; d.ring = ring;
-        if (wantPath) opsOff[i + 1] = opsOff[i] + (long long)s.qlen + s.tlen;
+        // op slot of the unit, filled from the back.  An alignment has (m + T + inserts + deletes) / 2 ops, and a ring scan
+        // is only walked when its distance is within kinit: (m + T + kinit) / 2 bounds the length (config 5: 1064 bytes
+        // instead of 2000 per pair to bring back over PCIe)
+        if (wantPath) {
+            const long long full = (long long)s.qlen + s.tlen;
+            opsOff[i + 1] = opsOff[i] + (ring && s.kinit >= 0 && s.kinit < full ? (full + s.kinit) / 2 + 8 : full);
+        }
         // executed work: whole matrix, or one 64-block wave per column inside the band
         // executed work: the strips update every block of every column; the rings count the updates inside the band themselves
         if (!ring) stats.word_steps += 2 * nb * (long long)s.tlen;
@@ -1932,6 +1938,7 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
             ++atLevel[lastL];
         }
     }
+    Lap lap;
     for (int l = 0; l <= nl; ++l) {
         if (atLevel[l] == 0) continue;
         std::vector<UnitSpec>& sel = selScratch_; std::vector<size_t>& who = whoScratch_;
@@ -1944,9 +1951,11 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
             sel.push_back(u); who.push_back(i);
         }
         if (sel.empty()) continue;
+        lap("nw level: select");
         SolveOut& so = soLevel_;
         const bool store = paths != nullptr && (l == nl || ringH[l] == 1);
         if (solve(EDLIB_MODE_NW, false, store, sel, so, l < nl ? ringOf[l] : 0, l < nl ? ringH[l] : 1)) return 1;
+        lap("nw level: solve");
         if (store) opsKeep_.insert(opsKeep_.end(), so.opsBufs.begin(), so.opsBufs.end());
         for (size_t q = 0; q < sel.size(); ++q) {
             const size_t i = who[q];
@@ -1955,6 +1964,7 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
             else if (sel[q].kinit >= kcap) score[i] = kInf;                              // > k: final
             else { lvl[i] = l + 1; ++atLevel[l + 1]; }                                   // next level
         }
+        lap("nw level: scores");
     }
     return 0;
 }
@@ -1964,6 +1974,7 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
 int Batch::run()
 {
     pool_quarantine(false);
+    Lap lap;
     DeviceGuard guard(device_);
     EDLIB_AMD_HIP(guard.status);
     const long long cells = stats.cells;
@@ -1996,7 +2007,7 @@ int Batch::run()
     EDLIB_AMD_HIP(hipEventRecord(evRun0_.e, stream_));
     if (d_ringSteps_.p) EDLIB_AMD_HIP(hipMemsetAsync(d_ringSteps_.p, 0, sizeof(unsigned long long), stream_));
     ringStepsUsed_ = false;
-    Lap lap;
+    lap("run: reset records");
 
     // ---- empty sequences: answered without any DP (edlib.cpp:166-184)
     for (int u : emptyUnits_) {
@@ -2086,7 +2097,9 @@ int Batch::run()
             bool fuse = fuseOn && cfg_.task == EDLIB_TASK_PATH && mode == EDLIB_MODE_NW;
             for (size_t i = 0; fuse && i < units.size(); ++i) fuse = !needs_hirschberg(units[i].qlen, units[i].tlen);
             fusedOps_.clear();
+            lap("run: pair specs");
             if (solveGlobalDistances(units, score, fuse ? &fusedOps_ : nullptr)) return 1;
+            lap("run: global distances");
             for (size_t i = 0; i < units.size(); ++i)
                 finalize_global(res[pairUnits_[i]], cfg_.k, mode, units[i].tlen, score[i]);
             if (fuse)
@@ -2101,6 +2114,7 @@ int Batch::run()
                                     so.posFlat.data() + so.posStart[i], so.posStart[i + 1] - so.posStart[i]);
         }
     }
+    lap("run: finalize pairs");
     if (!flatDone && alphabetLengthsEnd(res)) return 1;      // alphabetLength for everything the reads path did not cover (flat pairs: at collection)
     lap("run: phase 1 (distance)");
     std::vector<int>& live = live_;            // non-empty units with a solution (only the later phases want them)

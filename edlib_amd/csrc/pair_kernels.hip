@@ -213,13 +213,15 @@ scan_pairs_kernel(const PairScanArgs a)
             const int col = t - lane;
             u32 hp = 0, hn = 0;
             if (laneOn && col >= 0 && col < T) {
-                u32 ph0, ph1, mh0, mh1;
-                advance_block64(B, (u32)eqCur, (u32)(eqCur >> 32), (u32)x & 1u, ((u32)x >> 1) & 1u, ph0, ph1, mh0, mh1);
+                u32 ph0, ph1, mh0, mh1, xh0, xh1;
+                advance_block64(B, (u32)eqCur, (u32)(eqCur >> 32), (u32)x & 1u, ((u32)x >> 1) & 1u, ph0, ph1, mh0, mh1, xh0, xh1);
                 hp = ph1 >> 31; hn = mh1 >> 31;
                 bscore += (int)hp - (int)hn;
                 if (STORE) {
                     const long long si = sbase + (long long)t * nbS + lane;
-                    a.store[si] = StoreEntry{((u64)B.p1 << 32) | B.p0, ((u64)B.m1 << 32) | B.m0, bscore, {0, 0, 0}};
+                    StoreEntry e;
+                    store_planes(B, ph0, ph1, xh0, xh1, e.x, e.y);
+                    a.store[si] = e;
                 }
                 if (!lastStrip) {
                     if (lane == 63) a.aux[d.auxOff + col] = (int)(hp | (hn << 1));
@@ -326,15 +328,16 @@ template <int G> __device__ __forceinline__ int ring_ror(const int v, const int 
     else return __builtin_amdgcn_ds_bpermute(srcAddr, v);              // srcAddr = 4 * (lane of the ring's previous lane)
 }
 
-// Ring layout of the column store: one row of T entries per ring lane, block b in row b % G (blocks b and
-// b + G are never alive in the same column).  A lane writes consecutive entries step after step, and the
-// traceback walking left through a block reads them back-to-back (4 columns per 128-byte line).
-__host__ __device__ static inline long long ring_index(int G, int T, int c, int b) {
-    return (long long)(b % G) * T + c;
+// Ring layout of the column store: step-major, G entries per step, block b in slot b % G (blocks b and b + G are never
+// alive in the same column); block b meets column c at step c + b.  The lanes of a unit write G consecutive entries
+// per step (round 3, first layout: one row of T entries per ring lane -- every lane of the wave stored to a line of
+// its own, and the storing scan of config 5 took 0.55 ms against 0.24 ms without the store: the address coalescer
+// handles a line per cycle); the traceback walking left through a block row reads with stride G.
+__host__ __device__ static inline long long ring_index(int G, int c, int b) {
+    return (long long)(c + b) * G + (b % G);
 }
 long long ring_store_entries(int G, int qlen, int tlen) {
-    (void)qlen;
-    return (long long)tlen * G;
+    return ((long long)tlen + num_blocks(qlen)) * G;
 }
 
 // PEQ: where a lane finds the Peq word of (symbol, its block):
@@ -573,11 +576,13 @@ scan_pairs_ring_kernel(const PairScanArgs a)
         const u32 xx = __builtin_amdgcn_bitop3_b32((u32)x, xmask, xfix, 0xea /* (a & b) | c */);
         u32 hp = xx & 1u, hn = xx >> 16;
         u32 phT0 = 0, phT1 = 0, mhT0 = 0, mhT1 = 0;                   // horizontal deltas of row m-1's block (MODE != 0)
+        StoreEntry ent{0, 0};
 #pragma unroll
         for (int h = 0; h < H; ++h) {                                 // top to bottom: the carry stays in the lane
-            u32 ph0, ph1, mh0, mh1;
-            advance_block64(B[h], (u32)eqCur[h], (u32)(eqCur[h] >> 32), hp, hn, ph0, ph1, mh0, mh1);
+            u32 ph0, ph1, mh0, mh1, xh0, xh1;
+            advance_block64(B[h], (u32)eqCur[h], (u32)(eqCur[h] >> 32), hp, hn, ph0, ph1, mh0, mh1, xh0, xh1);
             hp = ph1 >> 31; hn = mh1 >> 31;
+            if constexpr (STORE) store_planes(B[h], ph0, ph1, xh0, xh1, ent.x, ent.y);    // (STORE: H == 1)
             if (MODE != 0) { const bool tr = h == hb; phT0 = tr ? ph0 : phT0; phT1 = tr ? ph1 : phT1; mhT0 = tr ? mh0 : mhT0; mhT1 = tr ? mh1 : mhT1; }
         }
         // carry (and with it the block score) of a lane outside its block's life: +1 per step
@@ -587,10 +592,7 @@ scan_pairs_ring_kernel(const PairScanArgs a)
         if (STORE || MODE != 0) {
             if (actm) {
                 const int col = t - b;
-                if constexpr (STORE) {
-                    a.store[storeOff + (long long)rl * T + col] =
-                        StoreEntry{((u64)B[0].p1 << 32) | B[0].p0, ((u64)B[0].m1 << 32) | B[0].m0, bscore, {0, 0, 0}};
-                }
+                if constexpr (STORE) a.store[storeOff + (long long)t * G + rl] = ent;     // ring_index(G, col, b)
                 if (MODE != 0 && b == nsb - 1) {
                     const u64 ph = ((u64)phT1 << 32) | phT0, mh = ((u64)mhT1 << 32) | mhT0;
                     sc += (int)((ph >> sh) & 1ull) - (int)((mh >> sh) & 1ull);
@@ -751,21 +753,24 @@ hipError_t launch_hirschberg_split(const SplitArgs& a, hipStream_t stream)
 // with one WAVE per unit and the walk's window of the store kept on chip were both slower at config 5's shape
 // (10,000 x 1 kb: 0.89 ms here): window in LDS 1.31 ms (three LDS round trips per step), window in registers with
 // the whole walk in the scalar unit 1.66 ms (39 waves per CU share one scalar ALU).
-// The walk through the column store, one unit per lane (reference: obtainAlignmentTraceback, edlib.cpp:930-1100; the
-// move preference is the reference's: up, then left, then diagonal).
+// The walk through the column store, one unit per lane (reference: obtainAlignmentTraceback, edlib.cpp:942-1141; the
+// move preference is the reference's: up, then left, then diagonal).  The store answers the three questions of a cell
+// directly (StoreEntry, pair_kernels.hpp), so the walk needs neither scores nor the neighbours' values.
 //
-// Round 2 walked cell by cell: a dependent 32-byte load and ~250 issued instructions of divergent control flow per
-// column, 0.9 us per column with one wave per SIMD and nothing to overlap with.  Round 3 found by measurement that the
-// load latency is NOT what bounds it (a per-lane line cache in LDS 1.37 ms, an 8-column x 2-block LDS window 1.18 ms, a
-// cyclic register ring 1.5 ms, and a clean 8-column register batch 0.93 ms, against 0.88 ms for the plain walk at
-// config 5's shape): it is the instruction stream of a lone wave.  So the step itself is rebuilt:
-//   * the columns of a block row are consumed strictly right to left, so each lane fetches the next kBatch columns of
-//     its block row in one go (consecutive entries of the ring layout, all loads in flight together) and finds the left
-//     neighbour of sub-iteration j at the static batch index j;
-//   * a run of up-moves is one count-leading-ones on the current column's Pv word instead of a loop of cell steps;
-//   * left / diagonal is straight-line code; the rare events (band edge, first row / column reached, leaving the block
-//     row) set flags that are resolved outside the hot sequence: the boundary tails are written after the loop, a lane
-//     that left its block row waits for the next batch.
+// Round 2 walked cell by cell over (Pv, Mv, score) entries: a dependent 32-byte load, two popcounts and ~250 issued
+// instructions of divergent control flow per column, 0.9 us per column with one wave per SIMD and nothing to overlap
+// with.  Round 3 found by measurement that the load latency is NOT what bounds it (a per-lane line cache in LDS 1.37 ms,
+// an 8-column x 2-block LDS window 1.18 ms, a cyclic register ring 1.5 ms, and a clean 8-column register batch 0.93 ms,
+// against 0.88 ms for the plain walk at config 5's shape): it is the instruction stream of a lone wave, and the byte
+// store per op under every s_waitcnt vmcnt (gfx9 counts loads and stores in one counter).  So:
+//   * the columns of a block row are consumed strictly right to left: each lane fetches the next kBatch columns of its
+//     block row in one go and finds the left neighbour of sub-iteration j at the static batch index j;
+//   * a run of up-moves is one count-leading-ones on the "up" plane instead of a loop of cell steps;
+//   * left / diagonal is predicated straight-line code on two bit tests; the rare events (first row / column reached,
+//     leaving the block row) set flags that are resolved outside the hot sequence: the boundary tails are written after
+//     the loop, a lane that left its block row waits for the next batch;
+//   * ops leave through a shift register, eight at a time.
+// 0.88 -> 0.44 ms with the old entries, -> see profiles/README.md with the planes.
 constexpr int kBatch = 8;
 __global__ void __launch_bounds__(64)
 traceback_kernel(const TracebackArgs a, const int lanesPerWave)
@@ -775,14 +780,17 @@ traceback_kernel(const TracebackArgs a, const int lanesPerWave)
     const bool have = lane < lanesPerWave && unit < a.numUnits;
     const PairDesc d = a.descs[have ? unit : 0];
     const int m = d.qlen, T = d.tlen, nb = num_blocks(m);
-    uint8_t* ops = a.ops + a.opsOff[have ? unit : 0];
-    int w = m + T;                                  // next write index is --w
-    int r = m - 1, c = T - 1, cur = have ? a.score[unit] : 0;
+    const long long slotAt = a.opsOff[have ? unit : 0];
+    uint8_t* ops = a.ops + slotAt;
+    const int slot = (int)(a.opsOff[have ? unit + 1 : 1] - slotAt);   // the unit's op slot (>= any alignment the walk can produce)
+    int w = slot;                                   // next write index is --w
+    int r = m - 1, c = T - 1;
     const StoreEntry* S = a.store + d.storeOff;
     // ring layout (scan_pairs_ring_kernel): only the blocks inside the band of threshold kinit exist.
     // The walk stays on cells of optimal paths, which are inside the band and exact; a neighbour outside
     // the band can never be "one less than here", so it is simply not a candidate (the reference's
-    // stored band behaves the same, edlib.cpp:996-1016).
+    // stored band behaves the same, edlib.cpp:996-1016).  A block's first column inside the band is computed
+    // against "+1 per row" to its left: Ph = 0 there, so the planes never offer the move either.
     const int G = d.ring;
     int dmin = 0;
     if (G) {
@@ -790,62 +798,49 @@ traceback_kernel(const TracebackArgs a, const int lanesPerWave)
         dmin = (D < 0 ? D : 0) - p;
     }
     // a unit whose scan ended above its threshold has no exact cells to walk on (it is rescanned at the next level)
-    const bool skip = !have || (G && cur > d.kinit);
+    const bool skip = !have || (G && a.score[unit] > d.kinit);
     bool done = skip;
-    // entries of one block row lie at a fixed stride: index(c, b) = rowBase(b) + c * colStride
+    // entries of one block row lie at a fixed stride: index(c, b) = row_base(b) + c * stride
     auto row_base = [&](int blk) -> long long {
-        if (G) return (long long)(blk % G) * T;
+        if (G) return (long long)blk * G + (blk % G);
         const int strip = blk >> 6, l = blk & 63;
         const int nbS = (nb - strip * 64) < 64 ? (nb - strip * 64) : 64;
         return strip_base(strip, T) + (long long)l * nbS + l;
     };
-    const int strideLast = (nb & 63) ? (nb & 63) : 64;      // entries per column of the last strip of the plain layout
-    u64 Pc = 0;                                      // Pv of column c, block r >> 6 (valid unless `fetch`)
+    const int strideLast = (nb & 63) ? (nb & 63) : 64;      // entries per step of the last strip of the plain layout
+    u64 Xc = 0, Yc = 0;                              // planes of column c, block r >> 6 (valid unless `fetch`)
     bool fetch = true;
-    bool edge = false;                               // at the left edge of the band: resolved at the top of the loop
     int tailOp = 0, tailCnt = 0;                     // the run along the matrix boundary, written after the loop
-    // ops leave through a shift register, eight at a time: a byte store per column would put a store round trip
-    // under every s_waitcnt vmcnt of the walk (gfx9 counts loads and stores in one counter)
     u64 acc = 0; int cnt = 0;
     auto push = [&](int op) {
         acc = (acc << 8) | (u64)op;
         if (++cnt == 8) { w -= 8; *reinterpret_cast<u64*>(ops + w) = acc; cnt = 0; }
     };
     while (__builtin_amdgcn_ballot_w64(!done) != 0ull) {
-        if (edge) {      // only the diagonal neighbour can exist: the bottom cell of the block above, one column left
-            const int bit = r & 63, bb = r >> 6;
-            if (bit == 0 && bb > 0) {
-                const int sv = (S + row_base(bb - 1) + (c - 1))->s;                 // ring layout only: stride 1
-                push(sv == cur ? 0 : 3);
-                cur = sv; --c; --r; fetch = true;
-            } else done = true;                      // not on an optimal path (cannot happen for an exact score)
-            edge = false;
-        }
         // ---- the batch: columns c-1 .. c-kBatch of block row b (columns left of 0 read column 0 and are never used)
         const int b = r >> 6, cb = c;
-        uint4 bpm[kBatch]; int bs[kBatch];
-        const int cs = G ? 1 : ((b >> 6) == ((nb - 1) >> 6) ? strideLast : 64);
+        uint4 bxy[kBatch];
+        const int cs = G ? G : ((b >> 6) == ((nb - 1) >> 6) ? strideLast : 64);
         const StoreEntry* row = S + row_base(b);
         if (!done) {
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) {
                 const int col = cb - 1 - j;
-                const StoreEntry* e = row + (long long)(col < 0 ? 0 : col) * cs;
-                bpm[j] = *reinterpret_cast<const uint4*>(&e->p); bs[j] = e->s;
+                bxy[j] = *reinterpret_cast<const uint4*>(row + (long long)(col < 0 ? 0 : col) * cs);
             }
-            if (fetch) { Pc = (row + (long long)c * cs)->p; fetch = false; }
+            if (fetch) { const uint4 v = *reinterpret_cast<const uint4*>(row + (long long)c * cs); Xc = ((u64)v.y << 32) | v.x; Yc = ((u64)v.w << 32) | v.z; fetch = false; }
         }
         bool live = !done;                           // still inside block row b with this batch
         const int bandLeft = G ? 64 * b + dmin : -0x40000000;   // block b exists in column x iff x >= bandLeft
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
-            // -- up-moves: the set bits of Pv from row r upwards are one INSERT each (vertical delta +1)
+            // -- up-moves: the set bits of the "up" plane from row r upwards are one INSERT each
             {
                 const int bit = r & 63;
-                const u64 nx = ~(Pc << (63 - bit));                                // row r at bit 63; the zeros shifted in end the run
+                const u64 nx = ~((Xc & ~Yc) << (63 - bit));                        // row r at bit 63; the zeros shifted in end the run
                 const int ups = live ? (nx ? __builtin_clzll(nx) : 64) : 0;        // leading ones, <= bit + 1
                 if (ups) { for (int i = 0; i < ups; ++i) push(1); }
-                cur -= ups; r -= ups;
+                r -= ups;
                 const bool top = ups > bit;                                         // ran through the top of the block
                 const bool endRow = top && r < 0;                                   // INSERT taken in row 0 (:1040-1046)
                 tailOp = endRow ? 2 : tailOp; tailCnt = endRow ? c + 1 : tailCnt;
@@ -854,19 +849,12 @@ traceback_kernel(const TracebackArgs a, const int lanesPerWave)
             // -- left or diagonal
             {
                 const int bit = r & 63;
-                const u64 Pl = ((u64)bpm[j].y << 32) | bpm[j].x, Ml = ((u64)bpm[j].w << 32) | bpm[j].z;   // column c - 1
-                const u64 above = (~0ull << bit) << 1;                              // rows below r in the block
-                int l = bs[j] - __popcll(Pl & above) + __popcll(Ml & above);
-                int ul = l - ((int)((Pl >> bit) & 1ull) - (int)((Ml >> bit) & 1ull));
-                const bool c0 = c == 0;                                             // column -1 boundary (:976-980)
-                l = c0 ? r + 1 : l; ul = c0 ? r : ul;
-                const bool atEdge = live && !c0 && c - 1 < bandLeft;               // block b is not in column c-1
-                edge = edge || atEdge; live = live && !atEdge;
-                const bool left = (l + 1 == cur);
-                if (live) push(left ? 2 : (ul == cur ? 0 : 3));
-                cur = live ? (left ? l : ul) : cur;
+                const bool lbit = ((Xc & Yc) >> bit) & 1ull, ybit = (Yc >> bit) & 1ull;
+                const bool left = lbit && (c == 0 || c - 1 >= bandLeft);            // (column -1 is the boundary: :976-980)
+                if (live) push(left ? 2 : (ybit ? 0 : 3));
                 c -= live ? 1 : 0;
-                Pc = live ? Pl : Pc;                                                // block b of the column the walk is in now
+                const u64 Xl = ((u64)bxy[j].y << 32) | bxy[j].x, Yl = ((u64)bxy[j].w << 32) | bxy[j].z;
+                Xc = live ? Xl : Xc; Yc = live ? Yl : Yc;                           // block b of the column the walk is in now
                 const bool endC = live && c < 0;
                 const bool endR = live && !endC && !left && r == 0;
                 tailOp = endC ? 1 : (endR ? 2 : tailOp);
@@ -877,12 +865,12 @@ traceback_kernel(const TracebackArgs a, const int lanesPerWave)
                 done = done || endC || endR; fetch = fetch || cross; live = live && !(endC || endR || cross);
             }
         }
-        // a lane that used up its batch inside the block row keeps Pc; one that left it re-reads (fetch)
+        // a lane that used up its batch inside the block row keeps its planes; one that left it re-reads (fetch)
     }
     for (int i = 0; i < cnt; ++i) ops[w - cnt + i] = (uint8_t)(acc >> (8 * i));
     w -= cnt;
     for (int i = 0; i < tailCnt; ++i) ops[--w] = (uint8_t)tailOp;
-    if (have) a.opsLen[unit] = skip ? 0 : m + T - w;
+    if (have) a.opsLen[unit] = skip ? 0 : slot - w;
 }
 
 hipError_t launch_traceback(const TracebackArgs& a, hipStream_t stream)

@@ -32,12 +32,18 @@ struct PairDesc {
                          // size G of scan_pairs_ring_kernel (band of threshold kinit)
 };
 
-// One block-step of the column store (the reference's AlignmentData Ps/Ms/scores, edlib.cpp:22-47): 32 bytes,
-// so that the traceback fetches a cell's block with one sector.
-struct __attribute__((aligned(32))) StoreEntry {
-    unsigned long long p, m;    // vertical delta vectors after the column
-    int s;                      // score of the block's bottom row
-    int pad[3];
+// One block-step of the column store: what the traceback needs to know about the 64 cells of block b in column c, as two
+// bit planes (bit r = row 64 b + r).  The reference keeps Pv, Mv and the block score per column (AlignmentData,
+// edlib.cpp:22-47: 20 bytes) and re-derives the neighbours' values cell by cell (edlib.cpp:942-1141); the walk only ever
+// asks three questions of a cell, in this order (up > left > diagonal):
+//   up possible    <=> D[r][c] = D[r-1][c] + 1    <=> Pv bit (vertical delta +1, after the column)
+//   left possible  <=> D[r][c] = D[r][c-1] + 1    <=> Ph bit (horizontal delta +1, before the shift; calculateBlock :426)
+//   diagonal free  <=> D[r][c] = D[r-1][c-1]      <=> Xh bit when neither of the above holds (:424; Xh | Mv is Hyyro's D0,
+//                                                     and a set Mv bit of column c-1 makes Ph = 1, i.e. the walk goes left)
+// Four outcomes per cell = two bits:  x = Pv | Ph ("an indel move"),  y = ~Pv & (Ph | Xh):
+//   up = x & ~y,  left = x & y,  diagonal = ~x with MATCH iff y.   16 bytes: one store per block-step, one load per column.
+struct __attribute__((aligned(16))) StoreEntry {
+    unsigned long long x, y;
 };
 
 struct PairScanArgs {
@@ -98,7 +104,7 @@ struct TracebackArgs {
     int numUnits;
     const int* score;           // [units] D[m][T] (start value of the walk)
     const StoreEntry* store;
-    uint8_t* ops;               // ops pool; unit u owns [opsOff[u], opsOff[u] + qlen + tlen)
+    uint8_t* ops;               // ops pool; unit u owns [opsOff[u], opsOff[u + 1]), filled from the back
     const long long* opsOff;
     int* opsLen;                // [units] number of ops; they occupy the END of the unit's range
 };
