@@ -488,7 +488,6 @@ scan_pairs_ring_kernel(const PairScanArgs a)
     }
     const int nstepsU = __builtin_amdgcn_readfirstlane(nsteps);       // (the loop bound in an SGPR)
     u32 c2 = 0;                                                       // twice the column of the NEXT row-offset fetch (col + 2)
-    u32 liveSteps = 0;                                                // steps this lane spends inside a block's life
     // vertical deltas summed over the blocks below block h of this lane (score of block h's bottom row = bscore - that)
     auto below_blocks = [&](const int h) {
         int d = 0;
@@ -556,7 +555,6 @@ scan_pairs_ring_kernel(const PairScanArgs a)
             c2 = 2u * (u32)(col + 2);
             actm = ~0u;
             ev = span + 1;                                            // closes at the top of the step after its last
-            liveSteps += (u32)(span + 1);
         }
     };
 
@@ -622,12 +620,35 @@ scan_pairs_ring_kernel(const PairScanArgs a)
         step(t, eqA, eqB, offA, offB);
         step(t + 1, eqB, eqA, offB, offA);
     }
-    if (a.wordSteps) {                                                // live 32-row word-columns of the wave: one atomic
-        u32 v = liveSteps;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += (u32)__shfl_xor((int)v, off, 64);
-        if (lane == 0 && v) atomicAdd(a.wordSteps, (unsigned long long)v * (2ull * H));
+}
+
+// Word-steps inside the band of a ring launch (EdlibAmdBatchStats.word_steps, bench.py's valu_roofline): the block lives of
+// scan_pairs_ring_kernel recounted from the band geometry, one thread per unit.  (Round 3 first counted them inside the
+// scan; the counter carried through the loop was the 65th and 66th VGPR of the Peq-in-LDS variant -- 7 waves per SIMD
+// instead of 8 -- and neither an LDS slot nor a recount after the loop got the allocator below 64.)
+__global__ void __launch_bounds__(256)
+count_ring_steps_kernel(const PairDesc* __restrict__ descs, const int n, const int mode, const int H, unsigned long long* out)
+{
+    const int unit = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long v = 0;
+    if (unit < n) {
+        const PairDesc d = descs[unit];
+        const int m = d.qlen, T = d.tlen, K = d.kinit, RH = 64 * H;
+        const int nsb = (num_blocks(m) + H - 1) / H;
+        const int D = (d.bandT ? d.bandT : T) - m, absD = D < 0 ? -D : D;
+        if (mode != 0 || K >= absD) {
+            const int p = mode != 0 ? (1 << 28) : (K - absD) >> 1;
+            const int dmin = (D < 0 ? D : 0) - p, dmax = (D > 0 ? D : 0) + p;
+            for (int b = 0; b < nsb; ++b) {
+                int f = RH * b + dmin, l = RH * b + RH - 1 + dmax;
+                f = f < 0 ? 0 : f; l = l > T - 1 ? T - 1 : l;
+                if (f <= l) v += (unsigned long long)(l - f + 1);
+            }
+        }
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v * (2ull * H));
 }
 
 template <int G, int MODE, bool STORE, int H = 1>
@@ -647,6 +668,8 @@ static hipError_t launch_scan_pairs_ring_t(const PairScanArgs& a, hipStream_t st
     } else {
         hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 0, H>), grid, dim3(64), tgt, stream, a);
     }
+    if (a.wordSteps)
+        hipLaunchKernelGGL(count_ring_steps_kernel, dim3((a.numUnits + 255) / 256), dim3(256), 0, stream, a.descs, a.numUnits, MODE, H, a.wordSteps);
     return hipGetLastError();
 }
 
