@@ -242,6 +242,7 @@ private:
     long long algoBase_ = -1;     // algorithmic bytes of the batch while its results are still on the device
     bool algoDirty_ = false;
     // per-unit scratch of the pair path, kept across runs (fresh multi-megabyte vectors are mmap + page faults + munmap)
+    std::vector<int> pairSpecsFor_;              // the pair units pairSpecs_ was built for
     std::vector<UnitSpec> pairSpecs_, selScratch_; std::vector<size_t> whoScratch_; std::vector<int> lvlScratch_, scoreMain_;
     SolveOut soMain_, soLevel_;
     std::vector<OpsOut> fusedOps_;

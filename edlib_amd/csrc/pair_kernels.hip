@@ -325,6 +325,9 @@ template <int G> __device__ __forceinline__ int ring_ror(const int v, const int 
     if constexpr (G == 64) return __builtin_amdgcn_mov_dpp(v, 0x13C /*wave_ror:1*/, 0xf, 0xf, true);
     else if constexpr (G == 16) return __builtin_amdgcn_mov_dpp(v, 0x121 /*row_ror:1*/, 0xf, 0xf, true);
     else if constexpr (G == 4) return __builtin_amdgcn_mov_dpp(v, 0x93 /*quad_perm:[3,0,1,2]*/, 0xf, 0xf, true);
+    // (rings that do not divide a DPP row -- 8 is packed two to a row, 21 and 32 cross rows: a whole-wave rotation plus
+    // v_readlane / v_writelane fix-ups of the rings' first lanes was measured in round 3: config 4's scans 19.6 -> 22.6 ms,
+    // the SGPR round trips stall the VALU longer than the LDS round trip they replace)
     else return __builtin_amdgcn_ds_bpermute(srcAddr, v);              // srcAddr = 4 * (lane of the ring's previous lane)
 }
 
