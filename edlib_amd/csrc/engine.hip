@@ -371,6 +371,14 @@ count_flags_kernel(const int* __restrict__ flags, int n, int* __restrict__ count
     if (i < n && flags[i]) atomicAdd(counter, 1);
 }
 
+// full-height pass of the reads path: a lane's threshold drops to what a scan of the target's first columns found
+__global__ void __launch_bounds__(256)
+seed_thresholds_kernel(int* __restrict__ kinit, const int* __restrict__ best, const int* __restrict__ cnt, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && cnt[i] > 0 && best[i] < kinit[i]) kinit[i] = best[i];
+}
+
 // flat pair path: how many units have more end locations than their list keeps (they need the exact second pass)
 __global__ void __launch_bounds__(256)
 count_over_kernel(const int* __restrict__ count, int n, int cap, int* __restrict__ counter)
@@ -679,16 +687,16 @@ int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, i
     // 2 = the banded kernel at full height (325 ms).  Default: 0 for four symbols, 1 above.
     static const int pass2Kernel = getenv("EDLIB_AMD_PASS2") ? atoi(getenv("EDLIB_AMD_PASS2")) : 0;
     const bool longGroup = g.nwords > kMaxReadWords;                  // no plain kernel for 12 / 16 words
+    // columns a lane walks: the segments' own columns (a launch may cover a prefix of the target only) and their warm-ups
+    const long long colsScanned = std::min<long long>(a.targetLength, (long long)numSegments * segLen) + (long long)(numSegments - 1) * warm;
     const bool fullHeight = banded_ && mode == EDLIB_MODE_HW && unbanded && (chained || ((pass2Kernel == 1 || syms_ > 4 || longGroup) && pass2Kernel != 2));
     if (fullHeight) {
         EDLIB_AMD_HIP(launch_scan_reads_full(g.nwords, syms_, a, stream_));
-        stats.word_steps += (long long)((nlanes + 63) / 64 * 64) * g.nwords *
-                            ((long long)a.targetLength + (long long)(numSegments - 1) * warm);
+        stats.word_steps += (long long)((nlanes + 63) / 64 * 64) * g.nwords * colsScanned;
     } else if (banded_ && mode == EDLIB_MODE_HW && (!unbanded || syms_ > 4 || longGroup)) EDLIB_AMD_HIP(launch_scan_reads_banded(g.nwords, syms_, a, stream_));
     else {
         EDLIB_AMD_HIP(launch_scan_reads(g.nwords, mode, a, stream_));
-        stats.word_steps += (long long)((nlanes + 63) / 64 * 64) * g.nwords *
-                            ((long long)a.targetLength + (long long)(numSegments - 1) * warm);
+        stats.word_steps += (long long)((nlanes + 63) / 64 * 64) * g.nwords * colsScanned;
     }
     scanTimerStop();
     if (dbg) {
@@ -910,6 +918,22 @@ int Batch::runGroupScans(ReadGroup& g, bool fullOnly)
             EDLIB_AMD_HIP(launch_build_peq_reads(g.nwords, syms_, d_qpool_.p, d_qoff_.p, d_perm2.p, (int)no64,
                                                  d_eqtbl_.p, d_presence_.p, cfg_.k, d_peq2.p, d_qlen2.p,
                                                  d_kinit2.p, d_extra2.p, stream_));
+            // Every segment starts from its lane's threshold, and a lane records a position whenever its best improves: from
+            // min(k, m) an unrelated read walks down ~100 improvements per segment, each a scattered 4-byte store (1.2 GB of
+            // write traffic per 1M-read step in round 2).  The first columns of the target give every lane a score that
+            // some column does reach; all segments start from that one (results do not depend on it: the best over
+            // the whole target is at most that score, and equal scores are still recorded).
+            static const bool seedOn = !(getenv("EDLIB_AMD_SEED") && getenv("EDLIB_AMD_SEED")[0] == '0');
+            const int seedCols = 4096;                               // (a lone wave per SIMD: 0.27 ms)
+            DevBuf<int> d_b0, d_c0, d_p0;                            // (live until the synchronisation below)
+            if (seedOn && mode == EDLIB_MODE_HW && last && no >= 4096 && S2 > 1 && T >= 16 * seedCols) {
+                EDLIB_AMD_HIP(d_b0.alloc(no)); EDLIB_AMD_HIP(d_c0.alloc(no)); EDLIB_AMD_HIP(d_p0.alloc(no * 8));
+                if (scanGroup(g, mode, nullptr, (int)no, kcapL, d_kinit2.p, 1, seedCols, 0,
+                              d_b0.p, d_c0.p, d_p0.p, 8, nullptr, nullptr, plain, nullptr, d_peq2.p, d_qlen2.p)) return 1;
+                hipLaunchKernelGGL(seed_thresholds_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, stream_,
+                                   d_kinit2.p, d_b0.p, d_c0.p, (int)no);
+                EDLIB_AMD_HIP(hipGetLastError());
+            }
             if (scanGroup(g, mode, nullptr, (int)no, kcapL, d_kinit2.p, S2, segLen2, warm2,
                           d_sb.p, d_sc.p, d_sp.p, 8, nullptr, nullptr, plain, nullptr, d_peq2.p, d_qlen2.p)) return 1;
             EDLIB_AMD_HIP(launch_merge_segments(d_sb.p, d_sc.p, d_sp.p, S2, 8, (int)no, d_map.p, 16,
