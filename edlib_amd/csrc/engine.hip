@@ -1448,7 +1448,17 @@ int Batch::initFlatPairs()
     EDLIB_AMD_HIP(d_flatPos_.alloc(scanMode == EDLIB_MODE_NW ? 1 : (size_t)n_ * kFlatPosCap));
     EDLIB_AMD_HIP(d_flatCensus_.alloc(1));
     EDLIB_AMD_HIP(h_flatCensus_.alloc(sizeof(int)));
+    // the word-steps of a run over the resident descriptors never change: counted here, once
+    {
+        unsigned long long* ctr = ringStepsCounter();
+        if (!ctr) return 1;
+        EDLIB_AMD_HIP(hipMemsetAsync(ctr, 0, sizeof(unsigned long long), stream_));
+        EDLIB_AMD_HIP(launch_count_ring_steps(d_flatDescs_.p, n_, scanMode, 1, ctr, stream_));
+        EDLIB_AMD_HIP(hipMemcpyAsync(h_ringSteps_.p, ctr, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+    }
     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));                // `pin` dies here
+    flatWordSteps_ = (long long)*reinterpret_cast<unsigned long long*>(h_ringSteps_.p);
+    ringStepsUsed_ = false;
     flatPairs_ = true;
     return 0;
 }
@@ -1467,7 +1477,8 @@ int Batch::runPairsFlat(bool& overflowed)
     a.peqFullStride = (int)std::min<long long>((long long)a.peqRowStride * tab_.sigmaT, 1 << 20);
     a.store = nullptr;
     a.outScore = d_flatOut3_.p; a.outCount = d_flatOut3_.p + n_; a.outLast = d_flatOut3_.p + 2 * (size_t)n_; a.posPool = d_flatPos_.p;
-    a.wordSteps = ringStepsCounter();
+    a.wordSteps = nullptr;
+    stats.word_steps += flatWordSteps_;
     scanTimerStart();
     EDLIB_AMD_HIP(launch_scan_pairs_ring(flatRing_, scanMode, false, a, stream_));
     scanTimerStop();

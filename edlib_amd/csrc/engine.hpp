@@ -250,6 +250,7 @@ private:
     // run is Peq build + ONE ring scan + an overflow census, results stay in HBM until results() (like the reads path)
     bool flatPairs_ = false, pairsCollected_ = true;
     int flatRing_ = 0;
+    long long flatWordSteps_ = 0;               // word-steps inside the bands of one run over the flat descriptors
     DevBuf<PairDesc> d_flatDescs_;
     DevBuf<int> d_flatOut3_, d_flatPos_, d_flatCensus_;
     PinBuf h_flatCensus_;

@@ -654,6 +654,13 @@ count_ring_steps_kernel(const PairDesc* __restrict__ descs, const int n, const i
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v * (2ull * H));
 }
 
+hipError_t launch_count_ring_steps(const PairDesc* descs, int numUnits, int mode, int H, unsigned long long* out, hipStream_t stream)
+{
+    if (numUnits == 0) return hipSuccess;
+    hipLaunchKernelGGL(count_ring_steps_kernel, dim3((numUnits + 255) / 256), dim3(256), 0, stream, descs, numUnits, mode, H, out);
+    return hipGetLastError();
+}
+
 template <int G, int MODE, bool STORE, int H = 1>
 static hipError_t launch_scan_pairs_ring_t(const PairScanArgs& a, hipStream_t stream)
 {
@@ -671,8 +678,7 @@ static hipError_t launch_scan_pairs_ring_t(const PairScanArgs& a, hipStream_t st
     } else {
         hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 0, H>), grid, dim3(64), tgt, stream, a);
     }
-    if (a.wordSteps)
-        hipLaunchKernelGGL(count_ring_steps_kernel, dim3((a.numUnits + 255) / 256), dim3(256), 0, stream, a.descs, a.numUnits, MODE, H, a.wordSteps);
+    if (a.wordSteps) return launch_count_ring_steps(a.descs, a.numUnits, MODE, H, a.wordSteps, stream);
     return hipGetLastError();
 }
 

@@ -92,6 +92,9 @@ constexpr int kMaxBandK = ring_max_k(64);
 hipError_t launch_scan_pairs_ring(int ringLanes, int mode, bool store, const PairScanArgs& a, hipStream_t stream,
                                   int blocksPerLane = 1);
 long long ring_store_entries(int ringLanes, int qlen, int tlen);
+// adds the word-steps inside the bands of `numUnits` ring units (64 H rows per ring-lane block, scan mode `mode`) to *out:
+// what launch_scan_pairs_ring does behind its scan when PairScanArgs::wordSteps is set
+hipError_t launch_count_ring_steps(const PairDesc* descs, int numUnits, int mode, int H, unsigned long long* out, hipStream_t stream);
 
 // reference buildPeq (edlib.cpp:358-384) for every unit: Peq[sym][block] from the
 // query bytes and the 256x256 byte equality matrix eq8 (identity + additionalEqualities).
