@@ -59,7 +59,7 @@ __device__ void scan_small(const u64* s_peq, const int nb, const uint8_t* s_t, c
     const u32 sh = (u32)(m - 1) & 63u;
     const bool tracker = lane == nb - 1;
     Block64 B{~0u, ~0u, 0u, 0u};                                     // column -1 (edlib.cpp:575-579)
-    int bscore = (lane + 1) * 64, sc = m, carry = 0;
+    int sc = m, carry = 0;
     int best = kthr, cnt = 0, last = -1;
     const int top = mode == 2 ? 0 : 1;                               // row -1: HW 0, SHW / NW +1 (edlib.cpp:584, 779)
     const int nsteps = Tn + nb - 1;
@@ -76,14 +76,14 @@ __device__ void scan_small(const u64* s_peq, const int nb, const uint8_t* s_t, c
         const int tbNN = byte_of(col + 2);
         const int x = __builtin_amdgcn_update_dpp(top, carry, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
         if (on && col >= 0 && col < Tn) {
-            u32 ph0, ph1, mh0, mh1;
-            advance_block64(B, (u32)eq, (u32)(eq >> 32), (u32)x & 1u, ((u32)x >> 1) & 1u, ph0, ph1, mh0, mh1);
+            u32 ph0, ph1, mh0, mh1, xh0, xh1;
+            advance_block64(B, (u32)eq, (u32)(eq >> 32), (u32)x & 1u, ((u32)x >> 1) & 1u, ph0, ph1, mh0, mh1, xh0, xh1);
             const u32 hp = ph1 >> 31, hn = mh1 >> 31;
-            bscore += (int)hp - (int)hn;
             carry = (int)(hp | (hn << 1));
-            if (STORE) {
-                u32* e = s_store + (size_t)(col * nb + lane) * 5;
-                e[0] = B.p0; e[1] = B.p1; e[2] = B.m0; e[3] = B.m1; e[4] = (u32)bscore;
+            if (STORE) {                                             // the two planes of pair_kernels.hpp StoreEntry
+                unsigned long long px, py;
+                store_planes(B, ph0, ph1, xh0, xh1, px, py);
+                *reinterpret_cast<uint4*>(s_store + (size_t)(col * nb + lane) * 4) = make_uint4((u32)px, (u32)(px >> 32), (u32)py, (u32)(py >> 32));
             }
             if (tracker) {
                 const u64 ph = ((u64)ph1 << 32) | ph0, mh = ((u64)mh1 << 32) | mh0;
@@ -222,34 +222,23 @@ one_pair_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out)
                     scan_small<true>(s_peq, nb, s_t, s0, 1, len, m, 0, m + len, s_pos, s_store, r);
                 }
                 // reference obtainAlignmentTraceback (edlib.cpp:942-1141): lane 0 walks from (m-1, len-1) to the origin on the
-                // stored columns; ops are written back to front
+                // stored planes (up = x & ~y, left = x & y, diagonal = ~x with MATCH iff y); ops are written back to front
                 int wpos = m + len;
                 if (lane == 0) {
-                    int r = m - 1, c = len - 1, cur = ed;
-                    auto P = [&](int col, int blk) { const u32* e = s_store + (size_t)(col * nb + blk) * 5; return ((u64)e[1] << 32) | e[0]; };
-                    auto M = [&](int col, int blk) { const u32* e = s_store + (size_t)(col * nb + blk) * 5; return ((u64)e[3] << 32) | e[2]; };
-                    auto Sc = [&](int col, int blk) { return (int)s_store[(size_t)(col * nb + blk) * 5 + 4]; };
+                    int r = m - 1, c = len - 1;
                     for (;;) {
-                        const int b = r >> 6, bit = r & 63;
-                        const u64 Pc = P(c, b), Mc = M(c, b);
-                        const int u = cur - ((int)((Pc >> bit) & 1ull) - (int)((Mc >> bit) & 1ull));
-                        int l, ul;
-                        if (c == 0) { l = r + 1; ul = r; }            // column -1 boundary (:976-980)
-                        else {
-                            const u64 Pl = P(c - 1, b), Ml = M(c - 1, b);
-                            const u64 above = (bit == 63) ? 0ull : (~0ull << (bit + 1));
-                            l = Sc(c - 1, b) - __popcll(Pl & above) + __popcll(Ml & above);
-                            ul = l - ((int)((Pl >> bit) & 1ull) - (int)((Ml >> bit) & 1ull));
-                        }
-                        if (u + 1 == cur) {                           // up: INSERT
-                            cur = u; s_ops[--wpos] = 1;
+                        const uint4 e = *reinterpret_cast<const uint4*>(s_store + (size_t)(c * nb + (r >> 6)) * 4);
+                        const u64 x = ((u64)e.y << 32) | e.x, y = ((u64)e.w << 32) | e.z;
+                        const int bit = r & 63;
+                        if (((x & ~y) >> bit) & 1ull) {               // up: INSERT
+                            s_ops[--wpos] = 1;
                             if (r == 0) { for (int i = 0; i < c + 1; ++i) s_ops[--wpos] = 2; break; }
                             --r;
-                        } else if (l + 1 == cur) {                    // left: DELETE
-                            cur = l; s_ops[--wpos] = 2; --c;
+                        } else if (((x & y) >> bit) & 1ull) {         // left: DELETE
+                            s_ops[--wpos] = 2; --c;
                             if (c == -1) { for (int i = 0; i < r + 1; ++i) s_ops[--wpos] = 1; break; }
                         } else {                                      // diagonal: MATCH / MISMATCH
-                            s_ops[--wpos] = (ul == cur) ? 0 : 3; cur = ul; --c;
+                            s_ops[--wpos] = ((y >> bit) & 1ull) ? 0 : 3; --c;
                             if (c == -1) { for (int i = 0; i < r; ++i) s_ops[--wpos] = 1; break; }
                             if (r == 0) { for (int i = 0; i < c + 1; ++i) s_ops[--wpos] = 2; break; }
                             --r;
@@ -302,7 +291,7 @@ int align_one_fused(const char* q, int m, const char* t, int T, EdlibAlignConfig
     if (fixed > (size_t)kOneLdsBudget) return 2;
     size_t storeCap = 0;
     if (task == 2) {
-        storeCap = ((size_t)kOneLdsBudget - fixed) / 20;
+        storeCap = ((size_t)kOneLdsBudget - fixed) / 16;
         // the window of the alignment: the whole target (NW), at most m + distance <= 2m columns (SHW / HW)
         const long long cols = mode == 0 ? T : std::min<long long>(T, 2LL * m);
         if ((long long)nb * cols > (long long)storeCap) return 2;
@@ -330,7 +319,7 @@ int align_one_fused(const char* q, int m, const char* t, int T, EdlibAlignConfig
     memcpy(ctx.in.p + sizeof(OneHeader) + ((m + 15) & ~15), t, (size_t)T);
     OneResult* r = reinterpret_cast<OneResult*>(ctx.out.p);
     r->code = -1;
-    const size_t lds = fixed + (task == 2 ? storeCap * 20 : 0) + 64;
+    const size_t lds = fixed + (task == 2 ? storeCap * 16 : 0) + 64;
     hipLaunchKernelGGL(one_pair_kernel, dim3(1), dim3(64), lds, ctx.stream, ctx.in.p, ctx.out.p);
     EDLIB_AMD_HIP(hipGetLastError());
     // alphabetLength (edlib.cpp:162, transformSequences :1417-1462) while the kernel runs: distinct bytes of query and target
