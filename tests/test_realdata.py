@@ -1,0 +1,165 @@
+"""The reference's own real-data shapes (SURVEY.md §8c "[probe] config-1 goldens"; /root/reference/test_data/perf_tests.sh:150-191):
+
+  * the 250 bp Illumina read against the 1 Mb chromosome, HW -l  =>  108, (350889,351126) (350889,351127);
+  * every file of test_data/E_coli_DH1/mason_illumina_reads/{50,100,250,500,10k}bp (HW) and prefixes/* (SHW) against
+    Chromosome_2890043_3890042_0.fasta, each directory as ONE shared-target batch, tasks distance / locations / path;
+  * the seven "Chromosome, NW" pairs (1,000,000 x ~1,000,000 bases): score, location, md5 of the op bytes and of both
+    CIGAR lines -- the band beyond every lane ring (distances 9,927 ... 395,021) and the Hirschberg regime.
+
+tests/golden/realdata/ holds the reference's data files (the 1 Mb ones xz-compressed) and expected.json, made by the
+compiled reference (oracle/gen_realdata_golden.py).  CPU part: the C99 restatement (and oracle/_ref where it travelled)
+reproduces the fixtures.  GPU part: the engine, through the C ABI."""
+import hashlib
+import json
+import lzma
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REAL = os.path.join(ROOT, "tests", "golden", "realdata")
+with open(os.path.join(REAL, "expected.json")) as _f:
+    EXP = json.load(_f)
+CHROM = "Chromosome_2890043_3890042_0.fasta.xz"
+FIELDS = ("editDistance", "numLocations", "alphabetLength", "endLocations", "startLocations", "alignmentLength")
+
+
+def read_fasta(path):
+    """first record of a FASTA file (plain or .xz) as bytes (the CLI's reader: apps/aligner/aligner.cpp:290-328)."""
+    op = lzma.open if path.endswith(".xz") else open
+    seq = []
+    with op(path, "rb") as f:
+        for line in f:
+            if line.startswith(b">"):
+                if seq:
+                    break
+                continue
+            seq.append(line.strip())
+    return b"".join(seq)
+
+
+_cache = {}
+
+
+def chromosome():
+    if "t" not in _cache:
+        _cache["t"] = read_fasta(os.path.join(REAL, "chromosome", CHROM))
+    return _cache["t"]
+
+
+def md5(b):
+    return hashlib.md5(b).hexdigest()
+
+
+def check_result(got, want, cigar, name):
+    """every field of EdlibAlignResult against the fixture; op bytes through their md5 and both CIGAR lines."""
+    for f in FIELDS:
+        assert got[f] == want[f], "%s: %s: got %r want %r" % (name, f, got[f], want[f])
+    if "ops_md5" in want:
+        assert got["alignment"] is not None, name
+        assert md5(got["alignment"]) == want["ops_md5"], name + ": op bytes"
+        ext, std = cigar(got["alignment"], True), cigar(got["alignment"], False)
+        assert md5((ext + "\n").encode()) == want["cigar_ext_md5"] and len(ext) == want["cigar_ext_len"], name + ": CIG_EXT"
+        assert md5((std + "\n").encode()) == want["cigar_std_md5"] and len(std) == want["cigar_std_len"], name + ": CIG_STD"
+        if "cigar_ext" in want:
+            assert ext == want["cigar_ext"], name
+    else:
+        assert got["alignment"] is None, name
+
+
+def test_survey_golden_is_in_the_fixture():
+    b = [b for b in EXP["mason"] if b["dir"].endswith("/250bp")][0]
+    c = [c for c in b["cases"] if c["file"] == "e_coli_DH1_illumina_1x250.fasta"][0]["locations"]
+    assert c["editDistance"] == 108
+    assert list(zip(c["startLocations"], c["endLocations"])) == [(350889, 351126), (350889, 351127)]
+    assert len(chromosome()) == 1000000
+    assert [c["percent"] for c in EXP["chromosome"]] == [99, 97, 94, 90, 80, 70, 60]
+    assert [c["editDistance"] for c in EXP["chromosome"]] == [9927, 31467, 62190, 99451, 201673, 306456, 395021]
+
+
+def _batches(short_only):
+    out = []
+    for key in ("mason", "prefixes"):
+        for b in EXP[key]:
+            if short_only and b["dir"].endswith("10kbp"):
+                continue
+            out.append(b)
+    return out
+
+
+@pytest.mark.parametrize("batch", _batches(True), ids=lambda b: b["dir"])
+def test_oracle_reproduces_read_fixtures(oracle, ref, batch):
+    """the restatement (and the compiled reference where it is) on the short-read directories: all three tasks."""
+    t = chromosome()
+    for c in batch["cases"]:
+        q = read_fasta(os.path.join(REAL, batch["dir"], c["file"]))
+        assert len(q) == c["qlen"]
+        for impl in (oracle, ref):
+            if impl is None:
+                continue
+            for task in ("distance", "locations", "path"):
+                got = impl.align(q, t, batch["mode"], task, -1)
+                check_result(got, c[task], lambda ops, e: impl.cigar(ops, 1 if e else 0), "%s/%s %s" % (batch["dir"], c["file"], task))
+
+
+def test_oracle_reproduces_chromosome_99(oracle):
+    c = EXP["chromosome"][0]
+    q = read_fasta(os.path.join(REAL, "chromosome", c["query"]))
+    got = oracle.align(q, chromosome(), "NW", "distance", -1)
+    assert (got["editDistance"], got["endLocations"], len(q)) == (9927, [999999], c["qlen"])
+
+
+# ------------------------------------------------------------------ GPU
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", _batches(False), ids=lambda b: b["dir"])
+@pytest.mark.parametrize("task", ["distance", "locations", "path"])
+def test_gpu_read_directories_as_shared_target_batches(engine, batch, task):
+    t = chromosome()
+    qs = [read_fasta(os.path.join(REAL, batch["dir"], c["file"])) for c in batch["cases"]]
+    got = engine.align_batch(qs, t, mode=batch["mode"], task=task, raw=True)
+    for g, c in zip(got, batch["cases"]):
+        assert g["status"] == 0
+        check_result(g, c[task], engine.cigar_from_alignment, "%s/%s %s" % (batch["dir"], c["file"], task))
+
+
+@pytest.mark.gpu
+def test_gpu_survey_golden_single_call(engine):
+    """the §8(c) golden through plain edlibAlign()."""
+    q = read_fasta(os.path.join(REAL, "mason_illumina_reads", "250bp", "e_coli_DH1_illumina_1x250.fasta"))
+    got = engine.align_raw(q, chromosome(), "HW", "locations", -1)
+    assert got["editDistance"] == 108
+    assert list(zip(got["startLocations"], got["endLocations"])) == [(350889, 351126), (350889, 351127)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", EXP["chromosome"], ids=lambda c: "p%d" % c["percent"])
+def test_gpu_chromosome_pairs_distance(engine, case):
+    q = read_fasta(os.path.join(REAL, "chromosome", case["query"]))
+    got = engine.align_raw(q, chromosome(), "NW", "distance", -1)
+    assert got["status"] == 0
+    assert (got["editDistance"], got["endLocations"], got["numLocations"], got["alphabetLength"]) == \
+        (case["editDistance"], case["endLocations"], 1, case["alphabetLength"])
+    # a fixed k at / just under the distance (edlib.cpp:197-217: one pass, -1 above k)
+    if case["percent"] in (99, 90):
+        d = case["editDistance"]
+        assert engine.align_raw(q, chromosome(), "NW", "distance", d)["editDistance"] == d
+        assert engine.align_raw(q, chromosome(), "NW", "distance", d - 1)["editDistance"] == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [c for c in EXP["chromosome"] if c["percent"] in (99, 97, 90, 60)], ids=lambda c: "p%d" % c["percent"])
+def test_gpu_chromosome_pairs_path(engine, case):
+    q = read_fasta(os.path.join(REAL, "chromosome", case["query"]))
+    got = engine.align_raw(q, chromosome(), "NW", "path", -1)
+    assert got["status"] == 0
+    check_result(got, case, engine.cigar_from_alignment, "chromosome p%d" % case["percent"])
+
+
+@pytest.mark.gpu
+def test_gpu_chromosome_pairs_as_one_batch(engine):
+    """all seven pairs in ONE pair batch (distance): the wide band next to itself at seven different widths."""
+    qs = [read_fasta(os.path.join(REAL, "chromosome", c["query"])) for c in EXP["chromosome"]]
+    got = engine.align_pairs(qs, [chromosome()] * len(qs), mode="NW", task="distance", raw=True)
+    assert [g["editDistance"] for g in got] == [c["editDistance"] for c in EXP["chromosome"]]
+    assert all(g["endLocations"] == [999999] for g in got)
