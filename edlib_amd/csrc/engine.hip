@@ -1112,6 +1112,7 @@ int Batch::solve(int mode, bool wantPositions, bool wantPath, const std::vector<
     out.posStart.assign(n + 1, 0); out.posFlat.clear();
     out.opsPtr.assign(n, nullptr); out.opsLen.assign(n, 0); out.opsBufs.clear();
     if (n == 0) return 0;
+    if (ring == kWide && wantPath) { set_error("the wide kernel keeps no column store"); return 1; }
     stats.path |= 2;
     // chunk so that the Peq pool and (for PATH) the column store stay within a budget
     const long long peqBudget = 4LL << 30, storeBudget = 12LL << 30;
@@ -1122,7 +1123,7 @@ int Batch::solve(int mode, bool wantPositions, bool wantPath, const std::vector<
         while (b < n) {
             const long long nb = (units[b].qlen + 63) / 64;
             const long long pb = nb * tab_.sigmaT * 8;
-            const long long sb = !wantPath ? 0 : (long long)sizeof(StoreEntry) * (ring ? ring_store_entries(ring, units[b].qlen, units[b].tlen)
+            const long long sb = !wantPath ? 0 : (long long)sizeof(StoreEntry) * (ring > 0 ? ring_store_entries(ring, units[b].qlen, units[b].tlen)
                                                             : pair_store_entries(units[b].qlen, units[b].tlen));
             if (b > a && (peqBytes + pb > peqBudget || storeBytes + sb > storeBudget)) break;
             peqBytes += pb; storeBytes += sb; ++b;
@@ -1153,21 +1154,24 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         d.peqOff = peqWords; peqWords += nb * tab_.sigmaT;
         d.auxOff = auxInts; if (nb > 64 && !ring) auxInts += s.tlen;
         d.storeOff = storeEntries;
-        if (wantPath) storeEntries += ring ? ring_store_entries(ring, s.qlen, s.tlen) : pair_store_entries(s.qlen, s.tlen);
+        if (wantPath) storeEntries += ring > 0 ? ring_store_entries(ring, s.qlen, s.tlen) : pair_store_entries(s.qlen, s.tlen);
         d.posCap = wantPositions ? kPosCap : 0;
         d.posOff = (long long)i * kPosCap;
-        d.colOff = -1; d.bandT = 0; d.ring = ring;
+        d.colOff = -1; d.bandT = 0; d.ring = ring > 0 ? ring : 0;
         // op slot of the unit, filled from the back.  An alignment has (m + T + inserts + deletes) / 2 ops, and a ring scan
         // is only walked when its distance is within kinit: (m + T + kinit) / 2 bounds the length (config 5: 1064 bytes
         // instead of 2000 per pair to bring back over PCIe)
         if (wantPath) {
             const long long full = (long long)s.qlen + s.tlen;
-            opsOff[i + 1] = opsOff[i] + (ring && s.kinit >= 0 && s.kinit < full ? (full + s.kinit) / 2 + 8 : full);
+            opsOff[i + 1] = opsOff[i] + (ring > 0 && s.kinit >= 0 && s.kinit < full ? (full + s.kinit) / 2 + 8 : full);
         }
         // executed work: whole matrix, or one 64-block wave per column inside the band
         // executed work: the strips update every block of every column; the rings count the updates inside the band themselves
         if (!ring) stats.word_steps += 2 * nb * (long long)s.tlen;
+        else if (ring == kWide) stats.word_steps += wide_word_steps(mode, s.qlen, s.tlen, 0, s.kinit);
     }
+    WidePlan wplan;
+    if (ring == kWide && planWide(mode, descs, n, wplan)) return 1;
     // A handful of units (edlibAlign() is one): the kernels write scores, positions and op strings straight into
     // device-visible pinned host memory -- no download commands behind the launches, one stream synchronisation.
     // (Descriptors still go up with a copy: the packed rings re-read them, and every read of host memory is a PCIe
@@ -1228,9 +1232,10 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     a.store = d_store_.p;
     a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p; a.posPool = d_posPool_.p;
     a.colP = nullptr; a.colM = nullptr; a.colS = nullptr;
-    a.wordSteps = ring ? ringStepsCounter() : nullptr;
+    a.wordSteps = ring > 0 ? ringStepsCounter() : nullptr;
     scanTimerStart();
-    if (ring) EDLIB_AMD_HIP(launch_scan_pairs_ring(ring, mode, wantPath, a, stream_, ringH));
+    if (ring == kWide) { if (launchWide(mode, a, descs, n, wplan)) return 1; }
+    else if (ring) EDLIB_AMD_HIP(launch_scan_pairs_ring(ring, mode, wantPath, a, stream_, ringH));
     else EDLIB_AMD_HIP(launch_scan_pairs(mode, wantPath, a, stream_));
     scanTimerStop();
     if (wantPath) {
@@ -1270,6 +1275,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     }
     const int* count = score + n; const int* last = count + n;
     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+    if (ring == kWide && checkWide()) return 1;
     lap("chunk: kernels+D2H");
 
     // exact second pass for units with more end locations than kPosCap
@@ -1286,16 +1292,20 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
             DevBuf<PairDesc> dd; DevBuf<int> pool2, s2, c2, l2;
             EDLIB_AMD_HIP(dd.alloc(d2.size())); EDLIB_AMD_HIP(pool2.alloc((size_t)ovfOff.back()));
             EDLIB_AMD_HIP(s2.alloc(d2.size())); EDLIB_AMD_HIP(c2.alloc(d2.size())); EDLIB_AMD_HIP(l2.alloc(d2.size()));
+            WidePlan wp2;
+            if (ring == kWide && planWide(mode, d2.data(), d2.size(), wp2)) return 1;
             EDLIB_AMD_HIP(hipMemcpyAsync(dd.p, d2.data(), d2.size() * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
             PairScanArgs a2 = a;
             a2.descs = dd.p; a2.numUnits = (int)d2.size(); a2.posPool = pool2.p;
             a2.outScore = s2.p; a2.outCount = c2.p; a2.outLast = l2.p;
             scanTimerStart();
-            EDLIB_AMD_HIP(launch_scan_pairs(mode, false, a2, stream_));
+            if (ring == kWide) { if (launchWide(mode, a2, d2.data(), d2.size(), wp2)) return 1; }
+            else EDLIB_AMD_HIP(launch_scan_pairs(mode, false, a2, stream_));
             scanTimerStop();
             ovfPos.resize((size_t)ovfOff.back());
             EDLIB_AMD_HIP(hipMemcpyAsync(ovfPos.data(), pool2.p, ovfPos.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
             EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+            if (ring == kWide && checkWide()) return 1;
             stats.overflow_units += (int)ovf.size();
             for (size_t j = 0; j < ovf.size(); ++j) {
                 const PairDesc& d = d2[j];
@@ -1332,6 +1342,58 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     if (zeroCopy) {          // the views into this chunk's pinned block die with it
         d_out3_.release(); d_posPool_.release(); d_opsLen_.release(); d_opsOff_.release(); d_ops_.release();
         d_outScore_.release(); d_outCount_.release(); d_outLast_.release();
+    }
+    return 0;
+}
+
+// ------------------------------------------------------ one unit on many waves
+
+// The strips of a unit run as a pipeline over `slots` single-wave workgroups whose hand-offs spin, so every workgroup of a
+// launch has to be resident: slots * (units per launch) stays within what the device holds (wide_resident_waves).
+int Batch::planWide(int mode, PairDesc* descs, size_t n, WidePlan& plan)
+{
+    if (wideCap_ < 0) wideCap_ = wide_resident_waves(tab_.sigmaT);
+    if (wideCap_ <= 0) { set_error("wide kernel: no resident waves (occupancy query failed)"); return 1; }
+    int want = 1;
+    for (size_t i = 0; i < n; ++i) want = std::max(want, wide_slots_wanted(mode, descs[i].qlen, descs[i].tlen, descs[i].bandT, descs[i].kinit));
+    if (const char* e = getenv("EDLIB_AMD_WIDE_SLOTS")) { if (atoi(e) > 0) want = atoi(e); }      // (tests: fewer slots than strips alive)
+    plan.slots = std::min(want, wideCap_);
+    plan.perLaunch = (size_t)std::max(1, wideCap_ / plan.slots);
+    long long words = 0, most = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (i % plan.perLaunch == 0) words = 0;
+        descs[i].auxOff = words;
+        words += wide_stream_words(descs[i].tlen, plan.slots);
+        most = std::max(most, words);
+    }
+    EDLIB_AMD_HIP(d_wide_.ensure((size_t)most));
+    if (!d_wabort_.p) { EDLIB_AMD_HIP(d_wabort_.alloc(1)); EDLIB_AMD_HIP(h_wabort_.alloc(sizeof(unsigned))); }
+    EDLIB_AMD_HIP(hipMemsetAsync(d_wabort_.p, 0, sizeof(unsigned), stream_));
+    return 0;
+}
+
+int Batch::launchWide(int mode, const PairScanArgs& a0, const PairDesc* hostDescs, size_t n, const WidePlan& plan)
+{
+    for (size_t g0 = 0; g0 < n; g0 += plan.perLaunch) {
+        const size_t g1 = std::min(n, g0 + plan.perLaunch);
+        const long long words = hostDescs[g1 - 1].auxOff + wide_stream_words(hostDescs[g1 - 1].tlen, plan.slots);
+        // every polled word starts at zero (tags are strip + 1): a granule of an earlier launch must never look fresh
+        EDLIB_AMD_HIP(hipMemsetAsync(d_wide_.p, 0, (size_t)words * sizeof(unsigned long long), stream_));
+        PairScanArgs a = a0;
+        a.descs = a0.descs + g0; a.numUnits = (int)(g1 - g0);
+        a.outScore = a0.outScore + g0; a.outCount = a0.outCount + g0; a.outLast = a0.outLast + g0;
+        a.wstream = d_wide_.p; a.wabort = d_wabort_.p;
+        EDLIB_AMD_HIP(launch_scan_pairs_wide(mode, a, plan.slots, stream_));
+    }
+    EDLIB_AMD_HIP(hipMemcpyAsync(h_wabort_.p, d_wabort_.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
+    return 0;
+}
+
+int Batch::checkWide()
+{
+    if (h_wabort_.p && *reinterpret_cast<const unsigned*>(h_wabort_.p) != 0u) {
+        set_error("wide kernel: a strip hand-off timed out (launch aborted)");
+        return 1;
     }
     return 0;
 }
@@ -1596,26 +1658,34 @@ int Batch::hirschbergLevel(const std::vector<PathPiece>& big, std::vector<int>& 
     for (int g = 0; g <= kNumRings; ++g) for (size_t p = 0; p < np; ++p) if (groupOf[p] == g) order.push_back(p);
     std::vector<PairDesc> descs(2 * np);
     std::vector<int> best(np);
+    // what no ring holds: the band on many waves (wide_kernels.hip); EDLIB_AMD_WIDE=0: the unbanded strips of round 3
+    const bool wideOff = getenv("EDLIB_AMD_WIDE") && getenv("EDLIB_AMD_WIDE")[0] == '0';
     long long peqWords = 0, auxInts = 0, colBlocks = 0;
     for (size_t q = 0; q < np; ++q) {
         const PathPiece& pc = big[order[q]];
         const int ring = rings[groupOf[order[q]]];
-        const bool banded = ring != 0;
+        const bool wide = ring == 0 && !wideOff;
+        const bool banded = ring != 0 || wide;
         const int lw = pc.T / 2, rw = pc.T - lw;                         // :1247-1248
         const long long nb = (pc.m + 63) / 64;
         best[q] = pc.score;
         for (int side = 0; side < 2; ++side) {
             PairDesc& d = descs[2 * q + side];
             d.qlen = pc.m; d.kinit = banded ? pc.score : 0; d.posCap = 0; d.posOff = 0; d.storeOff = 0;
-            d.bandT = banded ? pc.T : 0; d.ring = 0;
+            d.bandT = banded ? pc.T : 0; d.ring = 0; d.skip = 0;
             if (side == 0) { d.qoff = pc.qoff; d.qstep = 1; d.toff = pc.toff; d.tstep = 1; d.tlen = lw; }
             else { d.qoff = pc.qoff + pc.m - 1; d.qstep = -1; d.toff = pc.toff + pc.T - 1; d.tstep = -1; d.tlen = rw; }
             d.peqOff = peqWords; peqWords += nb * tab_.sigmaT;
             d.auxOff = auxInts; if (nb > 64 && !banded) auxInts += d.tlen;
             d.colOff = colBlocks; colBlocks += nb;
             if (!banded) stats.word_steps += 2 * nb * (long long)d.tlen;
+            else if (wide) stats.word_steps += wide_word_steps(0, d.qlen, d.tlen, d.bandT, d.kinit);
         }
     }
+    const size_t firstWide = np - groupCount[kNumRings];               // (the groups are laid out in ring order, this one last)
+    WidePlan wplan;
+    const bool anyWide = groupCount[kNumRings] > 0 && !wideOff;
+    if (anyWide && planWide(0, descs.data() + 2 * firstWide, 2 * groupCount[kNumRings], wplan)) return 1;
     const size_t n = descs.size();
     DevBuf<unsigned long long> colP, colM; DevBuf<int> colS, d_best, d_out;
     EDLIB_AMD_HIP(colP.alloc((size_t)colBlocks)); EDLIB_AMD_HIP(colM.alloc((size_t)colBlocks)); EDLIB_AMD_HIP(colS.alloc((size_t)colBlocks));
@@ -1652,6 +1722,7 @@ int Batch::hirschbergLevel(const std::vector<PathPiece>& big, std::vector<int>& 
         a.outScore = d_outScore_.p + 2 * first; a.outCount = d_outCount_.p + 2 * first; a.outLast = d_outLast_.p + 2 * first;
         scanTimerStart();
         if (rings[g]) EDLIB_AMD_HIP(launch_scan_pairs_ring(rings[g], 0, false, a, stream_));
+        else if (anyWide) { if (launchWide(0, a, descs.data() + 2 * first, 2 * groupCount[g], wplan)) return 1; }
         else EDLIB_AMD_HIP(launch_scan_pairs(EDLIB_MODE_NW, false, a, stream_));
         scanTimerStop();
         first += groupCount[g];
@@ -1663,6 +1734,7 @@ int Batch::hirschbergLevel(const std::vector<PathPiece>& big, std::vector<int>& 
     std::vector<int> out(3 * np);
     EDLIB_AMD_HIP(hipMemcpyAsync(out.data(), d_out.p, out.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+    if (anyWide && checkWide()) return 1;
     splitRow.resize(np); leftScore.resize(np); rightScore.resize(np);
     for (size_t q = 0; q < np; ++q) {
         const size_t p = order[q];
@@ -1852,13 +1924,17 @@ int Batch::solveSemiGlobalUnits(int mode, bool wantPositions, const std::vector<
     // units of up to 4 / 16 blocks on 4- / 16-lane rings, up to 32 / 64 blocks on 16-lane rings whose lanes hold 2 / 4
     // blocks (four units per wave, every lane busy: a 1025-base query on the strips uses 17 of a wave's 64 lanes), the
     // rest on the strips
-    static const int rings[5] = {4, 16, 16, 16, 0}, ringH[5] = {1, 1, 2, 4, 1};
-    const int NG = 5;
-    std::vector<int> grp(n, NG - 1);
-    size_t cnt[NG] = {0, 0, 0, 0, 0};
+    // more than 64 blocks: the strips as a pipeline over many waves (wide_kernels.hip) instead of one wave walking them
+    // one after the other
+    const bool wideOff = getenv("EDLIB_AMD_WIDE") && getenv("EDLIB_AMD_WIDE")[0] == '0';
+    static const int rings[6] = {4, 16, 16, 16, 0, kWide}, ringH[6] = {1, 1, 2, 4, 1, 1};
+    const int NG = 6;
+    std::vector<int> grp(n, 4);
+    size_t cnt[NG] = {0, 0, 0, 0, 0, 0};
     for (size_t i = 0; i < n; ++i) {
         const int nb = (units[i].qlen + 63) / 64;
         if (!ringsOff) grp[i] = nb <= 4 ? 0 : (nb <= 16 ? 1 : (nb <= 32 ? 2 : (nb <= 64 ? 3 : 4)));
+        if (nb > 64 && !wideOff) grp[i] = 5;
         ++cnt[grp[i]];
     }
     for (int g = 0; g < NG; ++g)
@@ -1947,6 +2023,31 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
     // 11.4 % sit under the 21-lane ring's 1216 -- three units per wave instead of two -- and the 7 % above it rerun).
     // (est = mean + sqrt(mean) / 2 + 8 <= cap is a bound on the mean: solved once per level, so that a unit costs a
     // multiply-add and a few compares -- the square root per unit was 2 ms of host time per 100,000 units)
+    // A handful of LONG units (the reference's 1 Mb Chromosome pairs, test_data/perf_tests.sh:180-191): a level costs its
+    // ~T dependent steps whether it succeeds or not (0.1 s per Mb), so each unit gets its own estimate from its first 4 kb
+    // (PREFIX mode on a 16-lane ring of 4-block lanes: ~1 ms) instead of climbing.
+    const bool wideOff = getenv("EDLIB_AMD_WIDE") && getenv("EDLIB_AMD_WIDE")[0] == '0';
+    std::vector<double> unitRate;
+    if (rate == 0.0 && n <= 512 && !bandOff && !getenv("EDLIB_AMD_NOPROBE")) {
+        std::vector<UnitSpec> probe; std::vector<size_t> who;
+        const int cut = 4096;
+        for (size_t i = 0; i < n; ++i)
+            if (std::min(units[i].qlen, units[i].tlen) >= 32768) {
+                UnitSpec u = units[i];
+                u.qlen = cut; u.tlen = cut + 512; u.kinit = cut;
+                probe.push_back(u); who.push_back(i);
+            }
+        if (!probe.empty()) {
+            SolveOut so;
+            if (solve(EDLIB_MODE_SHW, false, false, probe, so, 16, 4)) return 1;
+            unitRate.assign(n, 0.0);
+            for (size_t q = 0; q < probe.size(); ++q) unitRate[who[q]] = (double)std::max(so.score[q], 0) / cut;
+        }
+    }
+    auto mean_of = [&](size_t i) {
+        const UnitSpec& u = units[i];
+        return (unitRate.empty() ? rate : unitRate[i]) * std::min(u.qlen, u.tlen) + std::abs(u.qlen - u.tlen);
+    };
     double meanCap[kNumRings + 1];
     auto mean_cap = [](double cap) { if (cap < 8) return -1.0; const double r = (-0.5 + std::sqrt(0.25 + 4.0 * (cap - 8.0))) / 2.0; return r * r; };
     for (int l = 0; l < nl; ++l) meanCap[l] = mean_cap(std::min<double>(cap_of(l), kcap));
@@ -1954,12 +2055,14 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
     int levelOfKcap = nl;                                               // est = kcap when the caller's k is the smaller one
     for (int l = nl - 1; l >= 0; --l) if (kcap <= cap_of(l)) levelOfKcap = l;
     auto first_level = [&](size_t i) {
-        const UnitSpec& u = units[i];
-        const double mean = rate * std::min(u.qlen, u.tlen) + std::abs(u.qlen - u.tlen);
+        const double mean = mean_of(i);
         const int nbI = blocks(i);
         for (int l = 0; l < nl; ++l)
             if (nbI <= blocks_of(l) || mean <= meanCap[l] || l >= levelOfKcap) return l;
-        return (mean <= meanCap[nl] || kcap <= 2.0 * ring_max_k(64)) ? nl - 1 : nl;   // far above every band: straight to the strips
+        // above every ring: the band on many waves.  (Without it -- EDLIB_AMD_WIDE=0 -- the last ring is still tried while
+        // the estimate is within twice its limit: the unbanded strips cost nstrips times as much.)
+        if (wideOff) return (mean <= meanCap[nl] || kcap <= 2.0 * ring_max_k(64)) ? nl - 1 : nl;
+        return nl;
     };
     std::vector<int>& lvl = lvlScratch_;
     lvl.resize(n);
@@ -1971,7 +2074,7 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
     {
         int lastQ = -1, lastT = -1, lastL = 0;                           // batches of equal shapes: one evaluation
         for (size_t i = 0; i < n; ++i) {
-            if (units[i].qlen != lastQ || units[i].tlen != lastT) {
+            if (units[i].qlen != lastQ || units[i].tlen != lastT || !unitRate.empty()) {
                 lastQ = units[i].qlen; lastT = units[i].tlen;
                 lastL = bandOff ? nl : first_level(i);
                 if (!bandOff && fewUnits && lastL < nl - 1 && blocks(i) > blocks_of(lastL)) lastL = nl - 1;
@@ -1981,8 +2084,10 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
         }
     }
     Lap lap;
+    const bool wideLevel = !wideOff && paths == nullptr;                // what follows the rings: the wide band, else the strips
     for (int l = 0; l <= nl; ++l) {
         if (atLevel[l] == 0) continue;
+        if (l == nl && wideLevel) break;
         std::vector<UnitSpec>& sel = selScratch_; std::vector<size_t>& who = whoScratch_;
         sel.clear(); who.clear();
         sel.reserve(atLevel[l]); who.reserve(atLevel[l]);
@@ -2007,6 +2112,41 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
             else { lvl[i] = l + 1; ++atLevel[l + 1]; }                                   // next level
         }
         lap("nw level: scores");
+    }
+    // ---- beyond the rings: Ukkonen's band of ANY width on many waves (wide_kernels.hip).  The reference keeps doubling k
+    // (edlib.cpp:197-217); a pass here costs about T dependent steps whatever its K, so the first K is generous (1.5 x the
+    // estimate) and a failed pass doubles it.  K = max(m, T) is the whole matrix and always exact.
+    if (wideLevel && atLevel[nl] > 0) {
+        std::vector<size_t> rest;
+        std::vector<long long> kcur(n, 0);
+        for (size_t i = 0; i < n; ++i)
+            if (lvl[i] == nl) {
+                rest.push_back(i);
+                const double est = mean_of(i);
+                kcur[i] = std::max<long long>(2LL * (ring_max_k(64) + 128), (long long)(1.5 * est + 4.0 * std::sqrt(est) + 64.0));
+                if (const char* e = getenv("EDLIB_AMD_WIDE_K0")) { if (atoi(e) > 0) kcur[i] = atoi(e); }     // (tests: the ladder from a small K)
+            }
+        while (!rest.empty()) {
+            std::vector<UnitSpec>& sel = selScratch_;
+            sel.clear();
+            for (size_t i : rest) {
+                UnitSpec u = units[i];
+                u.kinit = (int)std::min<long long>(std::min<long long>(kcap, kcur[i]), std::max(u.qlen, u.tlen));
+                sel.push_back(u);
+            }
+            SolveOut& so = soLevel_;
+            if (solve(EDLIB_MODE_NW, false, false, sel, so, kWide)) return 1;
+            lap("nw wide level");
+            std::vector<size_t> again;
+            for (size_t q = 0; q < sel.size(); ++q) {
+                const size_t i = rest[q];
+                if (so.score[q] >= 0 && so.score[q] <= sel[q].kinit) score[i] = so.score[q];     // exact
+                else if (sel[q].kinit >= kcap) score[i] = kInf;                                     // > k: final
+                else if (sel[q].kinit >= std::max(sel[q].qlen, sel[q].tlen)) { set_error("wide band: no score inside the whole matrix"); return 1; }
+                else { kcur[i] = 2LL * sel[q].kinit; again.push_back(i); }
+            }
+            rest.swap(again);
+        }
     }
     return 0;
 }

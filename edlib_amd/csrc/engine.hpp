@@ -205,6 +205,15 @@ private:
               int ring = 0, int ringH = 1);
     int solveChunk(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units,
                    size_t a, size_t b, SolveOut& out, int ring, int ringH);
+    // ---- one unit on many waves (wide_kernels.hip): `ring` = kWide in solve() / solveChunk().  NW: the band of threshold
+    // UnitSpec::kinit, any width (exact iff score <= kinit); SHW / HW: the pipelined strips.  Distances / positions only.
+    static const int kWide = -1;
+    DevBuf<unsigned long long> d_wide_; DevBuf<unsigned> d_wabort_; PinBuf h_wabort_;
+    int wideCap_ = -1;                           // resident waves of the wide kernel on this device
+    struct WidePlan { int slots = 1; size_t perLaunch = 1; };
+    int planWide(int mode, PairDesc* descs, size_t n, WidePlan& plan);      // slots per unit, units per launch; assigns auxOff
+    int launchWide(int mode, const PairScanArgs& a, const PairDesc* hostDescs, size_t n, const WidePlan& plan);
+    int checkWide();                             // after the stream is idle: did a hand-off time out?
     // NW distances by threshold levels on rings of 4, 16, 64 lanes, then unbanded (the reference's
     // k-doubling, edlib.cpp:197-217, with thresholds chosen for the hardware)
     // paths != null (TASK_PATH, every unit below the 1 MiB rule): the levels run with the column store and the traceback, so

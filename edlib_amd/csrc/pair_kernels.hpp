@@ -71,6 +71,10 @@ struct PairScanArgs {
     // ring kernel: += 32-row word-columns of blocks INSIDE their life (the band), i.e. without the updates a lane runs on
     // dead state between two blocks (may be null)
     unsigned long long* wordSteps;
+    // wide kernel (wide_kernels.hip): hand-off granules of the strip pipelines (PairDesc::auxOff = the unit's first granule,
+    // wide_stream_words() per unit, zeroed before every launch) and the launch's abort word
+    unsigned long long* wstream;
+    unsigned* wabort;
 };
 
 // mode: 0 NW, 1 SHW, 2 HW.  store: also write the column store.
@@ -95,6 +99,16 @@ long long ring_store_entries(int ringLanes, int qlen, int tlen);
 // adds the word-steps inside the bands of `numUnits` ring units (64 H rows per ring-lane block, scan mode `mode`) to *out:
 // what launch_scan_pairs_ring does behind its scan when PairScanArgs::wordSteps is set
 hipError_t launch_count_ring_steps(const PairDesc* descs, int numUnits, int mode, int H, unsigned long long* out, hipStream_t stream);
+
+// One unit on many waves (wide_kernels.hip): strips of 64 blocks as a pipeline over `slots` resident single-wave workgroups
+// per unit (grid = slots x units: the caller keeps slots * units <= wide_resident_waves()).  mode 0: NW inside the band
+// of threshold desc.kinit (any K >= |tlen - qlen|, any query length; exact iff the result is <= K), desc.bandT / colOff
+// as for the rings; modes 1 / 2: every block of every column, outputs as launch_scan_pairs.  No column store.
+hipError_t launch_scan_pairs_wide(int mode, const PairScanArgs& a, int slots, hipStream_t stream);
+long long wide_stream_words(int tlen, int slots);                     // granules (u64) of one unit's hand-off area
+int wide_slots_wanted(int mode, int qlen, int tlen, int bandT, int K);   // waves that keep the unit's pipeline from stalling
+long long wide_word_steps(int mode, int qlen, int tlen, int bandT, int K);   // 32-row word-columns the launch computes
+int wide_resident_waves(int sigmaT);
 
 // reference buildPeq (edlib.cpp:358-384) for every unit: Peq[sym][block] from the
 // query bytes and the 256x256 byte equality matrix eq8 (identity + additionalEqualities).

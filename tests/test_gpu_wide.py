@@ -1,0 +1,126 @@
+"""-m gpu: one unit on many waves (scan_pairs_wide_kernel, edlib_amd/csrc/wide_kernels.hip) against the compiled
+reference: NW distances beyond the band of every lane ring (K > 3968), the K ladder from a small start, fewer pipeline
+slots than strips alive (hand-off buffers reused), Hirschberg halves on the wide band (TASK_PATH of long divergent
+pairs), long SHW / HW queries as pipelined strips, fixed k, mixed batches."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from edlib_amd import synth
+
+pytestmark = pytest.mark.gpu
+SEED_SHIFT = int(os.environ.get("EDLIB_FUZZ_SEED", "0"))
+FIELDS = ("status", "editDistance", "endLocations", "startLocations", "numLocations",
+          "alignment", "alignmentLength", "alphabetLength")
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _check(engine, impl, qs, ts, mode, task, k, what):
+    got = engine.align_pairs(qs, ts, mode=mode, task=task, k=k, raw=True)
+    bad = []
+    for i, (q, t, g) in enumerate(zip(qs, ts, got)):
+        want = impl.align(q, t, mode, task, k)
+        if want["status"] == 2:                       # oracle restatement: Hirschberg regime unsupported
+            continue
+        if any(g[f] != want[f] for f in FIELDS):
+            bad.append((i, len(q), len(t), {f: (g[f], want[f]) for f in FIELDS if g[f] != want[f] and f != "alignment"}))
+    assert not bad, (what, mode, task, k, bad[:3])
+
+
+def _mut(rng, n, sub, ins, dele):
+    t = synth.random_dna(rng.randrange(1 << 30), n)
+    q, _ = synth.mutate(t, rng.randrange(1 << 30), sub, ins, dele)
+    return q.tobytes(), t.tobytes()
+
+
+def test_nw_distances_beyond_the_rings(engine, checker):
+    """distances 4,000 ... 25,000 on queries of 5 ... 10 strips: first pass from the 4 kb prefix estimate"""
+    rng = random.Random(9001 + SEED_SHIFT)
+    qs, ts = [], []
+    for n, rate in ((33000, 0.06), (40000, 0.10), (36000, 0.25), (50000, 0.04), (34000, 0.5)):
+        q, t = _mut(rng, n, rate / 2, rate / 4, rate / 4)
+        qs.append(q); ts.append(t)
+    # unrelated, and very different lengths (|T - m| alone is beyond the rings)
+    qs.append(synth.random_dna(5, 33000).tobytes()); ts.append(synth.random_dna(6, 36000).tobytes())
+    qs.append(synth.random_dna(7, 9000).tobytes()); ts.append(synth.random_dna(8, 45000).tobytes())
+    qs.append(synth.random_dna(9, 47000).tobytes()); ts.append(synth.random_dna(10, 5000).tobytes())
+    for i in range(len(qs)):                           # one at a time (single call) ...
+        _check(engine, checker, qs[i:i + 1], ts[i:i + 1], "NW", "distance", -1, "wide single %d" % i)
+    _check(engine, checker, qs, ts, "NW", "distance", -1, "wide batch")       # ... and as one batch
+
+
+@pytest.mark.parametrize("slots", [None, 1, 2, 3])
+def test_k_ladder_from_a_small_start(engine, checker, slots):
+    """every pair on the wide kernel (rings off), K doubling from 64; with 1 / 2 / 3 slots a wave runs several strips of
+    its unit one after the other and the hand-off buffers of a slot are reused"""
+    rng = random.Random(9002 + SEED_SHIFT)
+    qs, ts = [], []
+    for n in (1, 63, 64, 65, 700, 4095, 4096, 4097, 8192, 8200, 12289, 17000, 21000):
+        for rate in (0.01, 0.2):
+            q, t = _mut(rng, n, rate / 2, rate / 4, rate / 4)
+            qs.append(q); ts.append(t)
+    qs.append(synth.random_dna(11, 9000).tobytes()); ts.append(synth.random_dna(12, 14000).tobytes())
+    with _env(EDLIB_AMD_NWBAND="0", EDLIB_AMD_WIDE_K0="64", EDLIB_AMD_WIDE_SLOTS=slots, EDLIB_AMD_ONEPAIR="0"):
+        _check(engine, checker, qs, ts, "NW", "distance", -1, "ladder slots=%s" % slots)
+        _check(engine, checker, qs[:10], ts[:10], "NW", "distance", 40, "ladder fixed k")
+
+
+def test_fixed_k_around_a_wide_distance(engine, checker):
+    rng = random.Random(9003 + SEED_SHIFT)
+    q, t = _mut(rng, 30000, 0.1, 0.05, 0.05)
+    d = checker.align(q, t, "NW", "distance", -1)["editDistance"]
+    assert d > 3968
+    for k in (d - 1, d, d + 1, 3968, 4000, 2 * d):
+        _check(engine, checker, [q], [t], "NW", "distance", k, "fixed k %d (d %d)" % (k, d))
+
+
+def test_paths_of_long_divergent_pairs(engine, ref):
+    """TASK_PATH: Hirschberg levels whose halves run inside bands beyond the rings (edlib.cpp:1231-1396)"""
+    if ref is None:
+        pytest.skip("the oracle restatement has no Hirschberg regime")
+    rng = random.Random(9004 + SEED_SHIFT)
+    qs, ts = [], []
+    for n, rate in ((30000, 0.2), (45000, 0.12), (20000, 0.5)):
+        q, t = _mut(rng, n, rate / 2, rate / 4, rate / 4)
+        qs.append(q); ts.append(t)
+    _check(engine, ref, qs, ts, "NW", "path", -1, "wide paths")
+    _check(engine, ref, qs[:1], ts[:1], "NW", "path", -1, "wide path single")
+
+
+@pytest.mark.parametrize("mode", ["SHW", "HW"])
+def test_long_semi_global_queries_as_pipelined_strips(engine, checker, mode):
+    rng = random.Random(9005 + SEED_SHIFT + len(mode))
+    qs, ts = [], []
+    for n, tn in ((4097, 9000), (9000, 30000), (13000, 13500), (20000, 5000)):
+        t = synth.random_dna(rng.randrange(1 << 30), tn)
+        a = 0 if mode == "SHW" else rng.randrange(0, max(1, tn - n))
+        src = t[a:a + n] if tn >= n else synth.random_dna(rng.randrange(1 << 30), n)
+        q, _ = synth.mutate(src, rng.randrange(1 << 30), 0.03, 0.01, 0.01)
+        qs.append(q.tobytes()); ts.append(t.tobytes())
+    qs.append(synth.random_dna(21, 5000).tobytes()); ts.append(synth.random_dna(22, 7000).tobytes())   # unrelated
+    for task in ("distance", "locations"):
+        _check(engine, checker, qs, ts, mode, task, -1, "strips %s" % task)
+    with _env(EDLIB_AMD_WIDE_SLOTS=1):
+        _check(engine, checker, qs, ts, mode, "distance", -1, "strips, one slot")
+    _check(engine, checker, qs[:2], ts[:2], mode, "distance", 300, "strips fixed k")
