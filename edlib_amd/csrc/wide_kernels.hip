@@ -43,7 +43,8 @@ typedef uint32_t u32;
 
 __host__ __device__ static inline int num_blocks(int m) { return (m + 63) >> 6; }
 
-constexpr long long kStripRows = 64 * 64;
+constexpr long long kStripRows = 64 * 32;                              // a strip: 64 lanes x one 32-row word
+__host__ __device__ static inline int num_words(int m) { return (m + 31) >> 5; }
 constexpr long long kWideInf = 1LL << 40;
 
 struct WideGeom { long long dmin, dmax; };
@@ -61,18 +62,18 @@ long long wide_stream_words(int tlen, int slots) { return (long long)slots * wid
 
 int wide_slots_wanted(int mode, int qlen, int tlen, int bandT, int K)
 {
-    const int nstrips = (num_blocks(qlen) + 63) / 64;
+    const int nstrips = (num_words(qlen) + 63) / 64;
     const WideGeom g = wide_geom(mode, qlen, tlen, bandT, K);
     long long bw = g.dmax - g.dmin + 1;
     if (bw > tlen) bw = tlen;
     if (bw < 0) bw = 0;
-    const long long live = (bw + 4096 + 63) / (4096 + 128) + 2;
+    const long long live = (bw + kStripRows + 63) / (kStripRows + 128) + 2;
     return (int)(live < nstrips ? live : nstrips);
 }
 
 long long wide_word_steps(int mode, int qlen, int tlen, int bandT, int K)
 {
-    const int nb = num_blocks(qlen), nstrips = (nb + 63) / 64;
+    const int nb = num_words(qlen), nstrips = (nb + 63) / 64;
     const WideGeom g = wide_geom(mode, qlen, tlen, bandT, K);
     long long v = 0;
     for (int s = 0; s < nstrips; ++s) {
@@ -82,7 +83,7 @@ long long wide_word_steps(int mode, int qlen, int tlen, int bandT, int K)
         if (c1 > tlen - 1) c1 = tlen - 1;
         if (c0 > c1) break;
         const int nbS = (nb - s * 64) < 64 ? (nb - s * 64) : 64;
-        v += 2LL * nbS * (c1 - c0 + 1);
+        v += (long long)nbS * (c1 - c0 + 1);
     }
     return v;
 }
@@ -103,17 +104,21 @@ __device__ __forceinline__ bool wide_spin_fail(unsigned& spins, const long long 
     return false;
 }
 
+#define BITOP3_OR_NOR32(a, b, c)  ((u32)__builtin_amdgcn_bitop3_b32((a), (b), (c), 0xf1))   /* a | ~(b | c)  */
+#define BITOP3_XOR_OR32(a, b, c)  ((u32)__builtin_amdgcn_bitop3_b32((a), (b), (c), 0xde))   /* (a ^ c) | b   */
+#define BITOP3_BFI(m, a, b)       ((u32)__builtin_amdgcn_bitop3_b32((m), (a), (b), 0xca))   /* m ? a : b     */
+
 template <int MODE, bool LDSPEQ>
 __global__ void __launch_bounds__(64)
 scan_pairs_wide_kernel(const PairScanArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) u64 s_peq[];      // [sigmaT][64]
+    extern __shared__ __attribute__((aligned(16))) u32 s_peq32[];    // [sigmaT][64] words of 32 rows
     const int lane = threadIdx.x;
     const int slot = blockIdx.x, W = gridDim.x, unit = blockIdx.y;
     const PairDesc d = a.descs[unit];
     const int m = d.qlen, T = d.tlen, K = d.kinit;
-    const int nb = num_blocks(m), nstrips = (nb + 63) >> 6;
-    const u32 sh = (u32)(m - 1) & 63u;                               // row m-1 inside the last block
+    const int nw = num_words(m), nb64 = num_blocks(m), nstrips = (nw + 63) >> 6;
+    const u32 sh = (u32)(m - 1) & 31u;                               // row m-1 inside the last word
     if (MODE == 0) {
         const long long D = (long long)(d.bandT ? d.bandT : T) - m, absD = D < 0 ? -D : D;
         if ((long long)K < absD) {                                   // no path of cost <= K exists (edlib.cpp:749-754)
@@ -127,9 +132,11 @@ scan_pairs_wide_kernel(const PairScanArgs a)
     int best = d.kinit, cnt = 0, lastCol = -1;                       // MODE != 0: columns scoring <= best qualify
     int* const pos = a.posPool + d.posOff;
     const bool dumpCol = a.colP != nullptr && d.colOff >= 0;
-    const u32 rowAbove = (MODE == 2) ? 0u : 0x55555555u;             // 16 codes of row -1: HW 0, SHW / NW +1 (:584, 779)
+    // a granule's data word: bit 15 - (c & 15) = "hout of column c is +1", bit 31 - (c & 15) = "is -1"
+    const u32 rowAbove = (MODE == 2) ? 0u : 0x0000ffffu;             // 16 columns of row -1: HW 0, SHW / NW +1 (:584, 779)
     const long long clk0 = (long long)wall_clock64();
     unsigned spins = 0;
+    const u32 laneOff = 4u * (u32)lane;
 
     for (int s = slot; s < nstrips; s += W) {
         const long long r0 = kStripRows * s;
@@ -140,7 +147,7 @@ scan_pairs_wide_kernel(const PairScanArgs a)
         const long long n0l = c0l + kStripRows, n1l = c1l + kStripRows;
         const int nextC0 = n0l < 0 ? 0 : (n0l > T ? T : (int)n0l);
         const bool nextLive = s + 1 < nstrips && nextC0 <= (n1l > T - 1 ? T - 1 : (int)n1l);
-        const int startCol = nextC0 - 1;                             // the strip below starts from our bottom score at this column
+        const int startCol = nextLive ? nextC0 - 1 : -0x40000000;    // the strip below starts from our bottom score at this column
         const bool hasUp = s > 0;
         const long long u1l = c1l - kStripRows;
         const int upC1 = u1l > T - 1 ? T - 1 : (int)u1l;             // last column of the strip above
@@ -148,16 +155,16 @@ scan_pairs_wide_kernel(const PairScanArgs a)
         u64* const myS = sbase + (long long)slot * per;
         const u32 tagUp = (u32)s, myTag = (u32)s + 1u;
 
-        const int nbS = (nb - s * 64) < 64 ? (nb - s * 64) : 64;
-        const int b = s * 64 + lane;
-        const bool laneOn = lane < nbS;
-        const bool tracker = b == nb - 1;                            // lane that owns row m-1
-        const unsigned long long* const peqRow = a.peq + d.peqOff + b;
+        const int nwS = (nw - s * 64) < 64 ? (nw - s * 64) : 64;
+        const int w = s * 64 + lane;                                 // this lane's 32-row word of the query
+        const bool laneOn = lane < nwS;
+        const bool tracker = w == nw - 1;                            // lane that owns row m-1
+        const u32* const peqRow = reinterpret_cast<const u32*>(a.peq + d.peqOff) + w;   // HBM Peq: [symbol][64-row block] u64
 
         if (LDSPEQ) {
-            __syncthreads();                                         // previous strip done with s_peq
+            __syncthreads();                                         // previous strip done with the slice
             for (int sy = 0; sy < a.sigmaT; ++sy)
-                s_peq[sy * 64 + lane] = laneOn ? a.peq[d.peqOff + (long long)sy * nb + b] : 0ull;
+                s_peq32[sy * 64 + lane] = laneOn ? peqRow[2LL * sy * nb64] : 0u;
             __syncthreads();
         }
 
@@ -171,15 +178,16 @@ scan_pairs_wide_kernel(const PairScanArgs a)
             }
             top = (int)(u32)v;
         }
-        Block64 B{~0u, ~0u, 0u, 0u};                                 // "+1 per row" (:759-763, 803-808)
-        int bscore = top + 64 * (lane + 1);                          // bottom of this lane's block at column c0 - 1
+        u32 Pv = ~0u, Mv = 0u;                                       // "+1 per row" (:759-763, 803-808)
+        int bscore = top + 32 * (lane + 1);                          // bottom of this lane's word at column c0 - 1
         int sc = top + (m - (int)r0);                                // row m-1 at column c0 - 1 (tracker)
-        u32 acc = 0;                                                 // the codes this lane emitted since the last fold, newest on top
+        u32 accP = 0, accM = 0;                                      // the houts of this lane since the last fold, newest at bit 0
+        u32 PhOut = 0, Bout = 0;                                     // what travels one lane down per step
 
-        // ---- target symbols (as LDS row offsets, symbol * 512) 64 columns per load, one chunk ahead
+        // ---- target symbols (as LDS row offsets, symbol * 256) 64 columns per load, one chunk ahead
         auto load_t = [&](const int base) -> u32 {
             const int c = base + lane;
-            return (c < T) ? (u32)a.tlut[a.tpool[d.toff + (long long)c * d.tstep]] << 9 : 0u;
+            return (c < T) ? (u32)a.tlut[a.tpool[d.toff + (long long)c * d.tstep]] << 8 : 0u;
         };
         const int base0 = c0 & ~63;
         u32 tcur = load_t(base0), tnext = load_t(base0 + 64);
@@ -192,16 +200,17 @@ scan_pairs_wide_kernel(const PairScanArgs a)
         };
         auto h_data = [&](const int base, const u64 v) -> u32 {
             const int gc = base + 16 * (lane & 3);
-            if (gc > upC1) return 0x55555555u;                       // beyond the life of the strip above: +1 per column
-            u32 w = (u32)v;
+            if (gc > upC1) return 0x0000ffffu;                       // beyond the life of the strip above: +1 per column
+            u32 x = (u32)v;
             if (gc + 15 > upC1) {                                    // its last granule: the columns behind upC1 likewise
-                const u32 mask = (1u << (2 * (upC1 - gc + 1))) - 1u;
-                w = (w & mask) | (0x55555555u & ~mask);
+                const u32 low = (1u << (15 - (upC1 - gc))) - 1u;     // their "+1" bits; the same bits 16 up are their "-1" bits
+                x = (x & ~(low | (low << 16))) | low;
             }
-            return w;
+            return x;
         };
         u32 hcur = rowAbove;
         u64 hnext = 0;
+        bool bail = false;
         if (hasUp) {
             u64 v = load_h(base0);
             while (__builtin_amdgcn_ballot_w64(!h_ok(base0, v)) != 0ull) {
@@ -211,48 +220,78 @@ scan_pairs_wide_kernel(const PairScanArgs a)
             hcur = h_data(base0, v);
             hnext = load_h(base0 + 64);
         }
+        auto rotate_t = [&](const int jn) { tcur = tnext; tnext = load_t(jn + 64); };
+        auto rotate_h = [&](const int j) {                           // entering the 64 columns from j on
+            u64 v = hnext;
+            while (__builtin_amdgcn_ballot_w64(!h_ok(j, v)) != 0ull) {
+                if (wide_spin_fail(spins, clk0, a.wabort)) { bail = true; break; }
+                v = load_h(j);
+            }
+            hcur = h_data(j, v);
+            hnext = load_h(j + 64);
+        };
+        u32 hwS = 0;                                                 // granule word of lane 0's current 16 columns (uniform)
 
         const int span = c1 - c0;                                    // lane l is active at steps l .. l + span
         const int nsteps = span + 64;
-        u32 carry = 0;
-        bool bail = false;
+        u32 eq = 0;                                                  // Peq word of this lane's current column
 
-        // One step: lane 0 is at column j = c0 + t.  The word that travels one lane down per step is
-        // {LDS offset of the receiver's Peq word of its NEXT column, code of the sender's hout}: offset = symbol * 512
-        // + lane * 8 grows by 8 per hop, the code sits in its low bits.  Lane 0 is fed {symbol of column j + 1, row
-        // above at column j} through the DPP `old` operand.
-        auto step = [&](auto fullTag, const int t, const u64 eqCur, u64& eqNxt) {
-            constexpr bool FULL = decltype(fullTag)::value;
-            const int j = c0 + t, jn = j + 1;
-            if (t >= 0 && (jn & 63) == 0) { tcur = tnext; tnext = load_t(jn + 64); }
-            if (hasUp && t > 0 && (j & 63) == 0) {
-                u64 v = hnext;
-                while (__builtin_amdgcn_ballot_w64(!h_ok(j, v)) != 0ull) {
-                    if (wide_spin_fail(spins, clk0, a.wabort)) { bail = true; break; }
-                    v = load_h(j);
-                }
-                hcur = h_data(j, v);
-                hnext = load_h(j + 64);
+        // The fold: every 16 columns of lane 63 the houts of all lanes go into their word scores; lane 63's are the
+        // granule of those columns (its last granule holds fewer: moved up to their columns' bits)
+        auto fold = [&](const int c63) {
+            if (nextLive && c63 >= c0 && c63 <= c1 && lane == 63) {
+                const int up = 15 - (c63 & 15);
+                st_agent(myS + 1 + (c63 >> 4), ((u64)myTag << 32) | ((accP << up) & 0xffffu) | ((accM << up) << 16));
             }
+            bscore += __popc(accP) - __popc(accM);
+            accP = 0; accM = 0;
+        };
+
+        // One step: lane 0 is at column j = c0 + t.  Two words travel one lane down per step: A = the sender's Ph (its
+        // bit 31 is hout = +1) and B = {bit 31: the sender's Mh bit 31 (hout = -1), bits 8..: LDS row offset of the
+        // receiver's NEXT column's symbol}.  Lane 0 is fed the row above at column j and the symbol of column j + 1
+        // through the DPP `old` operands.  POS = j & 15 where the caller knows it (unrolled blocks), else -1.
+        auto step = [&](auto fullTag, auto posTag, const int t) {
+            constexpr bool FULL = decltype(fullTag)::value;
+            constexpr int POS = decltype(posTag)::value;
+            const int j = c0 + t, jn = j + 1;
+            if (POS < 0) {
+                if (t >= 0 && (jn & 63) == 0) rotate_t(jn);
+                if (hasUp && t > 0 && (j & 63) == 0) rotate_h(j);
+                hwS = (u32)__builtin_amdgcn_readlane((int)hcur, (j >> 4) & 3);
+            }
+            const int pj = POS >= 0 ? POS : (j & 15);
             const u32 symw = (u32)__builtin_amdgcn_readlane((int)tcur, jn & 63);
-            const u32 hw = (u32)__builtin_amdgcn_readlane((int)hcur, (j >> 4) & 3);
-            const u32 in0 = symw | ((hw >> (2 * (j & 15))) & 3u);
-            const u32 x = (u32)__builtin_amdgcn_update_dpp((int)in0, (int)carry, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
-            const u32 addr = x & ~7u;
-            if (LDSPEQ) eqNxt = *reinterpret_cast<const u64*>(reinterpret_cast<const char*>(s_peq) + addr);
-            else eqNxt = laneOn ? peqRow[(long long)(x >> 9) * nb] : 0ull;
-            u32 code = 0;
+            const u32 feedA = hwS << (16 + pj);
+            const u32 feedB = ((hwS << pj) & 0x80000000u) | symw;
+            const u32 A = (u32)__builtin_amdgcn_update_dpp((int)feedA, (int)PhOut, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+            const u32 Bv = (u32)__builtin_amdgcn_update_dpp((int)feedB, (int)Bout, 0x138, 0xf, 0xf, false);
+            u32 eqNxt;
+            // (the slice is the only LDS object: its address is 0, and an address_space(3) access keeps hipcc from adding it)
+            if (LDSPEQ) eqNxt = *(const __attribute__((address_space(3))) u32*)(size_t)((Bv & 0x7fffff00u) | laneOff);
+            else eqNxt = laneOn ? peqRow[2LL * ((Bv & 0x7fffffffu) >> 8) * nb64] : 0u;
             const int rel = t - lane;
             if (FULL || (laneOn && (unsigned)rel <= (unsigned)span)) {
-                u32 ph0, ph1, mh0, mh1;
-                advance_block64(B, (u32)eqCur, (u32)(eqCur >> 32), x & 1u, (x >> 1) & 1u, ph0, ph1, mh0, mh1);
-                code = (ph1 >> 31) | ((mh1 >> 31) << 1);
-                acc = (acc >> 2) | (code << 30);
+                // reference calculateBlock (edlib.cpp:412-447) on a 32-row word
+                const u32 hneg = Bv >> 31;
+                const u32 eqn = eq | hneg;                            // Eq |= hinIsNeg     (:423)
+                const u32 xv = eq | Mv;                               // Xv = Eq | Mv       (:421)
+                const u32 sum = (eqn & Pv) + Pv;
+                const u32 xh = BITOP3_XOR_OR32(sum, eqn, Pv);         // (:424)
+                const u32 ph = BITOP3_OR_NOR32(Mv, xh, Pv);           // (:426)
+                const u32 mh = Pv & xh;                               // (:427)
+                const u32 phs = __builtin_amdgcn_alignbit(ph, A, 31);     // (ph << 1) | hin > 0   (:435-441)
+                const u32 mhs = __builtin_amdgcn_alignbit(mh, Bv, 31);    // (mh << 1) | hin < 0
+                Pv = BITOP3_OR_NOR32(mhs, xv, phs);
+                Mv = phs & xv;
+                PhOut = ph;
+                Bout = BITOP3_BFI(0x80000000u, mh, Bv);
+                accP = __builtin_amdgcn_alignbit(accP, ph, 31);       // (acc << 1) | hout bit
+                accM = __builtin_amdgcn_alignbit(accM, mh, 31);
                 if (MODE != 0) {
                     if (tracker) {
-                        const u64 ph = ((u64)ph1 << 32) | ph0, mh = ((u64)mh1 << 32) | mh0;
                         const int col = c0 + rel;
-                        sc += (int)((ph >> sh) & 1ull) - (int)((mh >> sh) & 1ull);
+                        sc += (int)((ph >> sh) & 1u) - (int)((mh >> sh) & 1u);
                         if (sc <= best && col >= d.skip) {           // edlib.cpp:658-673
                             if (sc < best) { best = sc; cnt = 0; }
                             if (cnt < d.posCap) pos[cnt] = col;
@@ -261,45 +300,65 @@ scan_pairs_wide_kernel(const PairScanArgs a)
                         }
                     }
                 }
+            } else {
+                Bout = Bv;                                            // every lane forwards the symbol stream
             }
-            carry = addr + 8u + code;                                // every lane forwards the symbol stream
-            // ---- every 16 steps (uniform in t) the codes are folded into the block score; the 16 codes of lane 63 are the
-            // granule of its columns c63 - 15 .. c63 (its last granule holds fewer: moved down to their columns' bits)
-            const int c63 = j - 63;
-            const bool live63 = nextLive && c63 >= c0 && c63 <= c1;
-            if (live63 && c63 == startCol) {
-                const int now = bscore + __popc(acc & 0x55555555u) - __popc(acc & 0xaaaaaaaau);
-                if (lane == 63) st_agent(myS, ((u64)myTag << 32) | (u32)now);
-            }
-            if ((c63 & 15) == 15 || c63 == c1) {
-                if (live63 && lane == 63) st_agent(myS + 1 + (c63 >> 4), ((u64)myTag << 32) | (acc >> (2 * (15 - (c63 & 15)))));
-                bscore += __popc(acc & 0x55555555u) - __popc(acc & 0xaaaaaaaau);
-                acc = 0;
+            eq = eqNxt;
+            if (POS < 0) {                                            // what lane 63 has finished (uniform in t)
+                const int c63 = j - 63;
+                if (c63 == startCol && c63 >= c0 && c63 <= c1) {
+                    const int now = bscore + __popc(accP) - __popc(accM);
+                    if (lane == 63) st_agent(myS, ((u64)myTag << 32) | (u32)now);
+                }
+                if ((c63 & 15) == 15 || c63 == c1) fold(c63);
             }
         };
-        u64 eqA = 0, eqB = 0;
-        for (int t = -1; t < nsteps && !bail; t += 2) {
-            if (t >= 63 && t + 1 <= span) {                          // every lane inside its columns
-                step(std::true_type{}, t, eqA, eqB);
-                step(std::true_type{}, t + 1, eqB, eqA);
+        auto P_ = [](auto v) { return v; };
+        for (int t = -1; t < nsteps && !bail;) {
+            const int j0 = c0 + t;
+            // sixteen straight-line steps: every lane inside its columns, lane 63 finishing a granule with the last one,
+            // nothing to publish but that granule
+            if (t >= 63 && t + 15 <= span && (j0 & 15) == 15 && !(startCol >= j0 - 63 && startCol <= j0 - 48)) {
+                if (((j0 + 1) & 63) == 0) rotate_t(j0 + 1);
+                step(std::true_type{}, std::integral_constant<int, 15>{}, t);
+                if (hasUp && ((j0 + 1) & 63) == 0) { rotate_h(j0 + 1); if (bail) break; }
+                hwS = (u32)__builtin_amdgcn_readlane((int)hcur, ((j0 + 1) >> 4) & 3);
+                step(std::true_type{}, std::integral_constant<int, 0>{}, t + 1);
+                step(std::true_type{}, std::integral_constant<int, 1>{}, t + 2);
+                step(std::true_type{}, std::integral_constant<int, 2>{}, t + 3);
+                step(std::true_type{}, std::integral_constant<int, 3>{}, t + 4);
+                step(std::true_type{}, std::integral_constant<int, 4>{}, t + 5);
+                step(std::true_type{}, std::integral_constant<int, 5>{}, t + 6);
+                step(std::true_type{}, std::integral_constant<int, 6>{}, t + 7);
+                step(std::true_type{}, std::integral_constant<int, 7>{}, t + 8);
+                step(std::true_type{}, std::integral_constant<int, 8>{}, t + 9);
+                step(std::true_type{}, std::integral_constant<int, 9>{}, t + 10);
+                step(std::true_type{}, std::integral_constant<int, 10>{}, t + 11);
+                step(std::true_type{}, std::integral_constant<int, 11>{}, t + 12);
+                step(std::true_type{}, std::integral_constant<int, 12>{}, t + 13);
+                step(std::true_type{}, std::integral_constant<int, 13>{}, t + 14);
+                step(std::true_type{}, std::integral_constant<int, 14>{}, t + 15);
+                fold(j0 + 15 - 63);
+                t += 16;
             } else {
-                step(std::false_type{}, t, eqA, eqB);
-                if (t + 1 < nsteps) step(std::false_type{}, t + 1, eqB, eqA);
+                step(std::false_type{}, std::integral_constant<int, -1>{}, t);
+                t += 1;
             }
         }
+        (void)P_;
         if (bail) return;
-        bscore += __popc(acc & 0x55555555u) - __popc(acc & 0xaaaaaaaau);       // (lanes above 63's last flush)
-        if (laneOn && c1 == T - 1 && dumpCol) {                      // stop column of a Hirschberg half
-            a.colP[d.colOff + b] = ((u64)B.p1 << 32) | B.p0; a.colM[d.colOff + b] = ((u64)B.m1 << 32) | B.m0;
-            a.colS[d.colOff + b] = bscore;
+        bscore += __popc(accP) - __popc(accM);                       // (what the last fold left)
+        if (laneOn && c1 == T - 1 && dumpCol) {                      // stop column of a Hirschberg half: 64-row blocks from two words
+            reinterpret_cast<u32*>(a.colP + d.colOff)[w] = Pv;
+            reinterpret_cast<u32*>(a.colM + d.colOff)[w] = Mv;
+            if ((w & 1) || w == nw - 1) a.colS[d.colOff + (w >> 1)] = bscore;      // (a missing upper half is all zeros)
         }
         if (tracker) {
             if (MODE == 0) {
                 if (c1 == T - 1) {
-                    // D[m][T] from the bottom score of row m-1's block and the vertical deltas below row m-1 (edlib.cpp:914-917)
-                    const u64 P = ((u64)B.p1 << 32) | B.p0, M = ((u64)B.m1 << 32) | B.m0;
-                    const u64 below = (sh == 63u) ? 0ull : (~0ull << (sh + 1));
-                    a.outScore[unit] = bscore - __popcll(P & below) + __popcll(M & below);
+                    // D[m][T] from the bottom score of row m-1's word and the vertical deltas below row m-1 (edlib.cpp:914-917)
+                    const u32 below = (sh == 31u) ? 0u : (~0u << (sh + 1));
+                    a.outScore[unit] = bscore - __popc(Pv & below) + __popc(Mv & below);
                     a.outCount[unit] = 1; a.outLast[unit] = T - 1;
                 }
             } else {
@@ -314,7 +373,7 @@ static hipError_t launch_wide_t(const PairScanArgs& a, int slots, hipStream_t st
 {
     const dim3 grid(slots, a.numUnits);
     if (a.sigmaT <= 32) {
-        const size_t lds = (size_t)a.sigmaT * 64 * sizeof(u64);
+        const size_t lds = (size_t)a.sigmaT * 64 * sizeof(u32);
         hipLaunchKernelGGL((scan_pairs_wide_kernel<MODE, true>), grid, dim3(64), lds, stream, a);
     } else {
         hipLaunchKernelGGL((scan_pairs_wide_kernel<MODE, false>), grid, dim3(64), 0, stream, a);
@@ -341,7 +400,7 @@ int wide_resident_waves(int sigmaT)
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     hipError_t e;
-    if (sigmaT <= 32) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, scan_pairs_wide_kernel<0, true>, 64, (size_t)sigmaT * 512);
+    if (sigmaT <= 32) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, scan_pairs_wide_kernel<0, true>, 64, (size_t)sigmaT * 256);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, scan_pairs_wide_kernel<0, false>, 64, 0);
     if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
     if (perCu > 8) perCu = 8;                                        // two waves per SIMD: more only share its issue slots

@@ -7,7 +7,7 @@ import random
 
 import pytest
 
-from wide_model import M64, geom, popc, strip_range, wide_scan
+from wide_model import M64, WB, geom, popc, strip_range, wide_scan
 
 ACGT = b"ACGT"
 
@@ -80,8 +80,8 @@ def test_hirschberg_half_dump(oracle, L):
         seen_exact = 0
         for b, (P, Mv, sc) in dump.items():
             v = sc
-            for bit in range(63, -1, -1):                   # decode from the bottom of the block upwards
-                i = 64 * b + bit
+            for bit in range(WB - 1, -1, -1):               # decode from the bottom of the word upwards
+                i = WB * b + bit
                 if i < len(q):
                     true = col[i + 1]
                     assert v >= true, (it, b, bit)
@@ -129,7 +129,7 @@ def test_strip_ranges_cover_the_band():
         K = abs(T - m) + rng.randrange(0, 3000)
         L = rng.choice([1, 2, 4, 64])
         dmin, dmax = geom(0, m, T, 0, K)
-        nb = (m + 63) // 64
+        nb = (m + WB - 1) // WB
         ns = (nb + L - 1) // L
         prev = None
         for s in range(ns):
@@ -139,7 +139,7 @@ def test_strip_ranges_cover_the_band():
                 assert all(strip_range(x, L, T, dmin, dmax)[0] > strip_range(x, L, T, dmin, dmax)[1] for x in range(s, ns))
                 break
             # every in-band cell of the strip's rows lies in its column range
-            for i in (64 * L * s, min(m, 64 * L * (s + 1)) - 1):
+            for i in (WB * L * s, min(m, WB * L * (s + 1)) - 1):
                 lo, hi = max(0, i + dmin), min(T - 1, i + dmax)
                 if lo <= hi:
                     assert c0 <= lo and hi <= c1

@@ -3,13 +3,16 @@ the strip pipeline restated over Python integers -- which columns a strip of L b
 above (the 2-bit codes of its bottom row's horizontal deltas in 16-column granules, +1 per column beyond the upper strip's
 last column, the absolute score it starts from), the codes folded into block scores every 16 steps, the NW score decode
 and the last-column dump of a Hirschberg half.  The hand-off PROTOCOL (tags, polling, slots) is not modelled: strips run
-one after the other here.  L (blocks per strip) is a parameter so that multi-strip cases stay small; the kernel has L = 64.
+one after the other here.  L (words per strip) is a parameter so that multi-strip cases stay small; the kernel has L = 64
+lanes of one 32-row word (WB = 32).
 
     D = bandT - m,  p = (K - |D|) >> 1,  [dmin, dmax] = [min(0, D) - p, max(0, D) + p]          (NW; SHW / HW: everything)
-    strip s: rows [64 L s, 64 L (s + 1)), columns [max(0, 64 L s + dmin), min(T - 1, 64 L s + 64 L - 1 + dmax)]
+    strip s: rows [WB L s, WB L (s + 1)), columns [max(0, WB L s + dmin), min(T - 1, WB L s + WB L - 1 + dmax)]
+    granule of 16 columns: bit 15 - (c & 15) = "hout of column c is +1", bit 31 - (c & 15) = "is -1"
 """
 
-M64 = (1 << 64) - 1
+WB = 32
+M64 = (1 << WB) - 1                                       # (the word mask; the name is the 64-row model's)
 
 
 def popc(x):
@@ -25,9 +28,9 @@ def geom(mode, m, T, bandT, K):
 
 
 def strip_range(s, L, T, dmin, dmax):
-    r0 = 64 * L * s
+    r0 = WB * L * s
     c0 = min(max(0, r0 + dmin), T)
-    c1 = min(T - 1, r0 + 64 * L - 1 + dmax)
+    c1 = min(T - 1, r0 + WB * L - 1 + dmax)
     return c0, c1
 
 
@@ -39,7 +42,7 @@ def block_step(pv, mv, eq, hin):
     xh = ((((eq2 & pv) + pv) & M64) ^ pv) | eq2
     ph = mv | (~(xh | pv) & M64)
     mh = pv & xh
-    hout = ((ph >> 63) & 1) - ((mh >> 63) & 1)
+    hout = ((ph >> (WB - 1)) & 1) - ((mh >> (WB - 1)) & 1)
     phu, mhu = ph, mh
     ph = (ph << 1) & M64
     mh = (mh << 1) & M64
@@ -54,7 +57,7 @@ def wide_scan(q, t, mode, K, L=64, bandT=0, skip=0, pos_cap=1 << 30):
     """(score, count, last, positions, dump) as the kernel leaves them.  NW: score exact iff <= K (None: K < |D|);
     dump = {block: (P, M, score)} of the blocks alive at column T - 1."""
     m, T = len(q), len(t)
-    nb = (m + 63) // 64
+    nb = (m + WB - 1) // WB
     nstrips = (nb + L - 1) // L
     if mode == 0 and K < abs((bandT or T) - m):
         return None
@@ -65,9 +68,9 @@ def wide_scan(q, t, mode, K, L=64, bandT=0, skip=0, pos_cap=1 << 30):
         for i, ch in enumerate(q):
             if ch == sy:
                 v |= 1 << i
-        peq[sy] = [(v >> (64 * b)) & M64 for b in range(nb)]
+        peq[sy] = [(v >> (WB * b)) & M64 for b in range(nb)]
     zero = [0] * nb
-    sh = (m - 1) & 63
+    sh = (m - 1) & (WB - 1)
     row_above = 0 if mode == 2 else 1                     # hin at row -1
     stream = {}                                           # granules of the previous strip: group -> 32-bit word
     start_score = None
@@ -83,7 +86,7 @@ def wide_scan(q, t, mode, K, L=64, bandT=0, skip=0, pos_cap=1 << 30):
             break
         nc0, nc1 = strip_range(s + 1, L, T, dmin, dmax)
         next_live = s + 1 < nstrips and nc0 <= nc1
-        r0 = 64 * L * s
+        r0 = WB * L * s
         nbS = min(L, nb - s * L)
         if c0 == 0:
             top = r0
@@ -92,8 +95,9 @@ def wide_scan(q, t, mode, K, L=64, bandT=0, skip=0, pos_cap=1 << 30):
             top = start_score
         P = [M64] * nbS
         Mv = [0] * nbS
-        bscore = [top + 64 * (l + 1) for l in range(nbS)]
-        acc = [0] * nbS                                    # 16 codes, newest on top
+        bscore = [top + WB * (l + 1) for l in range(nbS)]
+        accP = [0] * nbS                                   # the houts since the last fold, newest at bit 0
+        accM = [0] * nbS
         sc = top + (m - r0)
         out_stream = {}
         out_start = None
@@ -104,8 +108,7 @@ def wide_scan(q, t, mode, K, L=64, bandT=0, skip=0, pos_cap=1 << 30):
             if c > prev_c1:
                 return 1
             w = stream[c >> 4]
-            code = (w >> (2 * (c & 15))) & 3
-            return 1 if code == 1 else (-1 if code == 2 else 0)
+            return ((w >> (15 - (c & 15))) & 1) - ((w >> (31 - (c & 15))) & 1)
 
         for c in range(c0, c1 + 1):
             eqs = peq.get(t[c], zero)
@@ -113,8 +116,8 @@ def wide_scan(q, t, mode, K, L=64, bandT=0, skip=0, pos_cap=1 << 30):
             for l in range(nbS):
                 b = s * L + l
                 P[l], Mv[l], h, phu, mhu = block_step(P[l], Mv[l], eqs[b], h)
-                code = (1 if h > 0 else 0) | ((1 if h < 0 else 0) << 1)
-                acc[l] = (acc[l] >> 2) | (code << 30)
+                accP[l] = (accP[l] << 1) | (1 if h > 0 else 0)
+                accM[l] = (accM[l] << 1) | (1 if h < 0 else 0)
                 if mode != 0 and b == nb - 1:
                     sc += ((phu >> sh) & 1) - ((mhu >> sh) & 1)
                     if sc <= best and c >= skip:
@@ -128,13 +131,15 @@ def wide_scan(q, t, mode, K, L=64, bandT=0, skip=0, pos_cap=1 << 30):
             # lane L-1 has finished column c (the kernel's fold / flush schedule, in this lane's own time)
             lastl = nbS - 1
             if next_live and c == nc0 - 1:
-                out_start = bscore[lastl] + popc(acc[lastl] & 0x55555555) - popc(acc[lastl] & 0xaaaaaaaa)
+                out_start = bscore[lastl] + popc(accP[lastl]) - popc(accM[lastl])
             if (c & 15) == 15 or c == c1:
                 if next_live:
-                    out_stream[c >> 4] = acc[lastl] >> (2 * (15 - (c & 15)))
+                    up = 15 - (c & 15)
+                    out_stream[c >> 4] = ((accP[lastl] << up) & 0xffff) | ((accM[lastl] << up) << 16)
                 for l in range(nbS):
-                    bscore[l] += popc(acc[l] & 0x55555555) - popc(acc[l] & 0xaaaaaaaa)
-                    acc[l] = 0
+                    assert accP[l] < (1 << 16) and accM[l] < (1 << 16)
+                    bscore[l] += popc(accP[l]) - popc(accM[l])
+                    accP[l] = accM[l] = 0
         if c1 == T - 1:
             for l in range(nbS):
                 dump[s * L + l] = (P[l], Mv[l], bscore[l])
@@ -142,7 +147,7 @@ def wide_scan(q, t, mode, K, L=64, bandT=0, skip=0, pos_cap=1 << 30):
             if mode == 0:
                 if c1 == T - 1:
                     l = nb - 1 - s * L
-                    below = 0 if sh == 63 else (M64 << (sh + 1)) & M64
+                    below = 0 if sh == WB - 1 else (M64 << (sh + 1)) & M64
                     score = bscore[l] - popc(P[l] & below) + popc(Mv[l] & below)
                     count, last = 1, T - 1
             else:
