@@ -184,21 +184,26 @@ scan_pairs_wide_kernel(const PairScanArgs a)
         u32 accP = 0, accM = 0;                                      // the houts of this lane since the last fold, newest at bit 0
         u32 PhOut = 0, Bout = 0;                                     // what travels one lane down per step
 
-        // ---- target symbols (as LDS row offsets, symbol * 256) 64 columns per load, one chunk ahead
-        auto load_t = [&](const int base) -> u32 {
-            const int c = base + lane;
-            return (c < T) ? (u32)a.tlut[a.tpool[d.toff + (long long)c * d.tstep]] << 8 : 0u;
+        // ---- what lane 0 is fed, 64 columns at a time.  For lane 0's column j the feed is the pair {A, B}: A bit 31 = "the
+        // row above delivers +1 at column j", B = {bit 31: "delivers -1", bits 8..: LDS row offset (symbol * 256) of column
+        // j + 1}.  A chunk of 64 feeds is built lane-parallel when lane 0 enters it (lane i: column base + i) from the
+        // target bytes and the four granules of the strip above, both requested one chunk ahead, and written to an LDS
+        // ring; a step then costs lane 0's feed ONE broadcast LDS read instead of readlanes, shifts and ors in the scalar
+        // unit (a lone wave issues one instruction at a time, scalar or vector: they were a quarter of the step).
+        auto load_t = [&](const int base) -> u32 {                   // lane i: symbol of column base + i + 1
+            const int c = base + lane + 1;
+            return (c >= 0 && c < T) ? (u32)a.tlut[a.tpool[d.toff + (long long)c * d.tstep]] << 8 : 0u;
         };
-        const int base0 = c0 & ~63;
-        u32 tcur = load_t(base0), tnext = load_t(base0 + 64);
-        // ---- deltas of the row above: four granules (64 columns) per load, one chunk ahead
-        auto load_h = [&](const int base) -> u64 { return ld_agent(upS + 1 + (base >> 4) + (lane & 3)); };
-        auto h_ok = [&](const int base, const u64 v) -> bool {
+        auto h_needed = [&](const int base) -> bool {
             const int gc = base + 16 * (lane & 3);
-            const bool needed = gc + 15 >= c0 && gc <= upC1;
-            return !needed || (u32)(v >> 32) == tagUp;
+            return hasUp && gc + 15 >= c0 && gc <= upC1;
         };
+        auto load_h = [&](const int base) -> u64 {                   // lanes 4 g + {0..3}: granule of columns base + 16 g ..
+            return h_needed(base) ? ld_agent(upS + 1 + (base >> 4) + (lane & 3)) : 0ull;
+        };
+        auto h_ok = [&](const int base, const u64 v) -> bool { return !h_needed(base) || (u32)(v >> 32) == tagUp; };
         auto h_data = [&](const int base, const u64 v) -> u32 {
+            if (!hasUp) return rowAbove;
             const int gc = base + 16 * (lane & 3);
             if (gc > upC1) return 0x0000ffffu;                       // beyond the life of the strip above: +1 per column
             u32 x = (u32)v;
@@ -208,29 +213,33 @@ scan_pairs_wide_kernel(const PairScanArgs a)
             }
             return x;
         };
-        u32 hcur = rowAbove;
-        u64 hnext = 0;
         bool bail = false;
-        if (hasUp) {
-            u64 v = load_h(base0);
-            while (__builtin_amdgcn_ballot_w64(!h_ok(base0, v)) != 0ull) {
-                if (wide_spin_fail(spins, clk0, a.wabort)) return;
-                v = load_h(base0);
-            }
-            hcur = h_data(base0, v);
-            hnext = load_h(base0 + 64);
-        }
-        auto rotate_t = [&](const int jn) { tcur = tnext; tnext = load_t(jn + 64); };
-        auto rotate_h = [&](const int j) {                           // entering the 64 columns from j on
+        u32 tnext = 0; u64 hnext = 0;
+        const u32 feedBase = (u32)a.sigmaT * 256u * (LDSPEQ ? 1u : 0u);      // the feed ring follows the Peq slice
+        auto feed_at = [&](const u32 byteAddr) -> u64 { return *(const __attribute__((address_space(3))) u64*)(size_t)byteAddr; };
+        // lane 0 enters the 64 columns from `base` on (tnext / hnext hold what was requested for them)
+        auto enter_chunk = [&](const int base) {
             u64 v = hnext;
-            while (__builtin_amdgcn_ballot_w64(!h_ok(j, v)) != 0ull) {
+            while (__builtin_amdgcn_ballot_w64(!h_ok(base, v)) != 0ull) {
                 if (wide_spin_fail(spins, clk0, a.wabort)) { bail = true; break; }
-                v = load_h(j);
+                v = load_h(base);
             }
-            hcur = h_data(j, v);
-            hnext = load_h(j + 64);
+            const u32 words = h_data(base, v);                       // lanes 4 g + q: the word of group q
+            const u32 wd = (u32)__builtin_amdgcn_ds_bpermute(4 * (lane >> 4), (int)words);   // lane i: the word of ITS group
+            const u32 pj = (u32)lane & 15u;
+            const u32 fa = wd << (16u + pj);
+            const u32 fb = ((wd << pj) & 0x80000000u) | tnext;
+            *(__attribute__((address_space(3))) u64*)(size_t)(feedBase + 8u * (u32)lane) = ((u64)fb << 32) | fa;
+            tnext = load_t(base + 64);
+            hnext = load_h(base + 64);
         };
-        u32 hwS = 0;                                                 // granule word of lane 0's current 16 columns (uniform)
+        {
+            const int base0 = (c0 - 1) & ~63;                        // the chunk of lane 0's first step (column c0 - 1: symbols only)
+            tnext = load_t(base0);
+            hnext = load_h(base0);
+            enter_chunk(base0);
+            if (bail) return;
+        }
 
         const int span = c1 - c0;                                    // lane l is active at steps l .. l + span
         const int nsteps = span + 64;
@@ -249,29 +258,18 @@ scan_pairs_wide_kernel(const PairScanArgs a)
 
         // One step: lane 0 is at column j = c0 + t.  Two words travel one lane down per step: A = the sender's Ph (its
         // bit 31 is hout = +1) and B = {bit 31: the sender's Mh bit 31 (hout = -1), bits 8..: LDS row offset of the
-        // receiver's NEXT column's symbol}.  Lane 0 is fed the row above at column j and the symbol of column j + 1
-        // through the DPP `old` operands.  POS = j & 15 where the caller knows it (unrolled blocks), else -1.
-        auto step = [&](auto fullTag, auto posTag, const int t) {
-            constexpr bool FULL = decltype(fullTag)::value;
-            constexpr int POS = decltype(posTag)::value;
-            const int j = c0 + t, jn = j + 1;
-            if (POS < 0) {
-                if (t >= 0 && (jn & 63) == 0) rotate_t(jn);
-                if (hasUp && t > 0 && (j & 63) == 0) rotate_h(j);
-                hwS = (u32)__builtin_amdgcn_readlane((int)hcur, (j >> 4) & 3);
-            }
-            const int pj = POS >= 0 ? POS : (j & 15);
-            const u32 symw = (u32)__builtin_amdgcn_readlane((int)tcur, jn & 63);
-            const u32 feedA = hwS << (16 + pj);
-            const u32 feedB = ((hwS << pj) & 0x80000000u) | symw;
-            const u32 A = (u32)__builtin_amdgcn_update_dpp((int)feedA, (int)PhOut, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
-            const u32 Bv = (u32)__builtin_amdgcn_update_dpp((int)feedB, (int)Bout, 0x138, 0xf, 0xf, false);
+        // receiver's NEXT column's symbol}; lane 0 keeps its feed (the DPP `old` operands).  GENERIC: any step (rotation,
+        // publishing, lanes outside their columns); else a step inside a straight-line block.
+        auto step = [&](auto genericTag, const int t, const u64 feed) {
+            constexpr bool GENERIC = decltype(genericTag)::value;
+            const u32 A = (u32)__builtin_amdgcn_update_dpp((int)(u32)feed, (int)PhOut, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+            const u32 Bv = (u32)__builtin_amdgcn_update_dpp((int)(u32)(feed >> 32), (int)Bout, 0x138, 0xf, 0xf, false);
             u32 eqNxt;
-            // (the slice is the only LDS object: its address is 0, and an address_space(3) access keeps hipcc from adding it)
+            // (the slice is the first LDS object: its address is 0, and an address_space(3) access keeps hipcc from adding it)
             if (LDSPEQ) eqNxt = *(const __attribute__((address_space(3))) u32*)(size_t)((Bv & 0x7fffff00u) | laneOff);
             else eqNxt = laneOn ? peqRow[2LL * ((Bv & 0x7fffffffu) >> 8) * nb64] : 0u;
             const int rel = t - lane;
-            if (FULL || (laneOn && (unsigned)rel <= (unsigned)span)) {
+            if (!GENERIC || (laneOn && (unsigned)rel <= (unsigned)span)) {
                 // reference calculateBlock (edlib.cpp:412-447) on a 32-row word
                 const u32 hneg = Bv >> 31;
                 const u32 eqn = eq | hneg;                            // Eq |= hinIsNeg     (:423)
@@ -304,8 +302,8 @@ scan_pairs_wide_kernel(const PairScanArgs a)
                 Bout = Bv;                                            // every lane forwards the symbol stream
             }
             eq = eqNxt;
-            if (POS < 0) {                                            // what lane 63 has finished (uniform in t)
-                const int c63 = j - 63;
+            if (GENERIC) {                                            // what lane 63 has finished (uniform in t)
+                const int c63 = c0 + t - 63;
                 if (c63 == startCol && c63 >= c0 && c63 <= c1) {
                     const int now = bscore + __popc(accP) - __popc(accM);
                     if (lane == 63) st_agent(myS, ((u64)myTag << 32) | (u32)now);
@@ -313,39 +311,49 @@ scan_pairs_wide_kernel(const PairScanArgs a)
                 if ((c63 & 15) == 15 || c63 == c1) fold(c63);
             }
         };
-        auto P_ = [](auto v) { return v; };
         for (int t = -1; t < nsteps && !bail;) {
             const int j0 = c0 + t;
-            // sixteen straight-line steps: every lane inside its columns, lane 63 finishing a granule with the last one,
+            if (t >= 0 && (j0 & 63) == 0) { enter_chunk(j0); if (bail) break; }
+            const u32 slot0 = feedBase + 8u * ((u32)j0 & 63u);
+            // sixteen straight-line steps: every lane inside its columns, lane 63 finishing a granule with the fifteenth,
             // nothing to publish but that granule
-            if (t >= 63 && t + 15 <= span && (j0 & 15) == 15 && !(startCol >= j0 - 63 && startCol <= j0 - 48)) {
-                if (((j0 + 1) & 63) == 0) rotate_t(j0 + 1);
-                step(std::true_type{}, std::integral_constant<int, 15>{}, t);
-                if (hasUp && ((j0 + 1) & 63) == 0) { rotate_h(j0 + 1); if (bail) break; }
-                hwS = (u32)__builtin_amdgcn_readlane((int)hcur, ((j0 + 1) >> 4) & 3);
-                step(std::true_type{}, std::integral_constant<int, 0>{}, t + 1);
-                step(std::true_type{}, std::integral_constant<int, 1>{}, t + 2);
-                step(std::true_type{}, std::integral_constant<int, 2>{}, t + 3);
-                step(std::true_type{}, std::integral_constant<int, 3>{}, t + 4);
-                step(std::true_type{}, std::integral_constant<int, 4>{}, t + 5);
-                step(std::true_type{}, std::integral_constant<int, 5>{}, t + 6);
-                step(std::true_type{}, std::integral_constant<int, 6>{}, t + 7);
-                step(std::true_type{}, std::integral_constant<int, 7>{}, t + 8);
-                step(std::true_type{}, std::integral_constant<int, 8>{}, t + 9);
-                step(std::true_type{}, std::integral_constant<int, 9>{}, t + 10);
-                step(std::true_type{}, std::integral_constant<int, 10>{}, t + 11);
-                step(std::true_type{}, std::integral_constant<int, 11>{}, t + 12);
-                step(std::true_type{}, std::integral_constant<int, 12>{}, t + 13);
-                step(std::true_type{}, std::integral_constant<int, 13>{}, t + 14);
-                step(std::true_type{}, std::integral_constant<int, 14>{}, t + 15);
-                fold(j0 + 15 - 63);
+            if (t >= 63 && t + 15 <= span && (j0 & 15) == 0 && !(startCol >= j0 - 63 && startCol <= j0 - 48)) {
+                const u64 f0 = feed_at(slot0), f1 = feed_at(slot0 + 8), f2 = feed_at(slot0 + 16), f3 = feed_at(slot0 + 24);
+                step(std::false_type{}, t, f0);
+                const u64 f4 = feed_at(slot0 + 32);
+                step(std::false_type{}, t + 1, f1);
+                const u64 f5 = feed_at(slot0 + 40);
+                step(std::false_type{}, t + 2, f2);
+                const u64 f6 = feed_at(slot0 + 48);
+                step(std::false_type{}, t + 3, f3);
+                const u64 f7 = feed_at(slot0 + 56);
+                step(std::false_type{}, t + 4, f4);
+                const u64 f8 = feed_at(slot0 + 64);
+                step(std::false_type{}, t + 5, f5);
+                const u64 f9 = feed_at(slot0 + 72);
+                step(std::false_type{}, t + 6, f6);
+                const u64 f10 = feed_at(slot0 + 80);
+                step(std::false_type{}, t + 7, f7);
+                const u64 f11 = feed_at(slot0 + 88);
+                step(std::false_type{}, t + 8, f8);
+                const u64 f12 = feed_at(slot0 + 96);
+                step(std::false_type{}, t + 9, f9);
+                const u64 f13 = feed_at(slot0 + 104);
+                step(std::false_type{}, t + 10, f10);
+                const u64 f14 = feed_at(slot0 + 112);
+                step(std::false_type{}, t + 11, f11);
+                const u64 f15 = feed_at(slot0 + 120);
+                step(std::false_type{}, t + 12, f12);
+                step(std::false_type{}, t + 13, f13);
+                step(std::false_type{}, t + 14, f14);
+                fold(j0 + 14 - 63);
+                step(std::false_type{}, t + 15, f15);
                 t += 16;
             } else {
-                step(std::false_type{}, std::integral_constant<int, -1>{}, t);
+                step(std::true_type{}, t, feed_at(slot0));
                 t += 1;
             }
         }
-        (void)P_;
         if (bail) return;
         bscore += __popc(accP) - __popc(accM);                       // (what the last fold left)
         if (laneOn && c1 == T - 1 && dumpCol) {                      // stop column of a Hirschberg half: 64-row blocks from two words
@@ -373,10 +381,10 @@ static hipError_t launch_wide_t(const PairScanArgs& a, int slots, hipStream_t st
 {
     const dim3 grid(slots, a.numUnits);
     if (a.sigmaT <= 32) {
-        const size_t lds = (size_t)a.sigmaT * 64 * sizeof(u32);
+        const size_t lds = (size_t)a.sigmaT * 64 * sizeof(u32) + 512;     // Peq slice + the ring of lane 0's feeds
         hipLaunchKernelGGL((scan_pairs_wide_kernel<MODE, true>), grid, dim3(64), lds, stream, a);
     } else {
-        hipLaunchKernelGGL((scan_pairs_wide_kernel<MODE, false>), grid, dim3(64), 0, stream, a);
+        hipLaunchKernelGGL((scan_pairs_wide_kernel<MODE, false>), grid, dim3(64), 512, stream, a);
     }
     return hipGetLastError();
 }
@@ -400,8 +408,8 @@ int wide_resident_waves(int sigmaT)
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     hipError_t e;
-    if (sigmaT <= 32) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, scan_pairs_wide_kernel<0, true>, 64, (size_t)sigmaT * 256);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, scan_pairs_wide_kernel<0, false>, 64, 0);
+    if (sigmaT <= 32) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, scan_pairs_wide_kernel<0, true>, 64, (size_t)sigmaT * 256 + 512);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, scan_pairs_wide_kernel<0, false>, 64, 512);
     if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
     if (perCu > 8) perCu = 8;                                        // two waves per SIMD: more only share its issue slots
     if (perCu > 1) perCu -= 1;                                       // margin (the occupancy query can be one block per CU high)
