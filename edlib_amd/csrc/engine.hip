@@ -1743,6 +1743,74 @@ int Batch::hirschbergLevel(const std::vector<PathPiece>& big, std::vector<int>& 
     return 0;
 }
 
+// A scan of T columns is T dependent steps however many waves share its band; the two halves of the target are independent
+// of each other.  So the distance of a long unit is found like the first Hirschberg level finds its split
+// (edlib.cpp:1246-1260, 1314-1353): forward scan of (query, left half) and reverse scan of (reversed query, reversed right
+// half), both inside the band of the whole problem and dumped at their last column, then min over the query rows of
+// L[i] + R[i+1].  Half the dependent steps; exact iff the minimum is within the threshold (cells outside the band are
+// upper bounds).
+int Batch::solveWideSplit(const std::vector<UnitSpec>& units, std::vector<int>& out)
+{
+    const size_t np = units.size();
+    out.assign(4 * np, 0);
+    if (np == 0) return 0;
+    std::vector<PairDesc> descs(2 * np);
+    long long peqWords = 0, colBlocks = 0;
+    int maxRows = 1;
+    for (size_t q = 0; q < np; ++q) {
+        const UnitSpec& u = units[q];
+        const int lw = u.tlen / 2, rw = u.tlen - lw;
+        const long long nb = (u.qlen + 63) / 64;
+        maxRows = std::max(maxRows, u.qlen);
+        for (int side = 0; side < 2; ++side) {
+            PairDesc& d = descs[2 * q + side];
+            d.qlen = u.qlen; d.kinit = u.kinit; d.posCap = 0; d.posOff = 0; d.storeOff = 0; d.bandT = u.tlen; d.ring = 0; d.skip = 0;
+            if (side == 0) { d.qoff = u.qoff; d.qstep = u.qstep; d.toff = u.toff; d.tstep = u.tstep; d.tlen = lw; }
+            else {
+                d.qoff = u.qoff + (long long)(u.qlen - 1) * u.qstep; d.qstep = -u.qstep;
+                d.toff = u.toff + (long long)(u.tlen - 1) * u.tstep; d.tstep = -u.tstep; d.tlen = rw;
+            }
+            d.peqOff = peqWords; peqWords += nb * tab_.sigmaT;
+            d.auxOff = 0;
+            d.colOff = colBlocks; colBlocks += nb;
+            stats.word_steps += wide_word_steps(0, d.qlen, d.tlen, d.bandT, d.kinit);
+        }
+    }
+    WidePlan wplan;
+    if (planWide(0, descs.data(), descs.size(), wplan)) return 1;
+    const size_t n = descs.size();
+    DevBuf<unsigned long long> colP, colM, packed; DevBuf<int> colS, d_out;
+    EDLIB_AMD_HIP(colP.alloc((size_t)colBlocks)); EDLIB_AMD_HIP(colM.alloc((size_t)colBlocks)); EDLIB_AMD_HIP(colS.alloc((size_t)colBlocks));
+    EDLIB_AMD_HIP(packed.alloc(np)); EDLIB_AMD_HIP(d_out.alloc(4 * np));
+    // blocks outside the band at the stop column: P = M = 0 and a score no sum can reach
+    EDLIB_AMD_HIP(hipMemsetAsync(colP.p, 0, (size_t)colBlocks * 8, stream_));
+    EDLIB_AMD_HIP(hipMemsetAsync(colM.p, 0, (size_t)colBlocks * 8, stream_));
+    EDLIB_AMD_HIP(hipMemsetAsync(colS.p, 0x3f, (size_t)colBlocks * 4, stream_));
+    EDLIB_AMD_HIP(d_descs_.ensure(n)); EDLIB_AMD_HIP(d_peq64_.ensure((size_t)peqWords));
+    EDLIB_AMD_HIP(d_out3_.ensure(3 * n));
+    d_outScore_.alias(d_out3_.p, n); d_outCount_.alias(d_out3_.p + n, n); d_outLast_.alias(d_out3_.p + 2 * n, n);
+    EDLIB_AMD_HIP(d_posPool_.ensure(1));
+    EDLIB_AMD_HIP(hipMemcpyAsync(d_descs_.p, descs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
+    EDLIB_AMD_HIP(uploadEq8());
+    EDLIB_AMD_HIP(launch_build_peq_pairs(d_descs_.p, (int)n, d_qpool_.p, d_eq8_.p, d_idToByte_.p, tab_.sigmaT, d_peq64_.p, stream_));
+    PairScanArgs a{};
+    a.descs = d_descs_.p; a.numUnits = (int)n; a.qpool = d_qpool_.p; a.tpool = d_tpool_.p;
+    a.tlut = d_tlut_.p; a.sigmaT = tab_.sigmaT; a.peq = d_peq64_.p; a.aux = d_aux_.p; a.posPool = d_posPool_.p;
+    a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p;
+    a.colP = colP.p; a.colM = colM.p; a.colS = colS.p;
+    scanTimerStart();
+    if (launchWide(0, a, descs.data(), n, wplan)) return 1;
+    scanTimerStop();
+    SplitArgs sa{};
+    sa.descs = d_descs_.p; sa.numPieces = (int)np; sa.best = nullptr;
+    sa.colP = colP.p; sa.colM = colM.p; sa.colS = colS.p; sa.out = d_out.p;
+    EDLIB_AMD_HIP(launch_split_min(sa, packed.p, maxRows, stream_));
+    EDLIB_AMD_HIP(hipMemcpyAsync(out.data(), d_out.p, out.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+    if (checkWide()) return 1;
+    return 0;
+}
+
 // Alignment paths of NW jobs of any size (reference obtainAlignment, edlib.cpp:1161-1213): pieces at
 // or above the 1 MiB column-store estimate are halved Hirschberg-style, level by level across the
 // whole batch, until every piece fits the traceback branch; the pieces' op strings concatenate.
@@ -2126,25 +2194,38 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
                 kcur[i] = std::max<long long>(2LL * (ring_max_k(64) + 128), (long long)(1.5 * est + 4.0 * std::sqrt(est) + 64.0));
                 if (const char* e = getenv("EDLIB_AMD_WIDE_K0")) { if (atoi(e) > 0) kcur[i] = atoi(e); }     // (tests: the ladder from a small K)
             }
+        // long units: two half scans that meet in the middle (solveWideSplit: half the dependent steps); a unit of one
+        // target column has no two halves
+        const int splitMin = getenv("EDLIB_AMD_WIDE_SPLIT") ? atoi(getenv("EDLIB_AMD_WIDE_SPLIT")) : 16384;
         while (!rest.empty()) {
             std::vector<UnitSpec>& sel = selScratch_;
             sel.clear();
+            std::vector<UnitSpec> halves; std::vector<size_t> whoWhole, whoHalves;
             for (size_t i : rest) {
                 UnitSpec u = units[i];
                 u.kinit = (int)std::min<long long>(std::min<long long>(kcap, kcur[i]), std::max(u.qlen, u.tlen));
-                sel.push_back(u);
+                if (splitMin > 0 && std::min(u.qlen, u.tlen) >= splitMin && u.tlen >= 2) { halves.push_back(u); whoHalves.push_back(i); }
+                else { sel.push_back(u); whoWhole.push_back(i); }
             }
-            SolveOut& so = soLevel_;
-            if (solve(EDLIB_MODE_NW, false, false, sel, so, kWide)) return 1;
-            lap("nw wide level");
             std::vector<size_t> again;
-            for (size_t q = 0; q < sel.size(); ++q) {
-                const size_t i = rest[q];
-                if (so.score[q] >= 0 && so.score[q] <= sel[q].kinit) score[i] = so.score[q];     // exact
-                else if (sel[q].kinit >= kcap) score[i] = kInf;                                     // > k: final
-                else if (sel[q].kinit >= std::max(sel[q].qlen, sel[q].tlen)) { set_error("wide band: no score inside the whole matrix"); return 1; }
-                else { kcur[i] = 2LL * sel[q].kinit; again.push_back(i); }
+            auto settle = [&](size_t i, const UnitSpec& u, int got) -> int {
+                if (got >= 0 && got <= u.kinit) score[i] = got;                                   // exact
+                else if (u.kinit >= kcap) score[i] = kInf;                                          // > k: final
+                else if (u.kinit >= std::max(u.qlen, u.tlen)) { set_error("wide band: no score inside the whole matrix"); return 1; }
+                else { kcur[i] = 2LL * u.kinit; again.push_back(i); }
+                return 0;
+            };
+            if (!sel.empty()) {
+                SolveOut& so = soLevel_;
+                if (solve(EDLIB_MODE_NW, false, false, sel, so, kWide)) return 1;
+                for (size_t q = 0; q < sel.size(); ++q) if (settle(whoWhole[q], sel[q], so.score[q])) return 1;
             }
+            if (!halves.empty()) {
+                std::vector<int> sp;
+                if (solveWideSplit(halves, sp)) return 1;
+                for (size_t q = 0; q < halves.size(); ++q) if (settle(whoHalves[q], halves[q], sp[4 * q])) return 1;
+            }
+            lap("nw wide level");
             rest.swap(again);
         }
     }

@@ -214,6 +214,10 @@ private:
     int planWide(int mode, PairDesc* descs, size_t n, WidePlan& plan);      // slots per unit, units per launch; assigns auxOff
     int launchWide(int mode, const PairScanArgs& a, const PairDesc* hostDescs, size_t n, const WidePlan& plan);
     int checkWide();                             // after the stream is idle: did a hand-off time out?
+    // NW distance of long units as two half scans that meet in the middle (forward over the left half of the target,
+    // reverse over the right half, both inside the band of UnitSpec::kinit): out[4 u ..] = {min, split row, left, right};
+    // exact iff min <= kinit
+    int solveWideSplit(const std::vector<UnitSpec>& units, std::vector<int>& out);
     // NW distances by threshold levels on rings of 4, 16, 64 lanes, then unbanded (the reference's
     // k-doubling, edlib.cpp:197-217, with thresholds chosen for the hardware)
     // paths != null (TASK_PATH, every unit below the 1 MiB rule): the levels run with the column store and the traceback, so

@@ -771,6 +771,66 @@ hipError_t launch_hirschberg_split(const SplitArgs& a, hipStream_t stream)
     return hipGetLastError();
 }
 
+// The same pair of scans finds a DISTANCE: every alignment crosses from the left half of the target into the right half at
+// some query row i, so D[m][T] = min over i in [-1, m-1] of L[i] + R[i+1] (L, R as above; L[-1] = lw, R[m] = rw).  Two
+// half scans of T / 2 columns run side by side where one scan of T columns is T dependent steps.  Cells
+// outside the band are upper bounds, so the minimum is exact iff it is <= the scans' threshold.  Pass 1: packed
+// (sum << 32 | i) minima over the interior rows; pass 2: the boundary cases and the reference's preference among equal
+// sums (edlib.cpp:1321-1353: first interior row, then i = -1, then i = m-1) -- so the result is also the level-0 split of
+// the piece's path.  out[4p..4p+3] = {best, i, leftScore, rightScore}.
+__global__ void __launch_bounds__(256)
+split_min_rows_kernel(const SplitArgs a, unsigned long long* packed)
+{
+    const int p = blockIdx.y;
+    const PairDesc f = a.descs[2 * p], r = a.descs[2 * p + 1];
+    const int m = f.qlen;
+    unsigned long long mine = ~0ull;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i <= (long long)m - 2; i += (long long)gridDim.x * blockDim.x) {
+        const long long L = column_cell(a.colP, a.colM, a.colS, f.colOff, (int)i);
+        const long long R = column_cell(a.colP, a.colM, a.colS, r.colOff, m - 2 - (int)i);
+        const unsigned long long v = ((unsigned long long)(L + R) << 32) | (unsigned long long)i;
+        mine = v < mine ? v : mine;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(mine, off, 64);
+        mine = o < mine ? o : mine;
+    }
+    if ((threadIdx.x & 63) == 0 && mine != ~0ull) atomicMin(&packed[p], mine);
+}
+__global__ void __launch_bounds__(64)
+split_min_finish_kernel(const SplitArgs a, const unsigned long long* packed)
+{
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= a.numPieces) return;
+    const PairDesc f = a.descs[2 * p], r = a.descs[2 * p + 1];
+    const int m = f.qlen, lw = f.tlen, rw = r.tlen;
+    const long long R0 = column_cell(a.colP, a.colM, a.colS, r.colOff, m - 1);        // whole query vs right half
+    const long long Lm = column_cell(a.colP, a.colM, a.colS, f.colOff, m - 1);        // whole query vs left half
+    const unsigned long long pk = packed[p];
+    long long best = pk == ~0ull ? (1LL << 40) : (long long)(pk >> 32);
+    int row = pk == ~0ull ? -2 : (int)(unsigned)(pk & 0xffffffffu);
+    if (lw + R0 < best) { best = lw + R0; row = -1; }
+    if (Lm + rw < best) { best = Lm + rw; row = m - 1; }
+    int ls, rs;
+    if (row == -1) { ls = lw; rs = (int)R0; }
+    else if (row == m - 1) { ls = (int)Lm; rs = rw; }
+    else { ls = column_cell(a.colP, a.colM, a.colS, f.colOff, row); rs = column_cell(a.colP, a.colM, a.colS, r.colOff, m - 2 - row); }
+    a.out[4 * p] = best > 0x3fffffff ? 0x3fffffff : (int)best; a.out[4 * p + 1] = row; a.out[4 * p + 2] = ls; a.out[4 * p + 3] = rs;
+}
+
+hipError_t launch_split_min(const SplitArgs& a, unsigned long long* packed, int maxRows, hipStream_t stream)
+{
+    if (a.numPieces == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(packed, 0xff, (size_t)a.numPieces * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    int chunks = (maxRows + 256 * 16 - 1) / (256 * 16);
+    chunks = chunks < 1 ? 1 : (chunks > 1024 ? 1024 : chunks);
+    hipLaunchKernelGGL(split_min_rows_kernel, dim3(chunks, a.numPieces), dim3(256), 0, stream, a, packed);
+    hipLaunchKernelGGL(split_min_finish_kernel, dim3((a.numPieces + 63) / 64), dim3(64), 0, stream, a, packed);
+    return hipGetLastError();
+}
+
 // --------------------------------------------------------------- traceback
 
 // reference obtainAlignmentTraceback (edlib.cpp:942-1141), one lane per unit.

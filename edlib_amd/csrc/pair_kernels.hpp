@@ -146,5 +146,8 @@ struct SplitArgs {
     int* out;                   // [pieces][3]
 };
 hipError_t launch_hirschberg_split(const SplitArgs& a, hipStream_t stream);
+// distance of a piece from the same two dumps: min over the rows of L[i] + R[i+1] (SplitArgs::best unused);
+// out[4p..4p+3] = {min, row as above, leftScore, rightScore}; `packed`: numPieces words of scratch
+hipError_t launch_split_min(const SplitArgs& a, unsigned long long* packed, int maxRows, hipStream_t stream);
 
 }  // namespace edlib_amd
