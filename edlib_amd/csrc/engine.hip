@@ -1644,10 +1644,12 @@ int Batch::hirschbergLevel(const std::vector<PathPiece>& big, std::vector<int>& 
     static const int rings[kNumRings + 1] = {4, 8, 16, 21, 32, 64, 0};
     // (packing only pays with enough pieces to fill the chip: a handful of long pieces runs faster one per wave)
     const bool packed = np >= 256;
+    const bool wideOffEarly = getenv("EDLIB_AMD_WIDE") && getenv("EDLIB_AMD_WIDE")[0] == '0';
     auto ring_of = [&](const PathPiece& pc) {
         const bool off = getenv("EDLIB_AMD_NWBAND") && getenv("EDLIB_AMD_NWBAND")[0] == '0';
         if (off) return kNumRings;
-        if (!packed) return (pc.m > 64 * 64 && pc.score <= kMaxBandK) ? kNumRings - 1 : kNumRings;
+        // (a few long pieces are bound by dependent steps: 0.074 us on the wide kernel's waves against 0.12 on a ring's)
+        if (!packed) return (pc.m > 64 * 64 && pc.score <= kMaxBandK && (pc.T < 4096 || wideOffEarly)) ? kNumRings - 1 : kNumRings;
         for (int g = 0; g < kNumRings; ++g) if (pc.score <= ring_max_k(rings[g])) return g;
         return (pc.m + 63) / 64 <= 64 ? kNumRings - 1 : kNumRings;
     };
@@ -1840,7 +1842,22 @@ int Batch::solvePaths(const std::vector<PathPiece>& jobs, std::vector<OpsOut>& o
         }
         if (big.empty()) break;
         std::vector<int> row, ls, rs;
-        if (hirschbergLevel(big, row, ls, rs)) return 1;
+        // pieces whose two half scans already ran for the distance (solveWideSplit) bring their split along
+        std::vector<PathPiece> todo; std::vector<size_t> todoAt;
+        row.assign(big.size(), -2); ls.assign(big.size(), 0); rs.assign(big.size(), 0);
+        for (size_t b = 0; b < big.size(); ++b) {
+            const KnownSplit* ks = nullptr;
+            if (level == 0)
+                for (const KnownSplit& k : knownSplits_)
+                    if (k.qoff == big[b].qoff && k.m == big[b].m && k.toff == big[b].toff && k.T == big[b].T && k.score == big[b].score) { ks = &k; break; }
+            if (ks) { row[b] = ks->row; ls[b] = ks->left; rs[b] = ks->right; }
+            else { todo.push_back(big[b]); todoAt.push_back(b); }
+        }
+        if (!todo.empty()) {
+            std::vector<int> r2, l2, s2;
+            if (hirschbergLevel(todo, r2, l2, s2)) return 1;
+            for (size_t q = 0; q < todo.size(); ++q) { row[todoAt[q]] = r2[q]; ls[todoAt[q]] = l2[q]; rs[todoAt[q]] = s2[q]; }
+        }
         // replace pieces back to front so the recorded indices stay valid
         for (size_t b = big.size(); b-- > 0;) {
             const size_t j = where[b].first, i = where[b].second;
@@ -2095,12 +2112,33 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
     // ~T dependent steps whether it succeeds or not (0.1 s per Mb), so each unit gets its own estimate from its first 4 kb
     // (PREFIX mode on a 16-lane ring of 4-block lanes: ~1 ms) instead of climbing.
     const bool wideOff = getenv("EDLIB_AMD_WIDE") && getenv("EDLIB_AMD_WIDE")[0] == '0';
+    const bool wideLevel = !wideOff && paths == nullptr;                // what follows the rings: the wide band, else the strips
+    // A handful of units (edlibAlign() on a long pair is one) are bound by DEPENDENT STEPS, not by work: a ring scan is
+    // ~T steps of 0.12 us on one wave whether it succeeds or not, the wide kernel's two half scans are T / 2 steps of
+    // 0.074 us on as many waves as the band is tall.  So when the strips of all units' whole matrices fit the resident
+    // waves, units of 4 kb and more skip the rings: straight to two half scans, over the WHOLE matrix (no estimate, no
+    // ladder, always exact) while that is at most 2e10 cells, inside a band from the unit's own first 4 kb beyond that
+    // (the reference's 1 Mb Chromosome pairs, test_data/perf_tests.sh:180-191; PREFIX mode on a 16-lane ring of 4-block
+    // lanes: ~1 ms against 40 ms per pass).
+    std::vector<uint8_t> direct;
     std::vector<double> unitRate;
+    if (wideLevel && rate == 0.0 && n <= 64 && !bandOff) {
+        if (wideCap_ < 0) wideCap_ = wide_resident_waves(tab_.sigmaT);
+        long long waves = 0;
+        for (size_t i = 0; i < n; ++i)
+            if (std::min(units[i].qlen, units[i].tlen) >= 4096)        // whole matrix: every strip is alive; a band: a few dozen
+                waves += (double)units[i].qlen * (double)units[i].tlen <= 2e10 ? 2LL * ((units[i].qlen + 2047) / 2048) : 96;
+        if (waves > 0 && waves <= wideCap_) {
+            direct.assign(n, 0);
+            for (size_t i = 0; i < n; ++i) direct[i] = std::min(units[i].qlen, units[i].tlen) >= 4096;
+        }
+    }
+    auto whole_ok = [&](size_t i) { return (double)units[i].qlen * (double)units[i].tlen <= 2e10; };
     if (rate == 0.0 && n <= 512 && !bandOff && !getenv("EDLIB_AMD_NOPROBE")) {
         std::vector<UnitSpec> probe; std::vector<size_t> who;
         const int cut = 4096;
         for (size_t i = 0; i < n; ++i)
-            if (std::min(units[i].qlen, units[i].tlen) >= 32768) {
+            if (direct.empty() ? std::min(units[i].qlen, units[i].tlen) >= 32768 : (direct[i] && !whole_ok(i))) {
                 UnitSpec u = units[i];
                 u.qlen = cut; u.tlen = cut + 512; u.kinit = cut;
                 probe.push_back(u); who.push_back(i);
@@ -2142,17 +2180,17 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
     {
         int lastQ = -1, lastT = -1, lastL = 0;                           // batches of equal shapes: one evaluation
         for (size_t i = 0; i < n; ++i) {
-            if (units[i].qlen != lastQ || units[i].tlen != lastT || !unitRate.empty()) {
+            if (units[i].qlen != lastQ || units[i].tlen != lastT || !direct.empty()) {
                 lastQ = units[i].qlen; lastT = units[i].tlen;
                 lastL = bandOff ? nl : first_level(i);
                 if (!bandOff && fewUnits && lastL < nl - 1 && blocks(i) > blocks_of(lastL)) lastL = nl - 1;
+                if (!direct.empty() && direct[i]) lastL = nl;
             }
             lvl[i] = lastL;
             ++atLevel[lastL];
         }
     }
     Lap lap;
-    const bool wideLevel = !wideOff && paths == nullptr;                // what follows the rings: the wide band, else the strips
     for (int l = 0; l <= nl; ++l) {
         if (atLevel[l] == 0) continue;
         if (l == nl && wideLevel) break;
@@ -2191,12 +2229,14 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
             if (lvl[i] == nl) {
                 rest.push_back(i);
                 const double est = mean_of(i);
-                kcur[i] = std::max<long long>(2LL * (ring_max_k(64) + 128), (long long)(1.5 * est + 4.0 * std::sqrt(est) + 64.0));
+                const bool dir = !direct.empty() && direct[i];
+                kcur[i] = std::max<long long>(dir ? 1024 : 2LL * (ring_max_k(64) + 128), (long long)(1.5 * est + 4.0 * std::sqrt(est) + 64.0));
+                if (dir && whole_ok(i)) kcur[i] = std::max(units[i].qlen, units[i].tlen);
                 if (const char* e = getenv("EDLIB_AMD_WIDE_K0")) { if (atoi(e) > 0) kcur[i] = atoi(e); }     // (tests: the ladder from a small K)
             }
         // long units: two half scans that meet in the middle (solveWideSplit: half the dependent steps); a unit of one
         // target column has no two halves
-        const int splitMin = getenv("EDLIB_AMD_WIDE_SPLIT") ? atoi(getenv("EDLIB_AMD_WIDE_SPLIT")) : 16384;
+        const int splitMin = getenv("EDLIB_AMD_WIDE_SPLIT") ? atoi(getenv("EDLIB_AMD_WIDE_SPLIT")) : (direct.empty() ? 16384 : 4096);
         while (!rest.empty()) {
             std::vector<UnitSpec>& sel = selScratch_;
             sel.clear();
@@ -2223,7 +2263,12 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
             if (!halves.empty()) {
                 std::vector<int> sp;
                 if (solveWideSplit(halves, sp)) return 1;
-                for (size_t q = 0; q < halves.size(); ++q) if (settle(whoHalves[q], halves[q], sp[4 * q])) return 1;
+                for (size_t q = 0; q < halves.size(); ++q) {
+                    const UnitSpec& u = halves[q];
+                    if (sp[4 * q] <= u.kinit && u.qstep == 1 && u.tstep == 1)
+                        knownSplits_.push_back(KnownSplit{u.qoff, u.qlen, u.toff, u.tlen, sp[4 * q], sp[4 * q + 1], sp[4 * q + 2], sp[4 * q + 3]});
+                    if (settle(whoHalves[q], u, sp[4 * q])) return 1;
+                }
             }
             lap("nw wide level");
             rest.swap(again);
@@ -2246,6 +2291,7 @@ int Batch::run()
     scanEventsUsed_ = 0;
     haveResults_ = false;
     opsKeep_.clear();            // (the previous run's views die with the reset of their records below)
+    knownSplits_.clear();
     opsOwned_.clear();
     // TASK_DISTANCE over reads-path units only: nothing is assembled on the host until results() asks for it, so
     // the per-unit records (160 bytes each) are not even allocated in the timed run

@@ -218,6 +218,10 @@ private:
     // reverse over the right half, both inside the band of UnitSpec::kinit): out[4 u ..] = {min, split row, left, right};
     // exact iff min <= kinit
     int solveWideSplit(const std::vector<UnitSpec>& units, std::vector<int>& out);
+    // what the distance phase of this run already knows about a piece's first split (solveWideSplit): the path phase
+    // does not scan the two halves again
+    struct KnownSplit { long long qoff; int m; long long toff; int T; int score; int row, left, right; };
+    std::vector<KnownSplit> knownSplits_;
     // NW distances by threshold levels on rings of 4, 16, 64 lanes, then unbanded (the reference's
     // k-doubling, edlib.cpp:197-217, with thresholds chosen for the hardware)
     // paths != null (TASK_PATH, every unit below the 1 MiB rule): the levels run with the column store and the traceback, so

@@ -34,7 +34,8 @@ int main(int argc, char** argv)
     const Shape shapes[] = {
         {"100 x 100 NW distance", 100, 100, 0, 0, 2000}, {"100 x 100 NW path", 100, 100, 0, 2, 2000},
         {"1k x 1k NW distance", 1000, 1000, 0, 0, 1000}, {"1k x 1k NW path", 1000, 1000, 0, 2, 500},
-        {"10k x 10k NW distance", 10000, 10000, 0, 0, 200}, {"150 x 5Mb HW distance", 150, 5000000, 2, 0, 20},
+        {"10k x 10k NW distance", 10000, 10000, 0, 0, 200}, {"10k x 10k NW path", 10000, 10000, 0, 2, 100},
+        {"100k x 100k NW distance", 100000, 100000, 0, 0, 20}, {"150 x 5Mb HW distance", 150, 5000000, 2, 0, 20},
         {"150 x 5Mb HW path", 150, 5000000, 2, 2, 20},
     };
     printf("{\"library\": \"%s\", \"us_per_call\": {", argv[1]);
