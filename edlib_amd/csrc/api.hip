@@ -9,6 +9,7 @@
 #include <new>
 #include <string>
 #include <system_error>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -257,8 +258,38 @@ static int run_sharded(const char* q, const long long* qoff, const char* t, cons
     std::vector<int> rc(world, EDLIB_STATUS_OK);
     std::vector<std::string> err(world);
     const int per = (n + world - 1) / world;                     // same rule as edlib_amd/parallel.py
+    // Independent PAIRS vary in work (query x target cells): static slices leave devices idle behind the one that drew the
+    // long pairs.  SURVEY.md 8e: a shared queue of chunks of about equal work (contiguous unit ranges, ~8 per device, cut
+    // where the running sum of qlen * tlen crosses the next multiple of total / chunks) that the device threads pull from
+    // with one atomic counter.  Shared-target read batches (equal reads) and EDLIB_AMD_SHARD=static keep the static slices.
+    std::vector<int> cuts;                                       // chunk c = units [cuts[c], cuts[c + 1])
+    {
+        const char* how = getenv("EDLIB_AMD_SHARD");
+        const bool queue = toff != nullptr && world > 1 && n >= 2 * world && !(how && !strcmp(how, "static"));
+        if (queue) {
+            double total = 0;
+            for (int i = 0; i < n; ++i) total += (double)(qoff[i + 1] - qoff[i] + 1) * (double)(toff[i + 1] - toff[i] + 1);
+            const int chunks = std::min(n, 8 * world);
+            double acc = 0; int next = 1;
+            cuts.push_back(0);
+            for (int i = 0; i < n; ++i) {
+                acc += (double)(qoff[i + 1] - qoff[i] + 1) * (double)(toff[i + 1] - toff[i] + 1);
+                if (acc >= total * next / chunks && i + 1 < n) { cuts.push_back(i + 1); while (acc >= total * next / chunks) ++next; }
+            }
+            cuts.push_back(n);
+        }
+    }
+    std::atomic<int> nextChunk{0};
     auto work = [&](int r) {                                     // a thread body: nothing may escape it
         rc[r] = guarded(where, (int)EDLIB_STATUS_ERROR, [&] {
+            if (!cuts.empty()) {
+                for (;;) {
+                    const int c = nextChunk.fetch_add(1);
+                    if (c + 1 >= (int)cuts.size()) return (int)EDLIB_STATUS_OK;
+                    const int st = run_shard(q, qoff, t, toff, targetLength, cuts[c], cuts[c + 1], config, devs[r], results, &err[r]);
+                    if (st != EDLIB_STATUS_OK) { nextChunk.store((int)cuts.size()); return st; }       // nobody starts another chunk
+                }
+            }
             const int lo = std::min(n, r * per), hi = std::min(n, lo + per);
             return (hi > lo || n == 0) ? run_shard(q, qoff, t, toff, targetLength, lo, hi, config, devs[r], results, &err[r])
                                        : (int)EDLIB_STATUS_OK;

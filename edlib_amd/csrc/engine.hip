@@ -15,6 +15,7 @@
 // (solveGlobalDistances).  Thresholds only steer work: every result is a function of the full DP
 // matrix, so the user's k merely filters it (SURVEY.md §7 "results are band-independent").
 #include "engine.hpp"
+#include <sched.h>
 
 #if defined(__x86_64__)
 #include <immintrin.h>                 // build_tables: 16 target bytes per step through the alphabet scan (host)
@@ -208,13 +209,26 @@ int host_threads(int cap) {
         if (const char* env = getenv("EDLIB_AMD_HOST_THREADS")) { const int v = atoi(env); if (v >= 1) return v; }
         int n = (int)std::thread::hardware_concurrency();
         if (n < 1) n = 1;
-        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        {   // the affinity mask (taskset, container cpusets)
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c >= 1 && c < n) n = c; }
+        }
+        bool v2 = false;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {              // cgroup v2 quota
             char a[64] = {0}; long long per = 0;
+            v2 = true;
             if (fscanf(f, "%63s %lld", a, &per) == 2 && strcmp(a, "max") != 0 && per > 0) {
                 const long long q = (atoll(a) + per / 2) / per;
                 if (q >= 1 && q < n) n = (int)q;
             }
             fclose(f);
+        }
+        if (!v2) {                                                         // cgroup v1: cfs quota / period
+            long long quota = -1, per = 0;
+            if (FILE* f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(f, "%lld", &quota) != 1) quota = -1; fclose(f); }
+            if (FILE* f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f, "%lld", &per) != 1) per = 0; fclose(f); }
+            if (quota > 0 && per > 0) { const long long q = (quota + per / 2) / per; if (q >= 1 && q < n) n = (int)q; }
         }
         return n;
     }();

@@ -266,7 +266,7 @@ struct OneCtx {
     int device = -1;
     hipStream_t stream = nullptr;
     PinBuf in, out;
-    bool attr = false;
+    int attrDevice = -1;                    // device the kernel's dynamic-LDS limit was raised on
     // (runs at thread exit, for the main thread at process exit: no HIP call here; every call ended with a stream synchronisation)
     ~OneCtx() { if (stream) pool_stream_put(device, stream); }
 };
@@ -302,16 +302,29 @@ int align_one_fused(const char* q, int m, const char* t, int T, EdlibAlignConfig
     pool_quarantine(false);
     DeviceGuard guard(dev);
     EDLIB_AMD_HIP(guard.status);
-    if (ctx.device != dev) {
-        if (ctx.stream) { (void)hipStreamSynchronize(ctx.stream); pool_stream_release(ctx.stream); ctx.stream = nullptr; }
+    if (ctx.device != dev || !ctx.stream || !ctx.in.p || !ctx.out.p) {
+        // (Re)initialisation is transactional: the context names a device only while its stream and both mailboxes exist,
+        // so a failure part-way leaves "no context" and the next call starts over (never a null mailbox behind a valid
+        // device).  The old device's stream goes back under THAT device (pool_stream_release files under the current one).
+        if (ctx.stream) { (void)hipStreamSynchronize(ctx.stream); pool_stream_put(ctx.device, ctx.stream); ctx.stream = nullptr; }
+        ctx.device = -1; ctx.attrDevice = -1;
+        ctx.in.release(); ctx.out.release();
+        hipStream_t st = nullptr;
+        EDLIB_AMD_HIP(pool_stream(&st));
+        if (ctx.in.alloc(sizeof(OneHeader) + kOneMaxQ + kOneMaxT + 64) != hipSuccess ||
+            ctx.out.alloc(sizeof(OneResult) + 2 * (kOneMaxLoc + 1) * sizeof(int) + kOneMaxQ + kOneMaxT + 64) != hipSuccess) {
+            ctx.in.release(); ctx.out.release();
+            pool_stream_put(dev, st);
+            set_error("single-pair context: pinned mailbox allocation failed");
+            pool_quarantine(true);
+            return 1;
+        }
+        ctx.stream = st;
         ctx.device = dev;
-        EDLIB_AMD_HIP(pool_stream(&ctx.stream));
-        EDLIB_AMD_HIP(ctx.in.alloc(sizeof(OneHeader) + kOneMaxQ + kOneMaxT + 64));
-        EDLIB_AMD_HIP(ctx.out.alloc(sizeof(OneResult) + 2 * (kOneMaxLoc + 1) * sizeof(int) + kOneMaxQ + kOneMaxT + 64));
     }
-    if (!ctx.attr) {
+    if (ctx.attrDevice != dev) {            // (a function attribute is per device)
         EDLIB_AMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(one_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kOneLdsBudget + 1024));
-        ctx.attr = true;
+        ctx.attrDevice = dev;
     }
     OneHeader* h = reinterpret_cast<OneHeader*>(ctx.in.p);
     h->m = m; h->T = T; h->mode = mode; h->task = task; h->k = cfg.k; h->storeCap = (int)std::min<size_t>(storeCap, 0x7fffffff);

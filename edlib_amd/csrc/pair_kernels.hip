@@ -31,6 +31,7 @@
 //     back with the reference's candidate order up > left > diagonal.
 #include "pair_kernels.hpp"
 #include "block64.hpp"
+#include "lds_check.hpp"
 
 namespace edlib_amd {
 
@@ -379,7 +380,7 @@ scan_pairs_ring_kernel(const PairScanArgs a)
     // LDS byte address of the unit's target ring: 512-byte aligned, so that slot (c & 255) is tbase | (2 c & 511) -- one
     // v_and_or_b32 from a counter that advances by 2 per step
     const u32 tbase = (u32)(size_t)(__attribute__((address_space(3))) unsigned short*)s_tgt;
-    if (tbase & 511u) __builtin_trap();
+    // (the rings start 512-byte aligned: no static LDS in front of the dynamic block -- checked on the host, lds_check.hpp)
     auto tgt_at = [&](const u32 c2) -> int {
         return *(const __attribute__((address_space(3))) unsigned short*)(size_t)(tbase | (c2 & 511u));
     };
@@ -671,11 +672,14 @@ static hipError_t launch_scan_pairs_ring_t(const PairScanArgs& a, hipStream_t st
     // the whole-Peq mode saves the refills of packed rings, but only pays while LDS does not cap the
     // occupancy (measured: 10 KB per wave costs config 4 a third of its rate); row offsets are 16 bits
     if (G < 64 && a.peqFullStride > 0 && full + tgt <= 8192 && 8LL * a.peqRowStride * a.sigmaT < 65536 && a.peqRowStride % H == 0) {
+        EDLIB_AMD_CHECK_STATIC_LDS((scan_pairs_ring_kernel<G, MODE, STORE, 2, H>), 0);
         hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 2, H>), grid, dim3(64), full + tgt, stream, a);
     } else if (a.sigmaT <= 32) {
         const size_t lds = (size_t)a.sigmaT * 64 * H * sizeof(u64) + tgt;
+        EDLIB_AMD_CHECK_STATIC_LDS((scan_pairs_ring_kernel<G, MODE, STORE, 1, H>), 0);
         hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 1, H>), grid, dim3(64), lds, stream, a);
     } else {
+        EDLIB_AMD_CHECK_STATIC_LDS((scan_pairs_ring_kernel<G, MODE, STORE, 0, H>), 0);
         hipLaunchKernelGGL((scan_pairs_ring_kernel<G, MODE, STORE, 0, H>), grid, dim3(64), tgt, stream, a);
     }
     if (a.wordSteps) return launch_count_ring_steps(a.descs, a.numUnits, MODE, H, a.wordSteps, stream);

@@ -394,7 +394,8 @@ static hipError_t launch_scan_reads_full_s(int nwords, const ReadScanArgs& a, hi
 {
     dim3 grid((a.nlanes + 63) / 64, a.numSegments), block(64);
     switch (nwords) {
-#define CASE(N) case N: hipLaunchKernelGGL((scan_reads_full_kernel<N, S, CHAIN>), grid, block, 0, stream, a); break;
+#define CASE(N) case N: EDLIB_AMD_CHECK_STATIC_LDS((scan_reads_full_kernel<N, S, CHAIN>), N * S * 256); \
+                        hipLaunchKernelGGL((scan_reads_full_kernel<N, S, CHAIN>), grid, block, 0, stream, a); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
         default: return hipErrorInvalidValue;
@@ -421,8 +422,10 @@ static hipError_t launch_scan_reads_banded_s(int nwords, const ReadScanArgs& a, 
     const int nrblk = (a.nlanes + 63) / 64;
     dim3 grid(nrblk, a.numSegments), block(64);
     switch (nwords) {
-#define CASE(N) case N: if (a.filter) hipLaunchKernelGGL((scan_reads_banded_kernel<N, S, true>), grid, block, 0, stream, a); \
-                        else hipLaunchKernelGGL((scan_reads_banded_kernel<N, S, false>), grid, block, 0, stream, a); break;
+#define CASE(N) case N: if (a.filter) { EDLIB_AMD_CHECK_STATIC_LDS((scan_reads_banded_kernel<N, S, true>), N * S * 256); \
+                                            hipLaunchKernelGGL((scan_reads_banded_kernel<N, S, true>), grid, block, 0, stream, a); } \
+                        else { EDLIB_AMD_CHECK_STATIC_LDS((scan_reads_banded_kernel<N, S, false>), N * S * 256); \
+                               hipLaunchKernelGGL((scan_reads_banded_kernel<N, S, false>), grid, block, 0, stream, a); } break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
         default: return hipErrorInvalidValue;

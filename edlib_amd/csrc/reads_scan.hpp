@@ -3,6 +3,7 @@
 // to 8 words, the piece filter) and reads_kernels_long.hip (groups of 12 / 16 / 24 / 32 words): two translation units, so that
 // the long groups -- most of the compile time, code size grows with the square of the word count -- build in parallel.
 #pragma once
+#include "lds_check.hpp"
 #include "reads_kernels.hpp"
 
 namespace edlib_amd {
@@ -471,7 +472,7 @@ scan_reads_banded_kernel(const ReadScanArgs a)
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
-    if ((u32)(size_t)(__attribute__((address_space(3))) u32*)&s_eq[0][0][0] != 0u) __builtin_trap();
+    // (s_eq at LDS address 0 is checked on the host at the launch: lds_check.hpp)
     HwTrack tr;
     {
         const int k0 = a.kinit[slot];
@@ -587,7 +588,7 @@ scan_reads_full_kernel(const ReadScanArgs a)
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
-    if ((u32)(size_t)(__attribute__((address_space(3))) u32*)&s_eq[0][0][0] != 0u) __builtin_trap();
+    // (s_eq at LDS address 0 is checked on the host at the launch: lds_check.hpp)
     HwTrack tr;
     tr.best = a.kinit[slot];
     tr.cnt = 0;

@@ -34,6 +34,7 @@
 // and a launch-wide abort word turns a stuck hand-off into EDLIB_STATUS_ERROR instead of a hung queue.
 #include "pair_kernels.hpp"
 #include "block64.hpp"
+#include "lds_check.hpp"
 #include <type_traits>
 
 namespace edlib_amd {
@@ -382,6 +383,7 @@ static hipError_t launch_wide_t(const PairScanArgs& a, int slots, hipStream_t st
     const dim3 grid(slots, a.numUnits);
     if (a.sigmaT <= 32) {
         const size_t lds = (size_t)a.sigmaT * 64 * sizeof(u32) + 512;     // Peq slice + the ring of lane 0's feeds
+        EDLIB_AMD_CHECK_STATIC_LDS((scan_pairs_wide_kernel<MODE, true>), 0);        // the Peq slice starts at LDS address 0
         hipLaunchKernelGGL((scan_pairs_wide_kernel<MODE, true>), grid, dim3(64), lds, stream, a);
     } else {
         hipLaunchKernelGGL((scan_pairs_wide_kernel<MODE, false>), grid, dim3(64), 512, stream, a);

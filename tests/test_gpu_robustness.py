@@ -124,6 +124,31 @@ def test_oneshot_entry_points_shard_over_devices(engine, oracle, monkeypatch):
             assert same(g, oracle.align(q, t, "NW", "distance", -1)), devs
 
 
+def test_pair_batches_of_unequal_work_are_pulled_from_a_chunk_queue(engine, checker, monkeypatch):
+    """edlibAlignBatchPairs over several devices: pairs differ in work (query x target cells), so the device threads pull
+    chunks of about equal work from a shared queue instead of taking static slices.  Two "devices" on the
+    one GPU of the test box; a few long pairs among many short ones, in both orders; EDLIB_AMD_SHARD=static: the slices."""
+    rng = np.random.default_rng(77)
+    qs, ts = [], []
+    for i in range(60):
+        n = int(rng.choice([40, 150, 700, 5000])) if i % 13 else 20000
+        t = synth.random_dna(500 + i, n)
+        q, _ = synth.mutate(t, 900 + i, 0.03, 0.01, 0.01)
+        qs.append(q.tobytes()); ts.append(t.tobytes())
+    for order in (1, -1):
+        for how in (None, "static"):
+            monkeypatch.setenv("EDLIB_AMD_DEVICES", "0,0")
+            if how:
+                monkeypatch.setenv("EDLIB_AMD_SHARD", how)
+            else:
+                monkeypatch.delenv("EDLIB_AMD_SHARD", raising=False)
+            a, b = qs[::order], ts[::order]
+            for mode, task in (("NW", "distance"), ("HW", "locations")):
+                got = engine.align_batch_oneshot(a, None, targets=b, mode=mode, task=task)
+                for q, t, g in zip(a, b, got):
+                    assert same(g, checker.align(q, t, mode, task, -1)), (order, how, mode, len(q))
+
+
 def test_large_batch_takes_probe_and_leftover_paths(engine, ref, oracle):
     """A batch big enough for everything the k-doubling does above 16,384 reads: the 2048-read probe with its
     adaptive first threshold, a second pass with more than 4096 leftovers (band sample, plain full-height kernel),
@@ -213,3 +238,31 @@ def test_shw_against_long_targets_stops_at_2m(engine, checker):
     for i in range(0, len(qs), 37):
         want = checker.align(qs[i], ts[i], "SHW", "distance", -1)
         assert got[i]["editDistance"] == want["editDistance"] and got[i]["endLocations"] == want["endLocations"], i
+
+
+def test_invalid_mode_values(engine, checker):
+    """EdlibAlignConfig.mode outside {0, 1, 2} through the C ABI (edlib.cpp:205-225, 177-179): the
+    distance as NW, no locations; ERROR with an empty input.  Every field against the reference."""
+    fields = ("status", "editDistance", "endLocations", "startLocations", "numLocations", "alignment", "alignmentLength", "alphabetLength")
+    cases = [(b"ACGTACGT", b"ACGTTCGT"), (b"AAAA", b"TTTTTT"), (b"ACGT" * 40, b"ACGA" * 41), (b"", b"ACGT"), (b"ACGT", b""), (b"", b""),
+             (synth.random_dna(1, 3000).tobytes(), synth.random_dna(2, 3100).tobytes())]
+    for mode in (3, 7, -1, 100):
+        for task in ("distance", "locations"):
+            for k in (-1, 0, 3):
+                for q, t in cases:
+                    got = engine.align_raw(q, t, mode, task, k)
+                    want = checker.align(q, t, mode, task, k)
+                    for f in fields:
+                        assert got[f] == want[f], (mode, task, k, len(q), len(t), f, got[f], want[f])
+        # TASK_PATH with such a mode: the reference dereferences its NULL endLocations (a crash, no answer to match);
+        # here it has to come back with a status and no stray pointers
+        for q, t in cases:
+            got = engine.align_raw(q, t, mode, "path", -1)
+            assert got["status"] in (0, 1) and got["alignment"] is None and got["endLocations"] is None
+    # and in a batch (the batch entry points take the same config)
+    qs = [c[0] for c in cases[:3]]; ts = [c[1] for c in cases[:3]]
+    got = engine.align_pairs(qs, ts, mode=7, task="locations", raw=True)
+    for g, q, t in zip(got, qs, ts):
+        want = checker.align(q, t, 7, "locations", -1)
+        for f in fields:
+            assert g[f] == want[f], (f, g[f], want[f])

@@ -96,3 +96,23 @@ def test_live_differential_fuzz(oracle, ref):
         if a["status"] == 2:
             continue
         assert a == b, (mode, task, k, q, t)
+
+
+def test_invalid_mode_values(oracle, ref):
+    """a mode outside {NW, SHW, HW} (edlib.cpp:205-225: the distance is computed as NW but the end-location fix-up tests
+    mode == NW, so endLocations stays NULL and numLocations 0; :177-179: with an empty input the status is ERROR).
+    Pinned against the compiled reference where it is here; the restatement has to say the same."""
+    cases = [(b"ACGTACGT", b"ACGTTCGT"), (b"AAAA", b"TTTTTT"), (b"ACGT" * 40, b"ACGA" * 41), (b"", b"ACGT"), (b"ACGT", b""), (b"", b"")]
+    for mode in (3, 7, -1, 100):
+        for task in ("distance", "locations"):       # (TASK_PATH with such a mode: the reference dereferences its NULL endLocations)
+            for k in (-1, 0, 3):
+                for q, t in cases:
+                    got = oracle.align(q, t, mode, task, k)
+                    if q and t:
+                        assert got["status"] == 0
+                        nw = oracle.align(q, t, "NW", "distance", k)
+                        assert got["editDistance"] == nw["editDistance"], (mode, task, k, q, t)
+                    if ref is not None:
+                        want = ref.align(q, t, mode, task, k)
+                        for f in ("status", "editDistance", "endLocations", "startLocations", "numLocations", "alignment", "alphabetLength"):
+                            assert got[f] == want[f], (mode, task, k, q, t, f, got[f], want[f])
