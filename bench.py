@@ -335,6 +335,49 @@ def report(cfg_id, w, st, scan_ms, launches, steps, warmup, dt, value, world, sc
     }
 
 
+def measure_chromosome(repeat=2):
+    """The reference's own long-pair shape (test_data/perf_tests.sh:180-191 "Chromosome, NW": 1 Mb x 1 Mb, seven
+    divergences), one edlibAlign() call per pair, distance and path; answers against tests/golden/realdata/expected.json
+    (made by the compiled reference: score, location, md5 of the op bytes).  Seconds per call here, the reference's on one
+    core of this box for the 99 % pair (the rest of its column: the fixture's, taken in the build container)."""
+    import hashlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import edlib_amd
+    from test_realdata import EXP, REAL, chromosome, read_fasta
+    from oracle.oracle import load_ref
+    t = chromosome()
+    pairs = []
+    for c in EXP["chromosome"]:
+        q = read_fasta(os.path.join(REAL, "chromosome", c["query"]))
+        row = {"percent": c["percent"], "editDistance": c["editDistance"]}
+        best = None
+        for _ in range(repeat):
+            t0 = time.perf_counter(); g = edlib_amd.align_raw(q, t, "NW", "distance", -1); dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        row["gpu_s_distance"] = round(best, 4)
+        ok = g["status"] == 0 and g["editDistance"] == c["editDistance"] and g["endLocations"] == c["endLocations"]
+        best = None
+        for _ in range(repeat):
+            t0 = time.perf_counter(); g = edlib_amd.align_raw(q, t, "NW", "path", -1); dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        row["gpu_s_path"] = round(best, 4)
+        ok = ok and g["alignment"] is not None and hashlib.md5(g["alignment"]).hexdigest() == c["ops_md5"] \
+            and g["alignmentLength"] == c["alignmentLength"] and g["startLocations"] == c["startLocations"]
+        row["bit_exact"] = bool(ok)
+        row["reference_s_fixture"] = [c["ref_seconds_distance"], c["ref_seconds_path"]]
+        if c["percent"] == 99:
+            ref = load_ref()
+            if ref is not None:
+                t0 = time.perf_counter(); r = ref.align(q, t, "NW", "distance", -1); t1 = time.perf_counter()
+                ref.align(q, t, "NW", "path", -1); t2 = time.perf_counter()
+                row["reference_s_here"] = [round(t1 - t0, 3), round(t2 - t1, 3)]
+                row["bit_exact"] = bool(row["bit_exact"] and r["editDistance"] == c["editDistance"])
+        row["gcups_distance"] = round(len(q) * len(t) / row["gpu_s_distance"] / 1e9, 1)
+        pairs.append(row)
+    return {"workload": "7 x (1 Mb x 1 Mb) NW, one edlibAlign() per pair, distance and path", "pairs": pairs,
+            "bit_exact": sum(1 for r in pairs if r["bit_exact"]), "checked": len(pairs)}
+
+
 def measure_secondary(cfg_id, device, torch, steps=5, warmup=2):
     """One more BASELINE config on this rank's device: resident batch, `warmup` + `steps` timed steps between two
     device synchronisations, then the reference over the WHOLE batch (parity of every field + the CPU baseline)."""
@@ -496,6 +539,10 @@ def main():
                 out["secondary"]["config%d" % cid] = measure_secondary(cid, device, torch)
             except Exception as e:                                    # the headline line must survive
                 out["secondary"]["config%d" % cid] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            out["secondary"]["chromosome"] = measure_chromosome()
+        except Exception as e:
+            out["secondary"]["chromosome"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,37 +1,42 @@
 // wide_kernels.hip -- one (query, target) unit on MANY waves: the band of a long NW pair beyond every lane ring, and the
-// pipelined form of the 64-block strips for long SHW / HW queries.
+// pipelined form of the strips for long SHW / HW queries.
 //
-// Replaces, for units of more than 64 blocks, myersCalcEditDistanceNW with a fixed k (reference edlib.cpp:730-928; the
-// band is Ukkonen's, what the first/lastBlock bookkeeping of :744-830 converges to) and the column loop of
-// myersCalcEditDistanceSemiGlobal (:550-704).  The lane rings of pair_kernels.hip hold bands up to K = 3968 on one wave;
-// above that scan_pairs_kernel walked every block of every column with ONE wave, strip after strip (round 3: tens of
-// seconds for the reference's 1 Mb x 1 Mb Chromosome pairs, test_data/perf_tests.sh:180-191).  Here:
+// Replaces, for long units, myersCalcEditDistanceNW with a fixed k (reference edlib.cpp:730-928; the band is Ukkonen's,
+// what the first/lastBlock bookkeeping of :744-830 converges to) and the column loop of myersCalcEditDistanceSemiGlobal
+// (:550-704).  The lane rings of pair_kernels.hip hold bands up to K = 3968 on one wave; above that scan_pairs_kernel
+// walked every block of every column with ONE wave, strip after strip (round 3: tens of seconds for the reference's
+// 1 Mb x 1 Mb Chromosome pairs, test_data/perf_tests.sh:180-191).  Here:
 //
-//   * the query is cut into STRIPS of 64 blocks (4096 rows); strip s is one wave's work, lane = block, anti-diagonal
-//     schedule inside the wave exactly as in scan_pairs_kernel (lane l updates column j - l when lane 0 is at column j);
-//   * a strip only exists for the columns its blocks have inside the band: with d in [dmin, dmax] the diagonals a path of
-//     cost <= K can visit (:744-830), strip s runs columns [4096 s + dmin, 4096 s + 4095 + dmax] clipped to the target.
-//     All 64 lanes run that whole range (the blocks of a strip enter and leave the band within 4096 columns of each
-//     other: (bw + 4096) / (bw + 64) of the minimal work at band width bw, 1.24x at K = 16k, 1.03x at 128k);
+//   * the query is cut into STRIPS of 64 lanes x one 32-ROW WORD (2048 rows); strip s is one wave's work, anti-diagonal
+//     schedule inside the wave (lane l updates column j - l when lane 0 is at column j).  32-row words, not the
+//     reference's 64-row blocks: a unit on this kernel is a chain of dependent steps on waves that have their SIMD to
+//     themselves, where every issued instruction costs 2.2-3.5 ns whatever it is (tools/lone_wave_ubench.hip), and the
+//     block update (calculateBlock, :412-447) is 13 VALU instructions on a 32-bit word against 22 on a 64-bit pair;
+//   * a strip only exists for the columns its rows have inside the band: with d in [dmin, dmax] the diagonals a path of
+//     cost <= K can visit (:744-830), strip s runs columns [2048 s + dmin, 2048 s + 2047 + dmax] clipped to the target.
+//     All 64 lanes run that whole range ((bw + 2048) / (bw + 32) of the minimal work at band width bw);
 //   * the strips of a unit form a PIPELINE over `slots` resident waves (workgroup = one wave; slot j runs strips j,
 //     j + slots, ...): strip s + 1 consumes the horizontal deltas of strip s's bottom row (hout -> hin, :781-785) about
-//     100 columns behind it.  The deltas travel through HBM as 8-byte granules {tag = strip + 1, 16 columns x 2 bits},
-//     written by ONE agent-scope store of lane 63 every 16 steps and polled with agent-scope loads: the data is the
-//     flag (no fence, no separate counter; per-XCD L2s are not coherent, so both sides bypass them).  A consumer
-//     prefetches the granules of its next 64 columns while it works on the current ones;
+//     100 columns behind it.  The deltas travel through HBM as 8-byte granules {tag = strip + 1, 16 columns x (+1 bit,
+//     -1 bit)}, written by ONE agent-scope store of lane 63 every 16 steps and polled with agent-scope loads: the data
+//     is the flag (no fence, no separate counter; per-XCD L2s are not coherent, so both sides bypass them);
+//   * what lane 0 is fed per step -- the delta of the row above and the next target symbol -- is prepared 64 columns at
+//     a time by all lanes and parked in an LDS ring: one broadcast LDS read per step instead of scalar-unit glue;
+//   * sixteen steps at a time run as one straight-line block (no branch, no rare event inside); everything rare -- chunk
+//     rotation, polling, publishing, lanes outside their columns -- lives in a generic step between blocks;
 //   * a strip that starts after column 0 takes over the absolute score of the row above it from one more granule
 //     (bottom score of strip s at column c0(s + 1) - 1) and starts "+1 per row" below it, the reference's new block
 //     (:803-808); beyond the last column of the strip above, the row above delivers +1 per column (:779).  Cells outside
 //     the band only ever enter as such upper bounds, so values <= K stay exact (Ukkonen);
-//   * block scores are not followed per step: the 2-bit codes a lane emits are kept for 16 steps in the register that
-//     becomes the granule, and folded into the score by two popcounts when it is flushed;
-//   * NW: the last block's final state gives D[m][T] (:914-917); Hirschberg halves (bandT) stop at their column and dump
+//   * word scores are not followed per step: the hout bits a lane emits are shifted into two registers that become the
+//     granule, and folded into the score by two popcounts when it is flushed;
+//   * NW: the last word's final state gives D[m][T] (:914-917); Hirschberg halves (bandT) stop at their column and dump
 //     (Pv, Mv, score) of the blocks alive there (:1252-1260); SHW / HW: the lane of row m-1 follows its score and records
 //     best / count / positions (:658-673), no band.
 //
-// With slots >= (bw + 4096) / 4224 + 2 no wave ever waits for a free slot and a unit takes about T + bw dependent steps
-// whatever K is -- the time of ONE strip of the old kernel instead of nstrips of them.  Every spin is bounded (wall clock)
-// and a launch-wide abort word turns a stuck hand-off into EDLIB_STATUS_ERROR instead of a hung queue.
+// With slots >= (bw + 2048) / 2176 + 2 no wave ever waits for a free slot and a unit takes about T + bw dependent steps
+// whatever K is (0.074 us each on an MI355X).  Every spin is bounded (wall clock) and a launch-wide abort word turns a
+// stuck hand-off into EDLIB_STATUS_ERROR instead of a hung queue.
 #include "pair_kernels.hpp"
 #include "block64.hpp"
 #include "lds_check.hpp"
