@@ -25,6 +25,7 @@
 #include "block64.hpp"
 
 #include <cstring>
+#include <type_traits>
 
 namespace edlib_amd {
 
@@ -261,12 +262,192 @@ one_pair_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out)
     }
 }
 
+// ---------------------------------------------------------------- NW distance of one small pair, two waves
+//
+// A distance call is a chain of dependent steps on a wave that has its SIMD to itself (every issued
+// instruction costs 2.2-3.5 ns there), and the two halves of the target are independent of each other.  So for NW
+// without a path the call runs as TWO half scans on the two waves of one workgroup -- wave 0: query against the left
+// half, wave 1: reversed query against the reversed right half (what the first Hirschberg level does,
+// edlib.cpp:1246-1260) -- and D[m][T] = min over i of L[i] + R[i+1].  The scans are the wide kernel's step on 32-row
+// words (wide_kernels.hip): lane = word, 18 issued instructions per step, sixteen steps per straight-line block; the
+// feeds of lane 0 (row -1 is +1 per column, the next target byte as the LDS offset of its Peq row) are laid out for the
+// whole half before the scan.  Nothing is accumulated per step: every value of the last column is the top boundary plus
+// the vertical deltas above it, i.e. prefix sums of popcounts over the final Pv / Mv words.
+#define OP3_OR_NOR(a, b, c)  ((u32)__builtin_amdgcn_bitop3_b32((a), (b), (c), 0xf1))   /* a | ~(b | c)  */
+#define OP3_XOR_OR(a, b, c)  ((u32)__builtin_amdgcn_bitop3_b32((a), (b), (c), 0xde))   /* (a ^ c) | b   */
+#define OP3_BFI(m, a, b)     ((u32)__builtin_amdgcn_bitop3_b32((m), (a), (b), 0xca))   /* m ? a : b     */
+
+__global__ void __launch_bounds__(128)
+one_pair_nw_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
+    const OneHeader h = *reinterpret_cast<const OneHeader*>(in);
+    const int m = h.m, T = h.T, k = h.k;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nw = (m + 31) >> 5;                                    // 32-row words: at most 32 lanes of a wave
+    int shiftS = 2; while ((1 << shiftS) < 4 * nw) ++shiftS;         // Peq row stride in bytes: 4 nw rounded up to a power of two
+    const u32 tableBytes = 256u << shiftS;
+    const int lw = T / 2, rw = T - lw;                               // edlib.cpp:1247-1248
+    const int myT = wv == 0 ? lw : rw;
+    // ---- LDS: [Peq forward | Peq reverse] at address 0 | query | target | feeds of the two halves | final columns | minima
+    u32* s_peq = reinterpret_cast<u32*>(s_mem);
+    uint8_t* s_q = s_mem + 2 * tableBytes;
+    uint8_t* s_t = s_q + ((m + 15) & ~15);
+    u64* s_feed = reinterpret_cast<u64*>(s_t + ((T + 15) & ~15));    // [2][rw + 2]
+    u32* s_col = reinterpret_cast<u32*>(s_feed + 2 * (rw + 2));      // [2][3][32]: Pv, Mv, score above the word
+    int* s_min = reinterpret_cast<int*>(s_col + 2 * 3 * 32);
+    {
+        const u32* qs = reinterpret_cast<const u32*>(in + sizeof(OneHeader));
+        const u32* ts = reinterpret_cast<const u32*>(in + sizeof(OneHeader) + ((m + 15) & ~15));
+        for (int i = tid; i < (m + 3) / 4; i += 128) reinterpret_cast<u32*>(s_q)[i] = qs[i];
+        for (int i = tid; i < (T + 3) / 4; i += 128) reinterpret_cast<u32*>(s_t)[i] = ts[i];
+        for (u32 i = tid; i < 2 * tableBytes / 16; i += 128) reinterpret_cast<uint4*>(s_peq)[i] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    // buildPeq (edlib.cpp:358-384) keyed by the raw byte, forward and reversed: bit r of row[byte][word] = query[32 word + r] == byte
+    for (int i = tid; i < m; i += 128) {
+        const u32 c = s_q[i];
+        atomicOr(&s_peq[((c << shiftS) >> 2) + (i >> 5)], 1u << (i & 31));
+        const int ir = m - 1 - i;
+        atomicOr(&s_peq[((tableBytes + (c << shiftS)) >> 2) + (ir >> 5)], 1u << (ir & 31));
+    }
+    // feeds of lane 0: slot j + 1 = column j of the half: {A: row -1 delivers +1 (edlib.cpp:779), B: Peq row offset of column j + 1}
+    {
+        u64* f = s_feed + wv * (rw + 2);
+        const u32 base = wv == 0 ? 0u : tableBytes;
+        for (int j = lane - 1; j < myT; j += 64) {
+            const int c = j + 1;                                      // column of the half whose byte this feed carries
+            u32 off = base;
+            if (c < myT) off += (u32)s_t[wv == 0 ? c : T - 1 - c] << shiftS;
+            f[j + 1] = ((u64)off << 32) | 0x80000000u;
+        }
+    }
+    __syncthreads();
+    // ---- the half scan of this wave: lane l < nw owns word l, at step t it updates column t - l
+    u32 Pv = ~0u, Mv = 0u;                                           // column -1 (edlib.cpp:575-579)
+    if (myT > 0) {
+        const u32 laneOff = 4u * (u32)lane;
+        const u32 feedAddr = (u32)(size_t)(__attribute__((address_space(3))) u64*)(s_feed + wv * (rw + 2));
+        const u32 rowMask = ~((1u << shiftS) - 1u) & 0x7fffffffu;
+        auto feed_at = [&](const int slot) -> u64 { return *(const __attribute__((address_space(3))) u64*)(size_t)(feedAddr + 8u * (u32)slot); };
+        u32 PhOut = 0, Bout = 0, eq = 0;
+        auto step = [&](auto genericTag, const int t, const u64 feed) {
+            constexpr bool GENERIC = decltype(genericTag)::value;
+            const u32 A = (u32)__builtin_amdgcn_update_dpp((int)(u32)feed, (int)PhOut, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+            const u32 Bv = (u32)__builtin_amdgcn_update_dpp((int)(u32)(feed >> 32), (int)Bout, 0x138, 0xf, 0xf, false);
+            const u32 eqNxt = *(const __attribute__((address_space(3))) u32*)(size_t)((Bv & rowMask) | laneOff);
+            if (!GENERIC || (lane < nw && (unsigned)(t - lane) < (unsigned)myT)) {
+                const u32 hneg = Bv >> 31;                             // reference calculateBlock (edlib.cpp:412-447) on a 32-row word
+                const u32 eqn = eq | hneg;
+                const u32 xv = eq | Mv;
+                const u32 sum = (eqn & Pv) + Pv;
+                const u32 xh = OP3_XOR_OR(sum, eqn, Pv);
+                const u32 ph = OP3_OR_NOR(Mv, xh, Pv);
+                const u32 mh = Pv & xh;
+                const u32 phs = __builtin_amdgcn_alignbit(ph, A, 31);
+                const u32 mhs = __builtin_amdgcn_alignbit(mh, Bv, 31);
+                Pv = OP3_OR_NOR(mhs, xv, phs);
+                Mv = phs & xv;
+                PhOut = ph;
+                Bout = OP3_BFI(0x80000000u, mh, Bv);
+            } else {
+                Bout = Bv;
+            }
+            eq = eqNxt;
+        };
+        const int nsteps = myT + nw - 1;
+        // (the feed of step t is slot t + 1: column t of lane 0; step -1 only hands the first symbol down)
+        int t = -1;
+        while (t < nsteps) {
+            if (t >= nw - 1 && t + 15 <= myT - 1) {                    // every lane < nw inside its columns: sixteen straight-line steps
+                const u64 f0 = feed_at(t + 1), f1 = feed_at(t + 2), f2 = feed_at(t + 3), f3 = feed_at(t + 4);
+                step(std::false_type{}, t, f0);
+                const u64 f4 = feed_at(t + 5);
+                step(std::false_type{}, t + 1, f1);
+                const u64 f5 = feed_at(t + 6);
+                step(std::false_type{}, t + 2, f2);
+                const u64 f6 = feed_at(t + 7);
+                step(std::false_type{}, t + 3, f3);
+                const u64 f7 = feed_at(t + 8);
+                step(std::false_type{}, t + 4, f4);
+                const u64 f8 = feed_at(t + 9);
+                step(std::false_type{}, t + 5, f5);
+                const u64 f9 = feed_at(t + 10);
+                step(std::false_type{}, t + 6, f6);
+                const u64 f10 = feed_at(t + 11);
+                step(std::false_type{}, t + 7, f7);
+                const u64 f11 = feed_at(t + 12);
+                step(std::false_type{}, t + 8, f8);
+                const u64 f12 = feed_at(t + 13);
+                step(std::false_type{}, t + 9, f9);
+                const u64 f13 = feed_at(t + 14);
+                step(std::false_type{}, t + 10, f10);
+                const u64 f14 = feed_at(t + 15);
+                step(std::false_type{}, t + 11, f11);
+                const u64 f15 = feed_at(t + 16);
+                step(std::false_type{}, t + 12, f12);
+                step(std::false_type{}, t + 13, f13);
+                step(std::false_type{}, t + 14, f14);
+                step(std::false_type{}, t + 15, f15);
+                t += 16;
+            } else {
+                step(std::true_type{}, t, (t + 1 <= myT) ? feed_at(t + 1) : 0ull);
+                t += 1;
+            }
+        }
+    }
+    // ---- the last column of the half: score above each word = (columns of the half) + vertical deltas of the words above
+    {
+        const int d = (lane < nw) ? __popc(Pv) - __popc(Mv) : 0;       // (an empty half: Pv = ~0: +1 per row, D[i][-1] = i + 1)
+        int incl = d;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+        if (lane < 32) {
+            u32* c = s_col + wv * 96;
+            c[lane] = Pv; c[32 + lane] = Mv; c[64 + lane] = (u32)(myT + incl - d);
+        }
+    }
+    __syncthreads();
+    // ---- D[m][T] = min over i in [-1, m-1] of L[i] + R[i+1]   (L[-1] = lw, R[m] = rw; edlib.cpp:1314-1353)
+    auto cell = [&](const int half, const int r) -> int {             // value of row r in the half's last column
+        const u32* c = s_col + half * 96;
+        const int wd = r >> 5, bit = r & 31;
+        const u32 upto = (bit == 31) ? ~0u : ((2u << bit) - 1u);
+        return (int)c[64 + wd] + __popc(c[wd] & upto) - __popc(c[32 + wd] & upto);
+    };
+    int best = 0x3fffffff;
+    for (int i = tid - 1; i <= m - 1; i += 128) {
+        const int L = (i < 0) ? lw : cell(0, i);
+        const int R = (i == m - 1) ? rw : cell(1, m - 2 - i);
+        best = (L + R < best) ? L + R : best;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(best, off, 64); best = o < best ? o : best; }
+    if (lane == 0) s_min[wv] = best;
+    __syncthreads();
+    if (tid == 0) {
+        OneResult* res = reinterpret_cast<OneResult*>(out);
+        int* ends = reinterpret_cast<int*>(out + sizeof(OneResult));
+        int* starts = ends + kOneMaxLoc + 1;
+        const int ed0 = s_min[0] < s_min[1] ? s_min[0] : s_min[1];
+        const bool over = k >= 0 && ed0 > k;                          // edlib.cpp:744-747, 917
+        res->editDistance = over ? -1 : ed0;
+        res->numLocations = over ? 0 : 1; res->hasEnds = over ? 0 : 1;
+        res->hasStarts = (!over && h.task >= 1) ? 1 : 0;              // NW: start 0 (:267-271)
+        res->hasAlignment = 0; res->alignmentLength = 0;
+        if (!over) { ends[0] = T - 1; starts[0] = 0; }
+        res->code = 0;
+        __threadfence_system();
+    }
+}
+
 // per-thread context: stream + mailboxes (cached for the life of the thread)
 struct OneCtx {
     int device = -1;
     hipStream_t stream = nullptr;
     PinBuf in, out;
     int attrDevice = -1;                    // device the kernel's dynamic-LDS limit was raised on
+    bool nwKernelOk = false;                // one_pair_nw_kernel has no static LDS in front of its tables
     // (runs at thread exit, for the main thread at process exit: no HIP call here; every call ended with a stream synchronisation)
     ~OneCtx() { if (stream) pool_stream_put(device, stream); }
 };
@@ -282,10 +463,13 @@ int align_one_fused(const char* q, int m, const char* t, int T, EdlibAlignConfig
     const int mode = (int)cfg.mode, task = (int)cfg.task;
     if (mode < 0 || mode > 2 || task < 0 || task > 2) return 2;
     const int nb = (m + 63) / 64;
+    // NW without a path: two half scans on two waves (one_pair_nw_kernel), any size this file takes
+    static const bool nwFast = !(getenv("EDLIB_AMD_ONEPAIR_NW") && getenv("EDLIB_AMD_ONEPAIR_NW")[0] == '0');
+    const bool nwKernel = nwFast && mode == 0 && task != 2 && T >= 2;
     // One wave walks T + nb dependent steps of ~0.2 us here; beyond ~400 steps the batch-of-one path (ring kernel: ~0.12 us
     // per step behind ~45 us of launches and copies) is the faster one for distances.  PATH is faster here whenever its
     // store fits (1 k x 1 k: the general path takes 900 us).
-    if (task != 2 && T + nb > 400) return 2;
+    if (!nwKernel && task != 2 && T + nb > 400) return 2;
     // LDS: Peq table + sequences + positions + ops, the rest is the column store of a PATH call
     const size_t fixed = (size_t)256 * nb * 8 + ((m + 15) & ~15) + ((T + 15) & ~15) + kOneMaxLoc * sizeof(int) + ((m + T + 15) & ~15);
     if (fixed > (size_t)kOneLdsBudget) return 2;
@@ -324,6 +508,10 @@ int align_one_fused(const char* q, int m, const char* t, int T, EdlibAlignConfig
     }
     if (ctx.attrDevice != dev) {            // (a function attribute is per device)
         EDLIB_AMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(one_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kOneLdsBudget + 1024));
+        EDLIB_AMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(one_pair_nw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kOneLdsBudget + 1024));
+        hipFuncAttributes fa;               // the Peq tables of the two-wave kernel are addressed from LDS address 0
+        EDLIB_AMD_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(one_pair_nw_kernel)));
+        ctx.nwKernelOk = fa.sharedSizeBytes == 0;
         ctx.attrDevice = dev;
     }
     OneHeader* h = reinterpret_cast<OneHeader*>(ctx.in.p);
@@ -333,6 +521,13 @@ int align_one_fused(const char* q, int m, const char* t, int T, EdlibAlignConfig
     OneResult* r = reinterpret_cast<OneResult*>(ctx.out.p);
     r->code = -1;
     const size_t lds = fixed + (task == 2 ? storeCap * 16 : 0) + 64;
+    if (nwKernel && ctx.nwKernelOk) {
+        const int nw = (m + 31) / 32;
+        int shiftS = 2; while ((1 << shiftS) < 4 * nw) ++shiftS;
+        const size_t ldsNw = 2 * ((size_t)256 << shiftS) + ((m + 15) & ~15) + ((T + 15) & ~15) + 2 * (size_t)(T - T / 2 + 2) * 8 + 2 * 3 * 32 * 4 + 64;
+        hipLaunchKernelGGL(one_pair_nw_kernel, dim3(1), dim3(128), ldsNw, ctx.stream, ctx.in.p, ctx.out.p);
+    } else if (nwKernel && T + nb > 400) return 2;
+    else
     hipLaunchKernelGGL(one_pair_kernel, dim3(1), dim3(64), lds, ctx.stream, ctx.in.p, ctx.out.p);
     EDLIB_AMD_HIP(hipGetLastError());
     // alphabetLength (edlib.cpp:162, transformSequences :1417-1462) while the kernel runs: distinct bytes of query and target
