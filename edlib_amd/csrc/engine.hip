@@ -1171,7 +1171,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         if (wantPath) storeEntries += ring > 0 ? ring_store_entries(ring, s.qlen, s.tlen) : pair_store_entries(s.qlen, s.tlen);
         d.posCap = wantPositions ? kPosCap : 0;
         d.posOff = (long long)i * kPosCap;
-        d.colOff = -1; d.bandT = 0; d.ring = ring > 0 ? ring : 0;
+        d.colOff = -1; d.bandT = (s.band && mode == EDLIB_MODE_SHW) ? -1 : 0; d.ring = ring > 0 ? ring : 0;
         // op slot of the unit, filled from the back.  An alignment has (m + T + inserts + deletes) / 2 ops, and a ring scan
         // is only walked when its distance is within kinit: (m + T + kinit) / 2 bounds the length (config 5: 1064 bytes
         // instead of 2000 per pair to bring back over PCIe)
@@ -1182,7 +1182,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         // executed work: whole matrix, or one 64-block wave per column inside the band
         // executed work: the strips update every block of every column; the rings count the updates inside the band themselves
         if (!ring) stats.word_steps += 2 * nb * (long long)s.tlen;
-        else if (ring == kWide) stats.word_steps += wide_word_steps(mode, s.qlen, s.tlen, 0, s.kinit);
+        else if (ring == kWide) stats.word_steps += wide_word_steps(mode, s.qlen, s.tlen, d.bandT, s.kinit);
     }
     WidePlan wplan;
     if (ring == kWide && planWide(mode, descs, n, wplan)) return 1;
@@ -1973,6 +1973,12 @@ int Batch::solveSemiGlobal(int mode, bool wantPositions, const std::vector<UnitS
 {
     const size_t n = units.size();
     const bool off = getenv("EDLIB_AMD_HWSEG") && getenv("EDLIB_AMD_HWSEG")[0] == '0';
+    if (mode == EDLIB_MODE_SHW && n > 0 && !(getenv("EDLIB_AMD_SHWBAND") && getenv("EDLIB_AMD_SHWBAND")[0] == '0')) {
+        // (queries of up to four blocks sit whole on the smallest ring whatever their threshold: nothing to band)
+        bool any = false;
+        for (size_t i = 0; i < n && !any; ++i) any = units[i].qlen > 256;
+        if (any) return solveShwBanded(wantPositions, units, out);
+    }
     if (mode != EDLIB_MODE_HW || n == 0 || n >= 4096 || off) return solveSemiGlobalUnits(mode, wantPositions, units, out);
     const long long smax = std::max<long long>(1, 8192 / (long long)n);
     std::vector<UnitSpec> sub; std::vector<int> firstSeg(n + 1, 0); std::vector<int> base;   // base: first recorded column of a segment
@@ -2016,6 +2022,65 @@ int Batch::solveSemiGlobal(int mode, bool wantPositions, const std::vector<UnitS
     return 0;
 }
 
+// SHW with a threshold: D[i][j] >= |i - j|, so a scan with threshold K only needs the diagonals [-K, K] and the first
+// m + K columns (the reference's band for SHW, edlib.cpp:562, 602-630, written for a fixed k).  A unit with a real
+// threshold (the reverse scans of HW start locations run with k = the distance, :253-257; calls with k >= 0) is scanned
+// inside that band once; an open unit (k = -1: threshold m) climbs levels K = 256, 1024, 4096 ... like the reference
+// doubles k (:197-217), the answer being exact as soon as some column scores <= K.  What it buys: the smallest ring that
+// holds the BAND instead of the whole query (a 10 kb reverse scan with k = 100 on an 8-lane... here 16-lane ring, four
+// units per wave, instead of five 2048-row strips), and m + K columns instead of 2 m.
+int Batch::solveShwBanded(bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out)
+{
+    const size_t n = units.size();
+    out.score.assign(n, -1); out.count.assign(n, 0); out.last.assign(n, -1);
+    out.posStart.assign(n + 1, 0); out.posFlat.clear();
+    out.opsPtr.assign(n, nullptr); out.opsLen.assign(n, 0); out.opsBufs.clear();
+    std::vector<long long> kcur(n);
+    std::vector<std::vector<int>> posOf(wantPositions ? n : 0);
+    std::vector<size_t> rest;
+    // a level K can only find a column when row m-1 is inside its band somewhere: T >= m - K (else the kernels would never
+    // start the last block); levels that cannot are skipped, a unit whose own threshold cannot has no answer (-1)
+    auto reachable = [&](const UnitSpec& u, long long K) { return (long long)u.tlen >= (long long)u.qlen - K; };
+    for (size_t i = 0; i < n; ++i) {
+        const UnitSpec& u = units[i];
+        if (!reachable(u, std::min(u.kinit, u.qlen))) continue;
+        kcur[i] = u.kinit < u.qlen ? u.kinit : 256;
+        while (kcur[i] < u.kinit && !reachable(u, kcur[i])) kcur[i] *= 4;
+        rest.push_back(i);
+    }
+    while (!rest.empty()) {
+        std::vector<UnitSpec> sel; sel.reserve(rest.size());
+        for (size_t i : rest) {
+            UnitSpec u = units[i];
+            const long long K = std::min<long long>(kcur[i], u.kinit);
+            u.kinit = (int)K;
+            u.band = K < u.qlen ? 1 : 0;
+            u.tlen = (int)std::min<long long>(u.tlen, (long long)u.qlen + K);
+            sel.push_back(u);
+        }
+        SolveOut so;
+        if (solveSemiGlobalUnits(EDLIB_MODE_SHW, wantPositions, sel, so)) return 1;
+        std::vector<size_t> again;
+        for (size_t q = 0; q < sel.size(); ++q) {
+            const size_t i = rest[q];
+            if (so.score[q] >= 0 || sel[q].kinit >= units[i].kinit) {          // exact / the caller's own threshold found nothing
+                out.score[i] = so.score[q]; out.count[i] = so.count[q]; out.last[i] = so.last[q];
+                if (wantPositions) posOf[i].assign(so.posFlat.begin() + so.posStart[q], so.posFlat.begin() + so.posStart[q + 1]);
+                continue;
+            }
+            kcur[i] = 4LL * sel[q].kinit;
+            again.push_back(i);
+        }
+        rest.swap(again);
+    }
+    if (wantPositions)
+        for (size_t i = 0; i < n; ++i) {
+            out.posFlat.insert(out.posFlat.end(), posOf[i].begin(), posOf[i].end());
+            out.posStart[i + 1] = (long long)out.posFlat.size();
+        }
+    return 0;
+}
+
 int Batch::solveSemiGlobalUnits(int mode, bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out)
 {
     const size_t n = units.size();
@@ -2034,6 +2099,15 @@ int Batch::solveSemiGlobalUnits(int mode, bool wantPositions, const std::vector<
         const int nb = (units[i].qlen + 63) / 64;
         if (!ringsOff) grp[i] = nb <= 4 ? 0 : (nb <= 16 ? 1 : (nb <= 32 ? 2 : (nb <= 64 ? 3 : 4)));
         if (nb > 64 && !wideOff) grp[i] = 5;
+        // a banded SHW unit (UnitSpec::band) needs the ring that holds its band, not its query
+        if (mode == EDLIB_MODE_SHW && units[i].band && !ringsOff) {
+            // (the SHW band [-K, K] is 2 K + 1 rows wide, twice the NW band of the same threshold: ring_max_k / 2)
+            const long long K2 = 2LL * units[i].kinit;
+            if (nb > 4 && K2 <= ring_max_k(4)) grp[i] = 0;
+            else if (nb > 16 && K2 <= ring_max_k(16)) grp[i] = 1;
+            else if (nb > 32 && K2 <= ring_max_k(16, 2)) grp[i] = 2;
+            else if (nb > 64 && K2 <= ring_max_k(16, 4)) grp[i] = 3;
+        }
         ++cnt[grp[i]];
     }
     for (int g = 0; g < NG; ++g)

@@ -31,6 +31,7 @@ struct UnitSpec {
     long long toff; int tlen; int tstep;
     int kinit;
     int skip = 0;      // HW target segments: leading warm-up columns whose scores are not recorded
+    int band = 0;      // SHW: scan only the diagonals [-kinit, kinit] (a cell within kinit of the origin's diagonal has |i - j| <= kinit)
 };
 
 struct SolveOut {
@@ -230,6 +231,8 @@ private:
     // SHW / HW units: short queries packed on 4- and 16-lane rings, the rest on the strips
     int solveSemiGlobal(int mode, bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out);
     int solveSemiGlobalUnits(int mode, bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out);
+    // SHW inside Ukkonen's band (edlib.cpp:562, 602-630): threshold levels like the NW distances, target cut at m + K
+    int solveShwBanded(bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out);
     // alphabetLength of the empty / pair units: launched on a side stream before phase 1, collected after it
     int alphabetLengthsBegin();
     int alphabetLengthsEnd(std::vector<UnitResult>& res);

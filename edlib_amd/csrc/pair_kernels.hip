@@ -405,13 +405,17 @@ scan_pairs_ring_kernel(const PairScanArgs a)
     const long long storeOff = STORE ? uni64(dp->storeOff) : 0;
     const int nb = num_blocks(m);                                     // 64-row blocks
     const int nsb = (nb + H - 1) / H;                                 // ring-lane blocks of RH rows
-    const int D = (bandT ? bandT : T) - m, absD = D < 0 ? -D : D;     // the band is that of the whole problem
+    // MODE 1 with bandT < 0: SHW inside the band of threshold K -- a cell (i, j) with D <= K has |i - j| <= K, so the band
+    // is the diagonals [-K, K] whatever the lengths are (the reference's SHW band, edlib.cpp:562, 602-630, for a fixed k);
+    // the host cuts the target at column m + K and answers "none" itself when T < m - K
+    const bool shwBand = MODE == 1 && bandT < 0;
+    const int D = shwBand ? 0 : (bandT > 0 ? bandT : T) - m, absD = D < 0 ? -D : D;     // the band is that of the whole problem
     // last-column dump of Hirschberg halves: the packed rings look their slot up when they get there
     const bool dumpCol = a.colP != nullptr && (G != 64 || colOffU >= 0);
     const bool active = have && (MODE != 0 || K >= absD);
     if (have && !active && rl == 0) { a.outScore[unit] = 0x3fffffff; a.outCount[unit] = 0; a.outLast[unit] = -1; }
     if (__builtin_amdgcn_ballot_w64(active) == 0ull) return;
-    const int p = MODE != 0 ? (1 << 28) : (K - absD) >> 1;            // semi-global: the whole matrix
+    const int p = MODE != 0 ? (shwBand ? K : (1 << 28)) : (K - absD) >> 1;            // semi-global: the whole matrix unless banded
     const int dmin = (D < 0 ? D : 0) - p, dmax = (D > 0 ? D : 0) + p;
     int best = K, cnt = 0, lastCol = -1;                              // MODE != 0: columns scoring <= best qualify
     const u32 sh = (u32)(m - 1) & 63u;                                // row m-1 inside its 64-row block ...
@@ -639,9 +643,10 @@ count_ring_steps_kernel(const PairDesc* __restrict__ descs, const int n, const i
         const PairDesc d = descs[unit];
         const int m = d.qlen, T = d.tlen, K = d.kinit, RH = 64 * H;
         const int nsb = (num_blocks(m) + H - 1) / H;
-        const int D = (d.bandT ? d.bandT : T) - m, absD = D < 0 ? -D : D;
+        const bool shwBand = mode == 1 && d.bandT < 0;
+        const int D = shwBand ? 0 : (d.bandT > 0 ? d.bandT : T) - m, absD = D < 0 ? -D : D;
         if (mode != 0 || K >= absD) {
-            const int p = mode != 0 ? (1 << 28) : (K - absD) >> 1;
+            const int p = mode != 0 ? (shwBand ? K : (1 << 28)) : (K - absD) >> 1;
             const int dmin = (D < 0 ? D : 0) - p, dmax = (D > 0 ? D : 0) + p;
             for (int b = 0; b < nsb; ++b) {
                 int f = RH * b + dmin, l = RH * b + RH - 1 + dmax;

@@ -57,8 +57,9 @@ struct WideGeom { long long dmin, dmax; };
 // diagonals j - i a path of cost <= K can visit (NW); semi-global modes: the whole matrix
 __host__ __device__ static inline WideGeom wide_geom(int mode, int m, int T, int bandT, int K)
 {
+    if (mode == 1 && bandT < 0) return WideGeom{-(long long)K, (long long)K};     // SHW inside the band of threshold K: |i - j| <= K
     if (mode != 0) return WideGeom{-kWideInf, kWideInf};
-    const long long D = (long long)(bandT ? bandT : T) - m, absD = D < 0 ? -D : D;
+    const long long D = (long long)(bandT > 0 ? bandT : T) - m, absD = D < 0 ? -D : D;
     const long long p = ((long long)K - absD) >> 1;
     return WideGeom{(D < 0 ? D : 0) - p, (D > 0 ? D : 0) + p};
 }
@@ -126,7 +127,7 @@ scan_pairs_wide_kernel(const PairScanArgs a)
     const int nw = num_words(m), nb64 = num_blocks(m), nstrips = (nw + 63) >> 6;
     const u32 sh = (u32)(m - 1) & 31u;                               // row m-1 inside the last word
     if (MODE == 0) {
-        const long long D = (long long)(d.bandT ? d.bandT : T) - m, absD = D < 0 ? -D : D;
+        const long long D = (long long)(d.bandT > 0 ? d.bandT : T) - m, absD = D < 0 ? -D : D;
         if ((long long)K < absD) {                                   // no path of cost <= K exists (edlib.cpp:749-754)
             if (slot == 0 && lane == 0) { a.outScore[unit] = 0x3fffffff; a.outCount[unit] = 0; a.outLast[unit] = -1; }
             return;

@@ -124,3 +124,38 @@ def test_long_semi_global_queries_as_pipelined_strips(engine, checker, mode):
     with _env(EDLIB_AMD_WIDE_SLOTS=1):
         _check(engine, checker, qs, ts, mode, "distance", -1, "strips, one slot")
     _check(engine, checker, qs[:2], ts[:2], mode, "distance", 300, "strips fixed k")
+
+
+def test_shw_inside_the_band_of_a_threshold(engine, checker):
+    """SHW pairs on the smallest ring that holds the BAND [-K, K] (4 / 16 lanes, 16 lanes of 2 / 4 blocks) or on the wide
+    kernel inside that band: fixed k below / at / above the distance, k = -1 (levels 256, 1024, ...), the reverse scans
+    of HW start locations (k = the distance) behind HW locations / path on long queries, targets shorter than m - k."""
+    rng = random.Random(9006 + SEED_SHIFT)
+    qs, ts = [], []
+    for m in (300, 1100, 2500, 5000, 12000):
+        for rate in (0.01, 0.08, 0.3):
+            t = synth.random_dna(rng.randrange(1 << 30), m + rng.randrange(0, 3000))
+            q, _ = synth.mutate(t[:m], rng.randrange(1 << 30), rate / 2, rate / 4, rate / 4)
+            qs.append(q.tobytes()); ts.append(t.tobytes())
+    qs.append(synth.random_dna(31, 6000).tobytes()); ts.append(synth.random_dna(32, 9000).tobytes())   # unrelated
+    qs.append(synth.random_dna(33, 6000).tobytes()); ts.append(synth.random_dna(34, 2000).tobytes())   # target shorter than the query
+    for task in ("distance", "locations"):
+        _check(engine, checker, qs, ts, "SHW", task, -1, "shw band, open")
+    ds = [checker.align(q, t, "SHW", "distance", -1)["editDistance"] for q, t in zip(qs, ts)]
+    for k in (5, 40, 130, 500, 2000):
+        _check(engine, checker, qs, ts, "SHW", "locations", k, "shw band, fixed k")
+    for i in (1, 4, 7, 10, 13):                          # one unit at a time right around its own distance
+        for k in (ds[i] - 1, ds[i], ds[i] + 1):
+            if k >= 0:
+                _check(engine, checker, qs[i:i + 1], ts[i:i + 1], "SHW", "locations", k, "shw band at its distance")
+    # HW on long queries: every end location gets a reverse SHW scan with k = the distance (edlib.cpp:253-257)
+    hq, ht = [], []
+    for m, rate in ((1100, 0.02), (3000, 0.05), (7000, 0.01), (9000, 0.1)):
+        t = synth.random_dna(rng.randrange(1 << 30), 3 * m)
+        a = rng.randrange(0, 2 * m)
+        q, _ = synth.mutate(t[a:a + m], rng.randrange(1 << 30), rate / 2, rate / 4, rate / 4)
+        hq.append(q.tobytes()); ht.append(t.tobytes())
+    for task in ("locations", "path"):
+        _check(engine, checker, hq, ht, "HW", task, -1, "hw starts behind banded reverse scans")
+    with _env(EDLIB_AMD_SHWBAND="0"):
+        _check(engine, checker, qs[:6], ts[:6], "SHW", "locations", 40, "shw band off")

@@ -147,3 +147,27 @@ def test_strip_ranges_cover_the_band():
                 assert prev[0] <= c0 - 1 <= prev[1]          # the strip above passes column c0 - 1 (start score)
                 assert prev[1] >= c0                          # and is still alive at c0 (first hin is a real delta)
             prev = (c0, c1)
+
+
+@pytest.mark.parametrize("L", [1, 2, 3])
+def test_shw_inside_the_band_of_a_threshold(oracle, L):
+    """SHW with threshold K only needs the diagonals [-K, K] and the first m + K columns: same answer as the oracle with
+    k = K (score, every end position), "none" when the distance is above K"""
+    rng = random.Random(77 + L)
+    for it in range(60):
+        T = rng.randrange(1, 700)
+        t = _rand(rng, T)
+        q = _mutate(rng, t[:rng.randrange(1, T + 1)], rng.choice([0.02, 0.1, 0.3])) if rng.random() < 0.8 else _rand(rng, rng.randrange(1, 400))
+        m = len(q)
+        d = oracle.align(q, t, "SHW", "distance", -1)["editDistance"]
+        for K in sorted({max(1, d // 2), max(1, d - 1), max(1, d), d + 1, d + 40}):
+            if K >= m or T < m - K:
+                continue                                       # (the host scans such units unbanded / answers "none" itself)
+            want = oracle.align(q, t, "SHW", "distance", K)
+            tcut = t[:m + K]
+            score, count, last, positions, _ = wide_scan(q, tcut, 1, K, L=L, bandT=-1)
+            ends = [e for e in (want["endLocations"] or []) if e >= 0]
+            if want["editDistance"] < 0 or not ends:
+                assert score == -1 or (want["editDistance"] == m), (it, m, T, K, d, score)
+                continue
+            assert score == want["editDistance"] and positions == ends, (it, m, T, K, d, score, positions, ends)

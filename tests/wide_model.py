@@ -20,9 +20,11 @@ def popc(x):
 
 
 def geom(mode, m, T, bandT, K):
+    if mode == 1 and bandT < 0:                          # SHW inside the band of threshold K: |i - j| <= K
+        return -K, K
     if mode != 0:
         return -(1 << 40), 1 << 40
-    D = (bandT or T) - m
+    D = (bandT if bandT > 0 else T) - m
     p = (K - abs(D)) >> 1
     return min(0, D) - p, max(0, D) + p
 
@@ -59,7 +61,7 @@ def wide_scan(q, t, mode, K, L=64, bandT=0, skip=0, pos_cap=1 << 30):
     m, T = len(q), len(t)
     nb = (m + WB - 1) // WB
     nstrips = (nb + L - 1) // L
-    if mode == 0 and K < abs((bandT or T) - m):
+    if mode == 0 and K < abs((bandT if bandT > 0 else T) - m):
         return None
     dmin, dmax = geom(mode, m, T, bandT, K)
     peq = {}
