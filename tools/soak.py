@@ -117,6 +117,38 @@ def pair_case():
     return nq, compare(got, ref, task, "pairs mode=%s task=%s k=%d nq=%d base=%d sigma=%d" % (mode, task, k, nq, base, sig))
 
 
+def long_pair_case():
+    """a few long pairs: the wide kernel (NW bands beyond the rings, two half scans, Hirschberg halves), SHW / HW queries
+    of many strips, SHW inside the band of a threshold"""
+    from oracle.oracle import load_ref, load_oracle
+    chk = load_ref() or load_oracle()
+    nq = int(rng.choice([1, 2, 5]))
+    qs, ts = [], []
+    mode = str(rng.choice(["NW", "NW", "SHW", "HW"]))
+    for _ in range(nq):
+        tn = int(rng.choice([3000, 5000, 9000, 20000, 40000]))
+        t = synth.random_dna(int(rng.integers(1 << 30)), tn)
+        rate = float(rng.choice([0.005, 0.03, 0.12, 0.3]))
+        if mode == "NW":
+            q, _ = synth.mutate(t, int(rng.integers(1 << 30)), rate / 2, rate / 4, rate / 4)
+        else:
+            m = int(tn * (0.2 + 0.7 * rng.random()))
+            a = 0 if mode == "SHW" else int(rng.integers(0, tn - m + 1))
+            q, _ = synth.mutate(t[a:a + m], int(rng.integers(1 << 30)), rate / 2, rate / 4, rate / 4)
+        if rng.random() < 0.15: q = synth.random_dna(int(rng.integers(1 << 30)), max(1, len(q)))
+        qs.append(q.tobytes()); ts.append(t.tobytes())
+    task = str(rng.choice(["distance", "distance", "locations", "path"]))
+    if task == "path" and chk.name != "reference": task = "locations"      # (the restatement has no Hirschberg regime)
+    k = int(rng.choice([-1, -1, -1, 30, 400, 5000]))
+    got = edlib_amd.align_pairs(qs, ts, mode=mode, task=task, k=k, raw=True)
+    bad = None
+    for q, t, g in zip(qs, ts, got):
+        w = chk.align(q, t, mode, task, k)
+        if any(g[f] != w[f] for f in ("status", "editDistance", "endLocations", "startLocations", "numLocations", "alignment", "alphabetLength")):
+            bad = "long pairs mode=%s task=%s k=%d m=%d T=%d" % (mode, task, k, len(q), len(t))
+    return nq, bad
+
+
 def single_case():
     """edlibAlign() one pair at a time: the fused one-pair kernel and its hand-over to the general path"""
     from oracle.oracle import load_ref, load_oracle
@@ -136,7 +168,7 @@ def single_case():
 t0 = time.time(); cases = units = 0; failures = []
 while time.time() - t0 < budget and cases < max_cases:
     x = rng.random()
-    n, err = shared_case() if x < 0.55 else (pair_case() if x < 0.9 else single_case())
+    n, err = shared_case() if x < 0.5 else (pair_case() if x < 0.8 else (long_pair_case() if x < 0.9 else single_case()))
     cases += 1; units += n
     if err:
         failures.append(err); print("MISMATCH", err, file=sys.stderr)
