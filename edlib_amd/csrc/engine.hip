@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <system_error>
 #include <thread>
@@ -407,6 +408,7 @@ Batch::~Batch() {
     DeviceGuard guard(device_);
     if (side_) { (void)hipStreamSynchronize(side_); pool_stream_release(side_); }
     if (stream_) { (void)hipStreamSynchronize(stream_); pool_stream_release(stream_); }
+    wideGateRelease();           // (behind the synchronisation: a failed run may still have had a wide launch in flight)
     for (auto& p : scanEvents_) { pool_event_release(p.first, device_); pool_event_release(p.second, device_); }
 }
 
@@ -1386,8 +1388,34 @@ int Batch::planWide(int mode, PairDesc* descs, size_t n, WidePlan& plan)
     return 0;
 }
 
+// The strip pipelines spin on each other, so the workgroups of a wide launch must all be resident -- which the sizing of
+// ONE launch guarantees (planWide) and two launches from two host threads sharing the device would not: each could hold
+// the slots the other is waiting for until the hand-off timeout.  So wide launches of a process take turns per device:
+// the gate is taken before the first launch of a chunk and given back by checkWide() behind the stream synchronisation
+// that follows it (or when the batch is reset / destroyed after a failure in between).  A gate, not a std::mutex: it may
+// be released by another thread than the one that took it.
+namespace {
+struct WideGate { std::mutex m; std::condition_variable cv; bool busy = false; };
+WideGate& wide_gate(int device) { static WideGate* g = new WideGate[Pool::kMaxDev]; return g[(device >= 0 && device < Pool::kMaxDev) ? device : 0]; }
+}
+void Batch::wideGateRelease()
+{
+    if (!wideGateHeld_) return;
+    WideGate& g = wide_gate(device_);
+    { std::lock_guard<std::mutex> l(g.m); g.busy = false; }
+    g.cv.notify_one();
+    wideGateHeld_ = false;
+}
+
 int Batch::launchWide(int mode, const PairScanArgs& a0, const PairDesc* hostDescs, size_t n, const WidePlan& plan)
 {
+    if (!wideGateHeld_) {
+        WideGate& g = wide_gate(device_);
+        std::unique_lock<std::mutex> l(g.m);
+        g.cv.wait(l, [&] { return !g.busy; });
+        g.busy = true;
+        wideGateHeld_ = true;
+    }
     for (size_t g0 = 0; g0 < n; g0 += plan.perLaunch) {
         const size_t g1 = std::min(n, g0 + plan.perLaunch);
         const long long words = hostDescs[g1 - 1].auxOff + wide_stream_words(hostDescs[g1 - 1].tlen, plan.slots);
@@ -1405,6 +1433,7 @@ int Batch::launchWide(int mode, const PairScanArgs& a0, const PairDesc* hostDesc
 
 int Batch::checkWide()
 {
+    wideGateRelease();
     if (h_wabort_.p && *reinterpret_cast<const unsigned*>(h_wabort_.p) != 0u) {
         set_error("wide kernel: a strip hand-off timed out (launch aborted)");
         return 1;
@@ -2380,6 +2409,7 @@ int Batch::run()
     haveResults_ = false;
     opsKeep_.clear();            // (the previous run's views die with the reset of their records below)
     knownSplits_.clear();
+    wideGateRelease();           // (a run that failed between a wide launch and its check)
     opsOwned_.clear();
     // TASK_DISTANCE over reads-path units only: nothing is assembled on the host until results() asks for it, so
     // the per-unit records (160 bytes each) are not even allocated in the timed run

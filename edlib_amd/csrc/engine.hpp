@@ -214,7 +214,9 @@ private:
     struct WidePlan { int slots = 1; size_t perLaunch = 1; };
     int planWide(int mode, PairDesc* descs, size_t n, WidePlan& plan);      // slots per unit, units per launch; assigns auxOff
     int launchWide(int mode, const PairScanArgs& a, const PairDesc* hostDescs, size_t n, const WidePlan& plan);
-    int checkWide();                             // after the stream is idle: did a hand-off time out?
+    int checkWide();                             // after the stream is idle: did a hand-off time out?  Releases the device's wide gate.
+    bool wideGateHeld_ = false;                  // this batch holds its device's wide gate (launchWide .. checkWide)
+    void wideGateRelease();
     // NW distance of long units as two half scans that meet in the middle (forward over the left half of the target,
     // reverse over the right half, both inside the band of UnitSpec::kinit): out[4 u ..] = {min, split row, left, right};
     // exact iff min <= kinit

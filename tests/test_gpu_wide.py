@@ -159,3 +159,21 @@ def test_shw_inside_the_band_of_a_threshold(engine, checker):
         _check(engine, checker, hq, ht, "HW", task, -1, "hw starts behind banded reverse scans")
     with _env(EDLIB_AMD_SHWBAND="0"):
         _check(engine, checker, qs[:6], ts[:6], "SHW", "locations", 40, "shw band off")
+
+
+def test_concurrent_callers_take_turns_on_the_wide_kernel(engine, checker):
+    """edlibAlign() on long pairs from several host threads at once: the strip pipelines spin on each other, so two wide
+    launches must never share the device's resident-wave budget (Batch::launchWide: a per-device gate)"""
+    import threading
+    rng = random.Random(9007 + SEED_SHIFT)
+    pairs = [_mut(rng, n, 0.06, 0.03, 0.03) for n in (30000, 42000, 36000, 25000)]
+    want = [checker.align(q, t, "NW", "distance", -1)["editDistance"] for q, t in pairs]
+    got = [[None] * 3 for _ in pairs]
+
+    def work(i):
+        for r in range(3):
+            got[i][r] = engine.align_raw(pairs[i][0], pairs[i][1], "NW", "distance", -1)["editDistance"]
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(pairs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert got == [[w] * 3 for w in want]
