@@ -14,6 +14,9 @@
 #   latency      build/latency for the engine and the reference
 #   short|path|hwlong|wide   tools/bench_short_pairs.py, bench_path.py, bench_hw_long.py, bench_wide.py
 #   soak         tools/soak.py for SOAK_SECONDS (default 120)
+#   chrom        tools/bench_chromosome.py (CHROM_ARGS; the reference's 1 Mb Chromosome pairs, answers against the fixture)
+#   chromtrace   rocprofv3 --kernel-trace --stats of the seven chromosome distance + path calls
+#   chromtraffic rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of one chromosome distance call (99 %)
 #   ab           headline step of this build and of AB_LIB (default build/ab/libedlib_r02.so), alternating, on one box
 #   cmd          run $CMD
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
@@ -70,6 +73,20 @@ for stage in "$@"; do
     path)    timeout 600 python tools/bench_path.py 2>&1 | tee $OUT/${R}_path.json | cut -c1-2000 ;;
     hwlong)  timeout 900 python tools/bench_hw_long.py ${HWLONG_ARGS:-} 2>&1 | tee $OUT/${R}_hw_long.json | cut -c1-2500 ;;
     wide)    timeout 600 python tools/bench_wide.py 2>&1 | tee $OUT/${R}_wide_target.json | cut -c1-1500 ;;
+    chrom)   timeout 600 python tools/bench_chromosome.py ${CHROM_ARGS:---ref} 2>&1 | cut -c1-520 | tee $OUT/${R}_chromosome.json ;;
+    chromtrace)
+      d=$OUT/trace_chrom; rm -rf $d; mkdir -p $d
+      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o t -- python $ROOT/tools/bench_chromosome.py --repeat 1 > $d/out.json 2> $d/err.log )
+      f=$(find $d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${R}_chromosome_kernel_stats.csv && head -8 $f | cut -c1-170
+      f=$(find $d -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $ROOT/tools/prof_summaries.py trace "$f" "$OUT/${R}_chromosome_kernel_trace_edlib.csv"
+      rm -rf $d ;;
+    chromtraffic)
+      for ctr in FETCH_SIZE WRITE_SIZE; do
+        d=$OUT/pmc_chrom_$ctr; rm -rf $d; mkdir -p $d
+        ( cd /tmp && timeout -k 5 300 rocprofv3 --pmc $ctr --output-format csv -d $d -o p -- python $ROOT/tools/bench_chromosome.py --percents 99 --no-path --repeat 1 > $d/out.json 2> $d/err.log )
+        f=$(find $d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python $ROOT/tools/prof_summaries.py pmc "$f" "$OUT/${R}_pmc_chromosome_${ctr}.csv"
+        rm -rf $d
+      done ;;
     soak)    timeout $(( ${SOAK_SECONDS:-120} + 120 )) python tools/soak.py ${SOAK_SECONDS:-120} ${SOAK_SEED:-3} 2>&1 | tail -5 | tee $OUT/${R}_soak.log ;;
     ab)      # the headline step of two builds of the library on THIS box, alternating (AB_LIB: the other build)
              for i in 1 2; do for lib in edlib_amd/libedlib.so ${AB_LIB:-build/ab/libedlib_r02.so}; do
