@@ -402,6 +402,87 @@ count_over_kernel(const int* __restrict__ count, int n, int cap, int* __restrict
     if (i < n && count[i] > cap) atomicAdd(counter, 1);
 }
 
+// flat pair path, NW with the column store: units whose band level failed (score above the level's threshold while a
+// larger one was still allowed)
+__global__ void __launch_bounds__(256)
+count_failed_levels_kernel(const PairDesc* __restrict__ descs, const int* __restrict__ score, int n, int kcap, int* __restrict__ counter)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PairDesc d = descs[i];
+    const int whole = d.qlen > d.tlen ? d.qlen : d.tlen;
+    if (score[i] > d.kinit && d.kinit < whole && d.kinit < kcap) atomicAdd(counter, 1);
+}
+
+// flat pair path, HW start locations (reference edlib.cpp:228-266): every end location e of every unit gets a reverse
+// prefix scan -- reversed query against the reversed prefix target[0..e], threshold = the distance, at most m + distance
+// columns (:253-257).  One thread per unit writes the descriptors of its (at most posCap) scans into slots it takes from
+// a counter; slotOf[u * posCap + j] remembers which scan answers location j.
+__global__ void __launch_bounds__(256)
+flat_start_descs_kernel(const PairDesc* __restrict__ descs, const int* __restrict__ score, const int* __restrict__ count,
+                        const int* __restrict__ pos, int n, int posCap, long long revPeqBase, int ring,
+                        PairDesc* __restrict__ out, int* __restrict__ slotOf, int* __restrict__ counter, int cap)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    const PairDesc d = descs[u];
+    const int ed = score[u];
+    int c = ed < 0 ? 0 : count[u];
+    c = c > posCap ? posCap : c;
+    for (int j = 0; j < posCap; ++j) {
+        int slot = -1;
+        if (j < c) {
+            const int e = pos[(long long)u * posCap + j];
+            slot = atomicAdd(counter, 1);
+            if (slot < cap) {
+                PairDesc x{};
+                x.qoff = d.qoff + d.qlen - 1; x.qstep = -1; x.qlen = d.qlen;
+                x.toff = d.toff + e; x.tstep = -1;
+                const long long win = (long long)e + 1 < (long long)d.qlen + ed ? (long long)e + 1 : (long long)d.qlen + ed;
+                x.tlen = (int)win; x.kinit = ed;
+                x.peqOff = revPeqBase + d.peqOff;
+                x.posCap = 0; x.posOff = 0; x.storeOff = 0; x.auxOff = 0; x.colOff = -1; x.bandT = 0; x.skip = 0; x.ring = ring;
+                out[slot] = x;
+            } else slot = -1;
+        }
+        slotOf[(long long)u * posCap + j] = slot;
+    }
+}
+// start = e - (last position of the reverse scan)   (edlib.cpp:260)
+__global__ void __launch_bounds__(256)
+flat_starts_kernel(const int* __restrict__ slotOf, const int* __restrict__ pos, const int* __restrict__ lastOfScan, long long total,
+                   int* __restrict__ starts)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int s = slotOf[i];
+    starts[i] = s < 0 ? 0 : pos[i] - lastOfScan[s];
+}
+// flat pair path, TASK_PATH of SHW / HW units (edlib.cpp:276-289): NW of the query against target[start0 .. end0] of the
+// FIRST location, with the column store.  A unit without a solution, or whose first location is the empty prefix (-1:
+// the host writes its m inserts), gets an inactive descriptor (threshold below |T - m|).
+__global__ void __launch_bounds__(256)
+flat_path_descs_kernel(const PairDesc* __restrict__ descs, const int* __restrict__ score, const int* __restrict__ count,
+                       const int* __restrict__ pos, const int* __restrict__ starts, int n, int posCap,
+                       const long long* __restrict__ storeBase, int ring, PairDesc* __restrict__ out)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    PairDesc x = descs[u];
+    const int m = x.qlen, ed = score[u];
+    const int nb = (m + 63) >> 6, W = 64 * nb - m;
+    const bool lead = W > 0 && ed == m;                              // position -1 comes first
+    x.posCap = 0; x.posOff = 0; x.ring = ring; x.storeOff = storeBase[u]; x.colOff = -1; x.bandT = 0; x.skip = 0; x.auxOff = 0;
+    if (ed < 0 || count[u] <= 0 || lead) { x.tlen = 1; x.kinit = -1; }
+    else {
+        const int e0 = pos[(long long)u * posCap];
+        const int s0 = starts ? starts[(long long)u * posCap] : 0;
+        x.toff += s0; x.tlen = e0 - s0 + 1;
+        x.kinit = m > x.tlen ? m : x.tlen;                           // every block sits on the ring: the whole matrix
+    }
+    out[u] = x;
+}
+
 // --------------------------------------------------------------- Batch: init
 
 Batch::~Batch() {
@@ -1498,6 +1579,7 @@ int Batch::alphabetLengthsEnd(std::vector<UnitResult>& res)
 // ------------------------------------------------------------ flat pair path
 
 static const int kFlatPosCap = 16;
+static bool needs_hirschberg(int m, int T);       // (edlib.cpp:1188-1190, defined with the Hirschberg levels below)
 
 // Batches of short independent pairs (the verification step of a seed-and-extend mapper: 262,144 x 150 bp in 400 bp
 // windows) were host-bound: every run rebuilt 88-byte descriptors for every unit, uploaded them, downloaded 16 end
@@ -1517,6 +1599,12 @@ PairDesc Batch::flatDesc(int u) const
     // NW: the ring holds every block of the unit, so the band is the whole matrix (threshold max(m, T)); SHW / HW:
     // columns scoring <= min(k, m) are end-location candidates
     x.kinit = scanMode == EDLIB_MODE_NW ? std::max(m, T) : ((cfg_.k < 0 || cfg_.k > m) ? m : cfg_.k);
+    // NW with the column store (flatNwStore_): the first level of solveGlobalDistances -- the ring's band limit for a unit of
+    // more blocks than the ring has lanes, capped by the caller's k; a unit that fails it sends the run to the general path
+    if (flatNwStore_) {
+        const int kcap = cfg_.k >= 0 ? cfg_.k : 0x3fffffff;
+        x.kinit = std::min(kcap, (m + 63) / 64 <= flatRing_ ? std::max(m, T) : ring_max_k(flatRing_));
+    }
     x.peqOff = flatPeqOff_[u];
     x.storeOff = 0; x.auxOff = 0; x.posCap = scanMode == EDLIB_MODE_NW ? 0 : kFlatPosCap; x.posOff = (long long)u * kFlatPosCap;
     x.colOff = -1; x.bandT = 0; x.skip = 0; x.ring = flatRing_;
@@ -1527,15 +1615,32 @@ int Batch::initFlatPairs()
 {
     static const bool on = !(getenv("EDLIB_AMD_FLATPAIRS") && getenv("EDLIB_AMD_FLATPAIRS")[0] == '0');
     flatPairs_ = false;
-    if (!on || cfg_.task != EDLIB_TASK_DISTANCE || !emptyUnits_.empty() || !groups_.empty() || !longUnits_.empty()) return 0;
+    static const bool locOn = !(getenv("EDLIB_AMD_FLATLOC") && getenv("EDLIB_AMD_FLATLOC")[0] == '0');
+    flatStarts_ = flatPaths_ = flatNwStore_ = false;
+    if (!on || !emptyUnits_.empty() || !groups_.empty() || !longUnits_.empty()) return 0;
+    if (cfg_.task != EDLIB_TASK_DISTANCE && !locOn) return 0;
     if ((int)pairUnits_.size() != n_ || n_ < 1024) return 0;       // (a handful of units: the zero-copy path of solveChunk)
     const int mode = (int)cfg_.mode;
+    if (mode != EDLIB_MODE_NW && mode != EDLIB_MODE_SHW && mode != EDLIB_MODE_HW) return 0;
     const int scanMode = (mode == EDLIB_MODE_HW || mode == EDLIB_MODE_SHW) ? mode : EDLIB_MODE_NW;
     int maxBlocks = 0, maxT = 0;
     for (int u = 0; u < n_; ++u) { maxBlocks = std::max(maxBlocks, (qlen(u) + 63) / 64); maxT = std::max(maxT, tlen(u)); }
     // (long targets: the general path cuts HW targets into segments when the batch alone does not fill the chip)
     if (maxBlocks > 16 || maxT > 65536) return 0;
+    flatMaxBlocks_ = maxBlocks;
     flatRing_ = maxBlocks <= 4 ? 4 : 16;
+    // window of a unit's alignment: the whole target (NW), at most 2 m + 1 columns (SHW: the scan stops there; HW: m + distance)
+    auto window = [&](int u) { return scanMode == EDLIB_MODE_NW ? tlen(u) : (int)std::min<long long>(tlen(u), 2LL * qlen(u) + 1); };
+    if (cfg_.task == EDLIB_TASK_PATH) {
+        // paths stay flat when every unit's store fits a 4-lane ring: SHW / HW queries of at most 4 blocks (whole matrix of
+        // the window), NW pairs of up to 16 blocks inside the first band level; never in the Hirschberg regime (:1188-1190)
+        if (scanMode != EDLIB_MODE_NW && maxBlocks > 4) return 0;
+        for (int u = 0; u < n_; ++u) if (needs_hirschberg(qlen(u), window(u))) return 0;
+        flatPaths_ = true;
+        flatNwStore_ = scanMode == EDLIB_MODE_NW;
+        flatRing_ = 4;
+    }
+    flatStarts_ = cfg_.task != EDLIB_TASK_DISTANCE && mode == EDLIB_MODE_HW;
     PinBuf pin;
     EDLIB_AMD_HIP(pin.alloc((size_t)n_ * sizeof(PairDesc)));
     PairDesc* d = reinterpret_cast<PairDesc*>(pin.p);
@@ -1551,8 +1656,51 @@ int Batch::initFlatPairs()
     EDLIB_AMD_HIP(d_peq64_.ensure((size_t)peqWords));
     EDLIB_AMD_HIP(d_flatOut3_.alloc(3 * (size_t)n_));
     EDLIB_AMD_HIP(d_flatPos_.alloc(scanMode == EDLIB_MODE_NW ? 1 : (size_t)n_ * kFlatPosCap));
-    EDLIB_AMD_HIP(d_flatCensus_.alloc(1));
-    EDLIB_AMD_HIP(h_flatCensus_.alloc(sizeof(int)));
+    EDLIB_AMD_HIP(d_flatCensus_.alloc(2));
+    EDLIB_AMD_HIP(h_flatCensus_.alloc(2 * sizeof(int)));
+    if (flatStarts_) {
+        // reversed-query Peq rows (same layout as the forward ones, behind them) and their builder's descriptors
+        flatRevPeqBase_ = peqWords;
+        EDLIB_AMD_HIP(d_peq64_.ensure((size_t)(2 * peqWords)));
+        PinBuf rp;
+        EDLIB_AMD_HIP(rp.alloc((size_t)n_ * sizeof(PairDesc)));
+        PairDesc* r = reinterpret_cast<PairDesc*>(rp.p);
+        for (int u = 0; u < n_; ++u) { r[u] = d[u]; r[u].qoff = d[u].qoff + d[u].qlen - 1; r[u].qstep = -1; r[u].peqOff = flatRevPeqBase_ + d[u].peqOff; }
+        EDLIB_AMD_HIP(d_flatRevDescs_.alloc((size_t)n_));
+        EDLIB_AMD_HIP(hipMemcpyAsync(d_flatRevDescs_.p, r, (size_t)n_ * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
+        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+        flatStartCap_ = 2 * (size_t)n_ + 1024;
+        EDLIB_AMD_HIP(d_flatStartDescs_.alloc(flatStartCap_));
+        EDLIB_AMD_HIP(d_flatStartOut3_.alloc(3 * flatStartCap_));
+        EDLIB_AMD_HIP(d_flatSlotOf_.alloc((size_t)n_ * kFlatPosCap));
+        EDLIB_AMD_HIP(d_flatStartsOut_.alloc((size_t)n_ * kFlatPosCap));
+    }
+    if (flatPaths_) {
+        // op slots (m + window + 8 bytes per unit, filled from the back) and store ranges (a 4-lane ring over the window):
+        // upper bounds that depend on the batch only, laid out once
+        flatOpsOffHost_.assign((size_t)n_ + 1, 0);
+        std::vector<long long> storeBase((size_t)n_);
+        long long entries = 0;
+        for (int u = 0; u < n_; ++u) {
+            flatOpsOffHost_[u + 1] = flatOpsOffHost_[u] + qlen(u) + window(u) + 8;
+            storeBase[u] = entries; entries += ring_store_entries(flatRing_, qlen(u), window(u));
+        }
+        flatOpsTotal_ = flatOpsOffHost_[n_];
+        EDLIB_AMD_HIP(d_flatOpsOff_.alloc((size_t)n_ + 1)); EDLIB_AMD_HIP(d_flatStoreBase_.alloc((size_t)n_));
+        EDLIB_AMD_HIP(hipMemcpyAsync(d_flatOpsOff_.p, flatOpsOffHost_.data(), ((size_t)n_ + 1) * sizeof(long long), hipMemcpyHostToDevice, stream_));
+        EDLIB_AMD_HIP(hipMemcpyAsync(d_flatStoreBase_.p, storeBase.data(), (size_t)n_ * sizeof(long long), hipMemcpyHostToDevice, stream_));
+        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+        EDLIB_AMD_HIP(d_flatOps_.alloc((size_t)flatOpsTotal_)); EDLIB_AMD_HIP(d_flatOpsLen_.alloc((size_t)n_));
+        EDLIB_AMD_HIP(d_store_.ensure((size_t)entries));
+        if (flatNwStore_) {
+            // the phase-1 descriptors ARE the storing scans: give them their store ranges
+            for (int u = 0; u < n_; ++u) d[u].storeOff = storeBase[u];
+            EDLIB_AMD_HIP(hipMemcpyAsync(d_flatDescs_.p, d, (size_t)n_ * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
+            EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+        } else {
+            EDLIB_AMD_HIP(d_flatPathDescs_.alloc((size_t)n_)); EDLIB_AMD_HIP(d_flatPathOut3_.alloc(3 * (size_t)n_));
+        }
+    }
     // the word-steps of a run over the resident descriptors never change: counted here, once
     {
         unsigned long long* ctr = ringStepsCounter();
@@ -1568,8 +1716,9 @@ int Batch::initFlatPairs()
     return 0;
 }
 
-int Batch::runPairsFlat(bool& overflowed)
+int Batch::runPairsFlat(bool& overflowed, bool& fellBack)
 {
+    fellBack = false;
     const int mode = (int)cfg_.mode;
     const int scanMode = (mode == EDLIB_MODE_HW || mode == EDLIB_MODE_SHW) ? mode : EDLIB_MODE_NW;
     stats.path |= 2;
@@ -1578,16 +1727,30 @@ int Batch::runPairsFlat(bool& overflowed)
     PairScanArgs a{};
     a.descs = d_flatDescs_.p; a.numUnits = n_; a.qpool = d_qpool_.p; a.tpool = d_tpool_.p;
     a.tlut = d_tlut_.p; a.sigmaT = tab_.sigmaT; a.peq = d_peq64_.p; a.aux = nullptr;
-    a.peqRowStride = peq_row_stride(flatRing_);
+    a.peqRowStride = peq_row_stride(std::max(flatRing_, flatMaxBlocks_));
     a.peqFullStride = (int)std::min<long long>((long long)a.peqRowStride * tab_.sigmaT, 1 << 20);
-    a.store = nullptr;
+    a.store = flatNwStore_ ? d_store_.p : nullptr;
     a.outScore = d_flatOut3_.p; a.outCount = d_flatOut3_.p + n_; a.outLast = d_flatOut3_.p + 2 * (size_t)n_; a.posPool = d_flatPos_.p;
     a.wordSteps = nullptr;
     stats.word_steps += flatWordSteps_;
     scanTimerStart();
-    EDLIB_AMD_HIP(launch_scan_pairs_ring(flatRing_, scanMode, false, a, stream_));
+    EDLIB_AMD_HIP(launch_scan_pairs_ring(flatRing_, scanMode, flatNwStore_, a, stream_));
     scanTimerStop();
     overflowed = false;
+    if (flatNwStore_) {
+        // NW paths: the distance scan was the storing scan (one band level); walk it, and see whether every unit got its answer
+        TracebackArgs tb{};
+        tb.descs = d_flatDescs_.p; tb.numUnits = n_; tb.score = d_flatOut3_.p; tb.store = d_store_.p;
+        tb.ops = d_flatOps_.p; tb.opsOff = d_flatOpsOff_.p; tb.opsLen = d_flatOpsLen_.p;
+        EDLIB_AMD_HIP(launch_traceback(tb, stream_));
+        EDLIB_AMD_HIP(hipMemsetAsync(d_flatCensus_.p, 0, 2 * sizeof(int), stream_));
+        hipLaunchKernelGGL(count_failed_levels_kernel, dim3((n_ + 255) / 256), dim3(256), 0, stream_, d_flatDescs_.p, d_flatOut3_.p, n_,
+                           cfg_.k >= 0 ? cfg_.k : 0x3fffffff, d_flatCensus_.p);
+        EDLIB_AMD_HIP(hipMemcpyAsync(h_flatCensus_.p, d_flatCensus_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
+        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+        if (*reinterpret_cast<const int*>(h_flatCensus_.p) > 0) { fellBack = true; return 0; }     // some unit needs the next level: the general path has them
+        return 0;
+    }
     if (scanMode != EDLIB_MODE_NW) {
         EDLIB_AMD_HIP(hipMemsetAsync(d_flatCensus_.p, 0, sizeof(int), stream_));
         hipLaunchKernelGGL(count_over_kernel, dim3((n_ + 255) / 256), dim3(256), 0, stream_, d_flatOut3_.p + n_, n_, kFlatPosCap, d_flatCensus_.p);
@@ -1626,6 +1789,59 @@ int Batch::runPairsFlat(bool& overflowed)
             for (const PairDesc& x : d2) stats.word_steps += 2LL * ((x.qlen + 63) / 64) * x.tlen;
         }
     }
+    if (flatStarts_ || flatPaths_) return runFlatStartsAndPaths(fellBack);
+    return 0;
+}
+
+// Phases 2 and 3 of a flat SHW / HW batch (reference edlib.cpp:228-289), everything on the device: descriptors of the
+// reverse prefix scans written by a kernel from the phase-1 results (HW), one ring scan over them, the starts; then one
+// storing NW scan per unit over its first location's window + the traceback into the resident op slots.
+int Batch::runFlatStartsAndPaths(bool& fellBack)
+{
+    const int mode = (int)cfg_.mode;
+    const int* score = d_flatOut3_.p; const int* count = d_flatOut3_.p + n_;
+    PairScanArgs a{};
+    a.qpool = d_qpool_.p; a.tpool = d_tpool_.p; a.tlut = d_tlut_.p; a.sigmaT = tab_.sigmaT; a.peq = d_peq64_.p; a.aux = nullptr;
+    a.peqRowStride = peq_row_stride(std::max(flatRing_, flatMaxBlocks_));
+    a.peqFullStride = (int)std::min<long long>((long long)a.peqRowStride * tab_.sigmaT, 1 << 20);
+    a.posPool = d_flatPos_.p; a.wordSteps = nullptr;
+    if (flatStarts_) {
+        EDLIB_AMD_HIP(hipMemsetAsync(d_flatCensus_.p, 0, 2 * sizeof(int), stream_));
+        hipLaunchKernelGGL(flat_start_descs_kernel, dim3((n_ + 255) / 256), dim3(256), 0, stream_, d_flatDescs_.p, score, count, d_flatPos_.p,
+                           n_, kFlatPosCap, flatRevPeqBase_, flatRing_, d_flatStartDescs_.p, d_flatSlotOf_.p, d_flatCensus_.p, (int)flatStartCap_);
+        EDLIB_AMD_HIP(hipMemcpyAsync(h_flatCensus_.p, d_flatCensus_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
+        // (the reversed queries' Peq rows do not depend on the count: built while it travels)
+        EDLIB_AMD_HIP(launch_build_peq_pairs(d_flatRevDescs_.p, n_, d_qpool_.p, d_eq8_.p, d_idToByte_.p, tab_.sigmaT, d_peq64_.p, stream_));
+        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+        const int nscan = *reinterpret_cast<const int*>(h_flatCensus_.p);
+        if ((size_t)nscan > flatStartCap_) { fellBack = true; return 0; }
+        if (nscan > 0) {
+            PairScanArgs b = a;
+            b.descs = d_flatStartDescs_.p; b.numUnits = nscan; b.store = nullptr;
+            b.outScore = d_flatStartOut3_.p; b.outCount = d_flatStartOut3_.p + flatStartCap_; b.outLast = d_flatStartOut3_.p + 2 * flatStartCap_;
+            scanTimerStart();
+            EDLIB_AMD_HIP(launch_scan_pairs_ring(flatRing_, EDLIB_MODE_SHW, false, b, stream_));
+            scanTimerStop();
+        }
+        const long long total = (long long)n_ * kFlatPosCap;
+        hipLaunchKernelGGL(flat_starts_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, d_flatSlotOf_.p, d_flatPos_.p,
+                           d_flatStartOut3_.p + 2 * flatStartCap_, total, d_flatStartsOut_.p);
+        EDLIB_AMD_HIP(hipGetLastError());
+    }
+    if (flatPaths_ && !flatNwStore_) {
+        hipLaunchKernelGGL(flat_path_descs_kernel, dim3((n_ + 255) / 256), dim3(256), 0, stream_, d_flatDescs_.p, score, count, d_flatPos_.p,
+                           mode == EDLIB_MODE_HW ? d_flatStartsOut_.p : nullptr, n_, kFlatPosCap, d_flatStoreBase_.p, flatRing_, d_flatPathDescs_.p);
+        PairScanArgs b = a;
+        b.descs = d_flatPathDescs_.p; b.numUnits = n_; b.store = d_store_.p;
+        b.outScore = d_flatPathOut3_.p; b.outCount = d_flatPathOut3_.p + n_; b.outLast = d_flatPathOut3_.p + 2 * (size_t)n_;
+        scanTimerStart();
+        EDLIB_AMD_HIP(launch_scan_pairs_ring(flatRing_, EDLIB_MODE_NW, true, b, stream_));
+        scanTimerStop();
+        TracebackArgs tb{};
+        tb.descs = d_flatPathDescs_.p; tb.numUnits = n_; tb.score = d_flatPathOut3_.p; tb.store = d_store_.p;
+        tb.ops = d_flatOps_.p; tb.opsOff = d_flatOpsOff_.p; tb.opsLen = d_flatOpsLen_.p;
+        EDLIB_AMD_HIP(launch_traceback(tb, stream_));
+    }
     return 0;
 }
 
@@ -1641,6 +1857,25 @@ int Batch::collectPairsFlat(std::vector<UnitResult>& res)
     if (npos) EDLIB_AMD_HIP(hipMemcpyAsync(h + 3 * n, d_flatPos_.p, npos * sizeof(int), hipMemcpyDeviceToHost, stream_));
     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
     const int* score = h; const int* count = h + n; const int* pos = h + 3 * n;
+    // start locations / op strings of a flat LOC / PATH batch: downloaded now, into staging the records may point into
+    const bool wantStarts = cfg_.task != EDLIB_TASK_DISTANCE;
+    const int* starts = nullptr; const int* opsLen = nullptr; const uint8_t* ops = nullptr;
+    PinBuf stageStarts;
+    if (flatStarts_) {
+        EDLIB_AMD_HIP(stageStarts.alloc(n * kFlatPosCap * sizeof(int)));
+        EDLIB_AMD_HIP(hipMemcpyAsync(stageStarts.p, d_flatStartsOut_.p, n * kFlatPosCap * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        starts = reinterpret_cast<const int*>(stageStarts.p);
+    }
+    if (flatPaths_) {
+        auto blk = std::make_shared<PinBuf>();
+        EDLIB_AMD_HIP(blk->alloc((size_t)flatOpsTotal_ + n * sizeof(int)));
+        EDLIB_AMD_HIP(hipMemcpyAsync(blk->p, d_flatOpsLen_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        EDLIB_AMD_HIP(hipMemcpyAsync(blk->p + n * sizeof(int), d_flatOps_.p, (size_t)flatOpsTotal_, hipMemcpyDeviceToHost, stream_));
+        opsLen = reinterpret_cast<const int*>(blk->p); ops = blk->p + n * sizeof(int);
+        opsKeep_.push_back(blk);
+    }
+    if (flatStarts_ || flatPaths_) EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+    std::vector<UnitSpec> lateUnits; std::vector<std::pair<int, int>> lateWhere;
     size_t oi = 0;
     for (size_t u = 0; u < n; ++u) {
         UnitResult& r = res[u];
@@ -1650,6 +1885,41 @@ int Batch::collectPairsFlat(std::vector<UnitResult>& res)
             finalize_semiglobal(r, cfg_.k, qlen((int)u), score[u], flatOvfPos_.data() + flatOvfOff_[oi], flatOvfOff_[oi + 1] - flatOvfOff_[oi]);
             ++oi;
         } else finalize_semiglobal(r, cfg_.k, qlen((int)u), score[u], pos + u * kFlatPosCap, score[u] < 0 ? 0 : std::max(count[u], 0));
+        if (!wantStarts || r.editDistance < 0 || !r.hasEnds) continue;
+        // start locations (edlib.cpp:228-272): 0 for NW / SHW and for the empty prefix (-1); HW: what the reverse scans found.
+        // (finalize_semiglobal puts the -1 location, when there is one, in front of the kernel's list)
+        r.hasStarts = true;
+        r.starts.assign(r.ends.size(), 0);
+        if (starts) {
+            const size_t lead = (!r.ends.empty() && r.ends[0] == -1) ? 1 : 0;
+            for (size_t j = lead; j < r.ends.size(); ++j) {
+                if (j - lead < (size_t)kFlatPosCap) r.starts[j] = starts[u * kFlatPosCap + (j - lead)];
+                else {
+                    // beyond the 16 locations the flat layout keeps (a unit of the exact second pass): its reverse scan runs now
+                    const int m = qlen((int)u), e = r.ends[j];
+                    const long long win = std::min<long long>((long long)e + 1, (long long)m + r.editDistance);
+                    lateUnits.push_back(UnitSpec{qoff_[u] + m - 1, m, -1, tbase((int)u) + e, (int)win, -1, r.editDistance});
+                    lateWhere.push_back({(int)u, (int)j});
+                }
+            }
+        }
+        if (cfg_.task != EDLIB_TASK_PATH || r.ends.empty()) continue;
+        // the path of the first location (:276-289); an empty window is all inserts (:1168-1175)
+        r.hasAlignment = true;
+        if (r.ends[0] - r.starts[0] + 1 <= 0) {
+            opsOwned_.emplace_back((size_t)qlen((int)u), (uint8_t)EDLIB_EDOP_INSERT);
+            r.opsView = opsOwned_.back().data(); r.opsViewLen = (int)opsOwned_.back().size();
+        } else {
+            r.opsView = ops + flatOpsOffHost_[u + 1] - opsLen[u]; r.opsViewLen = opsLen[u];
+        }
+    }
+    if (!lateUnits.empty()) {
+        SolveOut so;
+        if (solveSemiGlobal(EDLIB_MODE_SHW, false, lateUnits, so)) return 1;
+        for (size_t i = 0; i < lateUnits.size(); ++i) {
+            UnitResult& r = res[(size_t)lateWhere[i].first];
+            r.starts[(size_t)lateWhere[i].second] = r.ends[(size_t)lateWhere[i].second] - so.last[i];     // (edlib.cpp:260)
+        }
     }
     if (alphabetLengthsEnd(res)) return 1;
     pairsCollected_ = true;
@@ -2445,10 +2715,15 @@ int Batch::run()
     }
     if (alphabetLengthsBegin()) return 1;
     bool flatDone = false;
-    if (flatPairs_) {                                   // ---- phase 1 of a flat pair batch: everything stays on the device
-        bool over = false;
-        if (runPairsFlat(over)) return 1;
-        flatDone = true; pairsCollected_ = false;
+    if (flatPairs_) {                                   // ---- a flat pair batch: everything stays on the device
+        bool over = false, fell = false;
+        if (runPairsFlat(over, fell)) return 1;
+        if (fell) {
+            // something the flat layouts do not hold (more than 16 end locations with starts / paths asked for, a band
+            // level that failed): this run takes the general path from the start
+            res.resize((size_t)n_);
+            for (size_t u = 0; u < res.size(); ++u) blank_record(res[u]);
+        } else { flatDone = true; pairsCollected_ = false; }
         lap("run: flat pairs");
     }
     // ---- phase 1: distance + end locations
@@ -2555,12 +2830,14 @@ int Batch::run()
     lap("run: phase 1 (distance)");
     std::vector<int>& live = live_;            // non-empty units with a solution (only the later phases want them)
     live.clear();
-    if (cfg_.task == EDLIB_TASK_LOC || cfg_.task == EDLIB_TASK_PATH)
+    // (a flat batch has done its phases 2 and 3 on the device: its records do not exist yet)
+    const bool laterPhases = !flatDone && (cfg_.task == EDLIB_TASK_LOC || cfg_.task == EDLIB_TASK_PATH);
+    if (laterPhases)
         for (int u = 0; u < n_; ++u)
             if (qlen(u) > 0 && tlen(u) > 0 && res[u].editDistance >= 0) live.push_back(u);
 
     // ---- phase 2: start locations (edlib.cpp:228-272)
-    if (cfg_.task == EDLIB_TASK_LOC || cfg_.task == EDLIB_TASK_PATH) {
+    if (laterPhases) {
         std::vector<UnitSpec>& units = startUnits_; std::vector<std::pair<int, int>>& where = startWhere_;   // capacity kept across runs
         units.clear(); where.clear();
         units.reserve(live.size() + live.size() / 8); where.reserve(live.size() + live.size() / 8);

@@ -280,7 +280,21 @@ private:
     std::vector<int> flatOvfUnit_; std::vector<long long> flatOvfOff_; std::vector<int> flatOvfPos_;   // exact lists of the last run's overflowing units
     PairDesc flatDesc(int u) const;
     int initFlatPairs();
-    int runPairsFlat(bool& overflowed);
+    int runPairsFlat(bool& overflowed, bool& fellBack);
+    // flat LOC / PATH (round 4): start locations and paths of a flat batch are found and kept on the device as well.
+    // HW starts: one reverse prefix scan per end location, descriptors written by a kernel from the phase-1 results;
+    // paths: one storing scan per unit over its window + the traceback into resident op slots.  What the fixed layouts
+    // cannot hold (more than 16 end locations, a band level that fails) makes the run fall back to the general path.
+    bool flatStarts_ = false, flatPaths_ = false, flatNwStore_ = false;
+    int flatMaxBlocks_ = 0;
+    size_t flatStartCap_ = 0;
+    long long flatRevPeqBase_ = 0, flatOpsTotal_ = 0;
+    DevBuf<PairDesc> d_flatRevDescs_, d_flatStartDescs_, d_flatPathDescs_;
+    DevBuf<int> d_flatSlotOf_, d_flatStartOut3_, d_flatStartsOut_, d_flatPathOut3_, d_flatOpsLen_;
+    DevBuf<long long> d_flatOpsOff_, d_flatStoreBase_;
+    DevBuf<uint8_t> d_flatOps_;
+    std::vector<long long> flatOpsOffHost_;
+    int runFlatStartsAndPaths(bool& fellBack);
     int collectPairsFlat(std::vector<UnitResult>& res);
     int ensureCollected();                       // results of the last run that are still on the device -> results_
 };

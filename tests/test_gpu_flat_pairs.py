@@ -70,3 +70,77 @@ def test_wide_alphabet_pairs(engine):
         q[::13] = 201
     _check(engine, qs, ts, "HW")
     _check(engine, qs, ts, "NW")
+
+
+# ---------------------------------------------------------------- start locations and paths stay flat too (round 4)
+
+_ALL = ("status", "editDistance", "numLocations", "alphabetLength", "locOff", "ends", "starts", "alnOff", "alignment")
+
+
+def _check_task(engine, qs, ts, mode, task, k=-1, what=""):
+    b = engine.PairBatch(qs, ts, mode=mode, task=task, k=k)
+    try:
+        b.run(); b.run()
+        got = b.results_flat()
+        again = b.results_flat()
+    finally:
+        b.close()
+    qoff = np.zeros(len(qs) + 1, dtype=np.int64); qoff[1:] = np.cumsum([len(q) for q in qs])
+    toff = np.zeros(len(ts) + 1, dtype=np.int64); toff[1:] = np.cumsum([len(t) for t in ts])
+    ref = O.pool_align(np.concatenate(qs), qoff, np.concatenate(ts), toff, False, mode, task, k)
+    z = np.zeros(0, dtype=np.int32)
+    for res_, tag in ((got, "first collection"), (again, "second collection")):
+        for f in _ALL:
+            a = res_[f] if res_[f] is not None else z
+            r = ref[f] if ref[f] is not None else z
+            assert np.array_equal(a, r), (mode, task, k, f, what, tag)
+
+
+def _window_pairs(n, seed, m, win, sub=0.03, indel=0.01):
+    """reads of m bases inside their own window (the verification step of a seed-and-extend mapper)"""
+    rng = np.random.default_rng(seed)
+    qs, ts = [], []
+    for i in range(n):
+        t = _ACGT[rng.integers(0, 4, win)]
+        a = int(rng.integers(0, win - m + 1))
+        q, _ = synth.mutate(t[a:a + m], int(rng.integers(1 << 30)), sub, indel, indel)
+        if i % 97 == 0:
+            q = _ACGT[rng.integers(0, 4, m)]                      # unrelated
+        qs.append(np.ascontiguousarray(q)); ts.append(t)
+    return qs, ts
+
+
+@pytest.mark.parametrize("mode", ["HW", "SHW", "NW"])
+@pytest.mark.parametrize("task", ["locations", "path"])
+def test_flat_locations_and_paths(engine, mode, task):
+    qs, ts = _window_pairs(2500, 21, 150, 400)
+    _check_task(engine, qs, ts, mode, task, what="150 in 400")
+    _check_task(engine, qs[:1200], ts[:1200], mode, task, k=4, what="fixed k")
+    qs, ts = _pairs(2000, 31, 256)                                 # every length edge, T < m, T = 1
+    _check_task(engine, qs, ts, mode, task, what="mixed lengths")
+
+
+def test_flat_nw_paths_of_one_kb_pairs(engine):
+    """BASELINE config 5's shape (1 kb NW pairs, PATH): the distance scan inside the first band level is the storing scan"""
+    qs, ts = synth.mutated_pairs(1500, 1000, seed=44, sub=0.03, ins=0.01, dele=0.01)
+    _check_task(engine, list(qs), list(ts), "NW", "path", what="config 5 shape")
+    # a divergent unit among them fails the level: the run falls back to the general path, same answers
+    qs = list(qs); ts = list(ts)
+    qs[17] = synth.random_dna(5, 1000)
+    _check_task(engine, qs, ts, "NW", "path", what="one divergent unit")
+
+
+def test_flat_batches_fall_back_when_lists_overflow(engine):
+    qs, ts = _pairs(2000, 5, 200, repeats=True)                    # unit 7: 59 end locations
+    for mode in ("HW", "SHW"):
+        for task in ("locations", "path"):
+            _check_task(engine, qs, ts, mode, task, what="overflowing list")
+
+
+def test_flat_paths_with_the_empty_prefix_first(engine):
+    """a query that matches nothing: distance m, first location -1 (when 64 does not divide m), the path is m inserts"""
+    rng = np.random.default_rng(9)
+    qs = [np.frombuffer(b"A" * int(rng.choice([10, 63, 64, 65, 100])), dtype=np.uint8) for _ in range(1200)]
+    ts = [np.frombuffer(b"C" * int(rng.choice([1, 30, 200])), dtype=np.uint8) for _ in range(1200)]
+    for mode in ("HW", "SHW"):
+        _check_task(engine, qs, ts, mode, "path", what="all mismatching")
