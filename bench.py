@@ -378,6 +378,14 @@ def measure_chromosome(repeat=2):
             "bit_exact": sum(1 for r in pairs if r["bit_exact"]), "checked": len(pairs)}
 
 
+def collection_note(collect_ms, ms_per_step):
+    """A step (`Batch.run()`) ends with the results resident in HBM; bringing them to the host (download, per-unit records,
+    flat arrays) happens in `results_flat()`, once per call whatever the number of steps.  Reported beside the step so that
+    the lazily collected paths (reads path, flat pair batches incl. their op strings) do not hide that work."""
+    return {"results_flat_ms": round(collect_ms, 3), "ms_per_step_plus_one_collection": round(ms_per_step + collect_ms, 3),
+            "what": "results_flat() after the timed steps: D2H of what run() left in HBM + per-unit records + flat arrays"}
+
+
 def measure_secondary(cfg_id, device, torch, steps=5, warmup=2):
     """One more BASELINE config on this rank's device: resident batch, `warmup` + `steps` timed steps between two
     device synchronisations, then the reference over the WHOLE batch (parity of every field + the CPU baseline)."""
@@ -394,8 +402,11 @@ def measure_secondary(cfg_id, device, torch, steps=5, warmup=2):
             scan_ms += st["scan_ms"]; launches += st["scan_launches"]
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        tc = time.perf_counter()
         flat = batch.results_flat()
+        collect_ms = (time.perf_counter() - tc) * 1e3
         out = report(cfg_id, w, st, scan_ms, launches, steps, warmup, dt, st["cells"] * steps / dt / 1e9, 1, "weak")
+        out["collection"] = collection_note(collect_ms, out["ms_per_step"])
         out["cpu_baseline"], out["parity_sample"] = cpu_baseline_and_parity(w, flat, w["n"])
     finally:
         batch.close()
@@ -494,8 +505,11 @@ def main():
         per_rank_ms = [x[0] for x in tl]
         devices = [x[1] for x in tl]
     flat = None
+    collect_ms = None
     if args.dump or (rank == 0 and world == 1 and not args.no_cpu_baseline):
+        tc = time.perf_counter()
         flat = batch.results_flat()
+        collect_ms = (time.perf_counter() - tc) * 1e3
     if args.dump:
         total = units if args.strong else units * world
         full = gather_int_results(flat["editDistance"], total, dist, coll_dev)    # shard order = rank order
@@ -506,6 +520,8 @@ def main():
     if rank == 0:
         out = report(args.config, w, st, scan_ms, launches, max(1, args.steps), args.warmup, dt, value, world,
                      "strong" if args.strong else "weak")
+        if collect_ms is not None:
+            out["collection"] = collection_note(collect_ms, out["ms_per_step"])
         out["per_rank_ms_per_step"] = per_rank_ms
         out["devices"] = devices
         out["devices_distinct"] = len(set(devices))
