@@ -663,7 +663,8 @@ int Batch::makeGroup(const std::vector<int>& units, int w, std::unique_ptr<ReadG
     }
     const size_t ns = (size_t)g->nslots, S = (size_t)g->numSegments;
     EDLIB_AMD_HIP(g->d_perm.alloc(ns));
-    EDLIB_AMD_HIP(hipMemcpy(g->d_perm.p, g->perm.data(), ns * sizeof(int), hipMemcpyHostToDevice));
+    // (on the batch's own stream: nothing of this library runs on the null stream; perm lives as long as the group)
+    EDLIB_AMD_HIP(hipMemcpyAsync(g->d_perm.p, g->perm.data(), ns * sizeof(int), hipMemcpyHostToDevice, stream_));
     EDLIB_AMD_HIP(g->d_qlen.alloc(ns)); EDLIB_AMD_HIP(g->d_kinit.alloc(ns));
     // Small groups (a call of edlibAlign() is one slot block): the merged per-slot results live in device-visible
     // pinned host memory -- the merge / Peq / census kernels write them there, nothing is downloaded, and the
