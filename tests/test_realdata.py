@@ -163,3 +163,34 @@ def test_gpu_chromosome_pairs_as_one_batch(engine):
     got = engine.align_pairs(qs, [chromosome()] * len(qs), mode="NW", task="distance", raw=True)
     assert [g["editDistance"] for g in got] == [c["editDistance"] for c in EXP["chromosome"]]
     assert all(g["endLocations"] == [999999] for g in got)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exe_name", ["build/edlib-aligner-batch", "oracle/_ref/aligner_amd"])
+def test_gpu_cli_on_a_chromosome_pair(exe_name, tmp_path):
+    """`edlib-aligner -m NW -l` and `-p -f CIG_EXT` on the 99 % Chromosome pair (the command line of
+    test_data/perf_tests.sh:180-191), through the batch CLI and through the reference's unmodified CLI linked to this library"""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, exe_name)
+    if not os.path.exists(exe):
+        pytest.skip("%s was not built" % exe_name)
+    case = EXP["chromosome"][0]
+    paths = []
+    for name in (case["query"], case["target"]):
+        p = str(tmp_path / name[:-3])
+        with open(p, "wb") as f:
+            f.write(b">" + name.encode() + b"\n")
+            seq = read_fasta(os.path.join(REAL, "chromosome", name))
+            for i in range(0, len(seq), 60):
+                f.write(seq[i:i + 60] + b"\n")
+        paths.append(p)
+    out = subprocess.run([exe, "-m", "NW", "-l"] + paths, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-500:] + out.stderr[-500:]
+    m = re.search(r"^#0: (-?\d+)\s+(\d+)\s+\[ \((\d+), (\d+)\) \]", out.stdout, re.M)
+    assert m and (int(m.group(1)), int(m.group(3)), int(m.group(4))) == (case["editDistance"], 0, 999999), out.stdout[-500:]
+    out = subprocess.run([exe, "-m", "NW", "-p", "-f", "CIG_EXT"] + paths, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-500:] + out.stderr[-500:]
+    m = re.search(r"^Cigar:\n(.*)$", out.stdout, re.M)
+    assert m and len(m.group(1)) == case["cigar_ext_len"]
+    assert md5((m.group(1) + "\n").encode()) == case["cigar_ext_md5"]
