@@ -1637,6 +1637,14 @@ int Batch::initFlatPairs()
         // the window), NW pairs of up to 16 blocks inside the first band level; never in the Hirschberg regime (:1188-1190)
         if (scanMode != EDLIB_MODE_NW && maxBlocks > 4) return 0;
         for (int u = 0; u < n_; ++u) if (needs_hirschberg(qlen(u), window(u))) return 0;
+        // (the resident column store and op slots are upper bounds per unit: a batch whose bounds add up to more than a
+        // slice of the HBM keeps the general path, which sizes them per chunk)
+        long long storeBytes = 0, opBytes = 0;
+        for (int u = 0; u < n_; ++u) {
+            storeBytes += 16LL * ring_store_entries(4, qlen(u), window(u));
+            opBytes += qlen(u) + window(u) + 8;
+        }
+        if (storeBytes > (32LL << 30) || opBytes > (8LL << 30)) return 0;
         flatPaths_ = true;
         flatNwStore_ = scanMode == EDLIB_MODE_NW;
         flatRing_ = 4;
