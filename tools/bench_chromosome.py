@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--no-path", action="store_true")
     ap.add_argument("--ref", action="store_true", help="also time the compiled reference on this box (one core)")
     ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--batch", action="store_true", help="also: all selected pairs as ONE resident pair batch (distance, path)")
     a = ap.parse_args()
     want = [int(x) for x in a.percents.split(",")]
     t = chromosome()
@@ -74,6 +75,17 @@ def main():
             if not a.no_path and c["percent"] >= 90:
                 t0 = time.perf_counter(); ref.align(q, t, "NW", "path", -1); line["reference_s_here"]["path"] = round(time.perf_counter() - t0, 3)
         print(json.dumps(line), flush=True)
+    if a.batch:
+        sel = [c for c in EXP["chromosome"] if c["percent"] in want]
+        qs = [read_fasta(os.path.join(REAL, "chromosome", c["query"])) for c in sel]
+        for task in (("distance",) if a.no_path else ("distance", "path")):
+            b = edlib_amd.PairBatch(qs, [t] * len(qs), mode="NW", task=task)
+            b.run(); st = b.run()
+            res = b.results(raw=True)
+            b.close()
+            ok = all(r["editDistance"] == c["editDistance"] and (task == "distance" or md5(r["alignment"]) == c["ops_md5"]) for r, c in zip(res, sel))
+            print(json.dumps({"batch_of": len(sel), "task": task, "run_ms": round(st["run_ms"], 2), "scan_ms": round(st["scan_ms"], 2),
+                              "gcups": round(st["cells"] / st["run_ms"] / 1e6, 1), "ok": bool(ok)}), flush=True)
 
 
 if __name__ == "__main__":
