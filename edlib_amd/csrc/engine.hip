@@ -636,7 +636,10 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
 }
 
 // One reads-per-lane group: the units of one word count, padded to whole waves, with its resident buffers.
-int Batch::makeGroup(const std::vector<int>& units, int w, std::unique_ptr<ReadGroup>& g)
+// oneRoundWaves > 0: the group runs on a kernel of which the chip holds that many waves without two sharing a SIMD (the
+// full-height kernels of 24 / 32 words: 24 / 32 KB of LDS rows per wave) -- one launch of at most that many waves, segments as
+// long as that allows (long_reads.hip, solveTallFull: the 1025th wave costs a third of the rate, every warm-up is work)
+int Batch::makeGroup(const std::vector<int>& units, int w, std::unique_ptr<ReadGroup>& g, long long oneRoundWaves)
 {
     const int mode = (int)cfg_.mode;
     const int T = shared_ ? tlen(0) : 0;
@@ -656,6 +659,7 @@ int Batch::makeGroup(const std::vector<int>& units, int w, std::unique_ptr<ReadG
         // over 1535 / 2047 columns: 4096-column segments were half warm-up)
         const long long maxS = std::max<long long>(1, std::min<long long>(std::min(65535, std::max(1, T / 4096)), T / (4LL * g->warm)));
         S = std::max(1LL, std::min(S, maxS));
+        if (oneRoundWaves > 0 && oneRoundWaves / nrblk >= 1) S = std::min(S, oneRoundWaves / nrblk);
         g->segLen = roundup((int)((T + S - 1) / S), 16);
         g->numSegments = (T + g->segLen - 1) / g->segLen;
     } else {
@@ -2764,6 +2768,10 @@ int Batch::run()
         for (int w = 1; w <= kMaxLongReadWords4; ++w) {
             if (byWords[w].empty()) continue;
             std::unique_ptr<ReadGroup> g;
+            // (many short segments here: a single strip warms up over at most 2047 columns, and 7,930 waves balance themselves
+            // over the SIMDs where one round of 1,014 does not -- 513 / 768 / 1024-base reads: 110 / 125 / 166 ms against
+            // 129 / 144 / 172 with makeGroup's oneRoundWaves; the chained strips of solveTallFull warm up over 2m - 1 columns
+            // of the WHOLE query, which is what makes one round the better plan there)
             if (makeGroup(byWords[w], w, g)) return 1;
             stats.path |= 1;
             if (runGroupScans(*g, true) || runGroupExact(*g) || collectGroup(*g, res)) return 1;

@@ -169,7 +169,7 @@ private:
     int syms_ = 4;               // Peq rows per word of the reads kernels: target symbols rounded up to 4, 8 or 16
     int packTarget();
     int runReads();                                   // device work only; results stay in HBM
-    int makeGroup(const std::vector<int>& units, int words, std::unique_ptr<ReadGroup>& g);
+    int makeGroup(const std::vector<int>& units, int words, std::unique_ptr<ReadGroup>& g, long long oneRoundWaves = 0);
     int runGroupScans(ReadGroup& g, bool fullOnly);
     int runGroupExact(ReadGroup& g);
     int collectGroup(ReadGroup& g, std::vector<UnitResult>& res);
@@ -307,6 +307,9 @@ int align_one_fused(const char* q, int qn, const char* t, int tn, EdlibAlignConf
 // helpers shared by engine.hip and long_reads.hip
 int roundup(int x, int q);
 void plan_segments(int nlanes, int T, int mode, int warmFull, long long wantWaves, int& S, int& segLen, int& warm);
+// waves of the 24- / 32-word full-height lane kernels (24 / 32 KB of LDS rows each) the chip runs without two of them sharing
+// a SIMD: one per SIMD of 256 CUs (EDLIB_AMD_TALL_WAVES overrides; read per call: tools/tall_matrix.sh sweeps it)
+inline long long tall_round_waves() { const char* e = getenv("EDLIB_AMD_TALL_WAVES"); return e ? std::max(64LL, atoll(e)) : 1024; }
 void finalize_semiglobal(UnitResult& r, int kcfg, int m, int best, const int* pos, long long npos);
 
 int device_count();

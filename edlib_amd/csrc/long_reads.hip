@@ -327,18 +327,30 @@ int Batch::solveTallFull(const std::vector<int>& units, std::vector<UnitResult>&
         const int nl = (int)set.size();
         int mmax = 0;
         for (int u : set) mmax = std::max(mmax, qlen(u));
-        // one segmentation for every launch of the set: warm-up 2m - 1 of its tallest query, segments of at least 8 warm-ups
+        // one segmentation for every launch of the set: warm-up 2m - 1 of its tallest query
         const int warm = 2 * mmax - 1;
         const long long nrblk = (nl + 63) / 64;
         // as many segments as it takes to fill the chip (a wave of this kernel holds 32 KB of LDS rows: ~1280 resident
-        // waves), none shorter than four warm-ups
-        const long long maxS = std::max<long long>(1, std::min<long long>(std::min(65535, std::max(1, T / 4096)), T / (4LL * warm)));
-        const long long S = std::max<long long>(1, std::min<long long>((2048 + nrblk - 1) / nrblk, maxS));
+        // waves), none shorter than ONE warm-up.  (Rounds 2-3 asked for four: 559 unrelated reads of 6,000 bases then are 9 x 104
+        // waves, fewer than the chip has SIMDs, and 410 of 8,192 bases fell below the floor underneath and went to kernel W.
+        // Measured per 16,384-read-equivalents batch, tools/tall_matrix.sh: 6,000 bases 860 -> 745 ms, 8,192: 959 -> 803,
+        // 10,000: 969 -> 933; a wave that recomputes as many columns as it owns still beats an idle SIMD.)
+        const char* wm = getenv("EDLIB_AMD_TALL_WARMS");              // (shortest segment in warm-ups; read per call)
+        const long long warms = wm ? std::max(1LL, atoll(wm)) : 1;
+        const long long maxS = std::max<long long>(1, std::min<long long>(std::min(65535, std::max(1, T / 4096)), T / (warms * warm)));
+        // ONE round of waves, at most one per SIMD (tall_round_waves): measured per 16,384-read-equivalents batch with
+        // tools/tall_matrix.sh, 6,000-base reads (9 read blocks) at 768 / 896 / 1024 / 1152 / 1792 / 2043 waves: 672 / 628 /
+        // 593 / 822 / 679 / 645 ms -- the kernel is bound by VALU issue, a SIMD with two of its waves takes twice as long and
+        // the launch waits for it, and every extra segment is another warm-up of 2m - 1 columns.  Rounds 2-3 aimed at 2048
+        // waves and four warm-ups per segment: 860 ms there (and 158 x 13 = 2054 waves for 4,096-base reads: 566 ms against
+        // 438 at 78 x 13).
+        const long long S = std::max<long long>(1, std::min<long long>(std::max(1LL, tall_round_waves() / nrblk), maxS));
         // The strip levels of a set run one after the other, and a segment cannot be shorter than a few warm-ups (2m - 1
         // columns each): a handful of very tall queries does not fill the chip this way (335 queries of 10 kb: 6 x 62
         // waves).  Those stay on kernel W, which cuts the target of each unit on its own.
         const char* mw = getenv("EDLIB_AMD_TALL_MIN_WAVES");          // (read per call: the tests lower it)
-        if (nrblk * S < (mw ? atoll(mw) : 768)) { handBack.insert(handBack.end(), set.begin(), set.end()); continue; }
+        // (512: the floor of 1024 / nrblk alone never goes below 513 waves; 410 reads of 8,192 bases on 532 waves: 807 ms, on kernel W: 959)
+        if (nrblk * S < (mw ? atoll(mw) : 512)) { handBack.insert(handBack.end(), set.begin(), set.end()); continue; }
         const int segLen = roundup((int)((T + S - 1) / S), 16);
         const int numSegments = (T + segLen - 1) / segLen;
         const int chainBlocks = (segLen + warm) / 16 + 3;
