@@ -32,8 +32,8 @@ __global__ void __launch_bounds__(64) k(u64* out, u32 seed, int iters)
         if (KIND == 5) { REP16(asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32 %1, %0, %2\n v_add_u32 %1, %1, %2\n v_add_u32 %1, %1, %2"
                                             : "+v"(a), "+v"(c) : "v"(b));) }                                      // dpp + 3 dependent adds (64 instr)
         if (KIND == 6) { REP64(asm volatile("ds_read_b32 %0, %0\n s_waitcnt lgkmcnt(0)" : "+v"(addr));) }          // dependent LDS chain
-        if (KIND == 7) { REP16(asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1" : "+s"(seed));) }   // dependent SALU
-        if (KIND == 8) { REP16(asm volatile("v_add_u32 %0, %0, %2\n s_add_u32 %1, %1, 1\n v_add_u32 %0, %0, %2\n s_add_u32 %1, %1, 1" : "+v"(a), "+s"(seed) : "v"(b));) }  // VALU / SALU interleaved
+        if (KIND == 7) { REP16(asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1" : "+s"(seed) :: "scc");) }   // dependent SALU (s_add writes SCC: without the clobber the loop's own compare was lost and the kernel never ended)
+        if (KIND == 8) { REP16(asm volatile("v_add_u32 %0, %0, %2\n s_add_u32 %1, %1, 1\n v_add_u32 %0, %0, %2\n s_add_u32 %1, %1, 1" : "+v"(a), "+s"(seed) : "v"(b) : "scc");) }  // VALU / SALU interleaved
         if (KIND == 9) { REP16(asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %0, %4\n v_add_u32 %3, %1, %4"
                                             : "+v"(a), "+v"(c), "+v"(e), "+v"(g) : "v"(b));) }                    // 2 chains
         if (KIND == 10) { REP16(asm volatile("v_readlane_b32 %1, %0, 3\n v_mov_b32 %0, %1\n v_readlane_b32 %1, %0, 3\n v_mov_b32 %0, %1" : "+v"(a), "+s"(seed));) }   // readlane -> mov round trips
