@@ -24,7 +24,7 @@ ROOT=$PWD; R=${R:-r03}; OUT=$ROOT/gpurun_out/visit_$R; mkdir -p $OUT; export TMP
 say() { echo "==== $* ($(date +%T))"; }
 trace() {   # $1 = tag, rest = bench args
   local tag=$1; shift; local d=$OUT/trace_$tag; rm -rf $d; mkdir -p $d
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o t -- python $ROOT/bench.py "$@" > $d/bench.json 2> $d/err.log )
+  ( cd /tmp && timeout -k 5 ${TRACE_TIMEOUT:-300} rocprofv3 --kernel-trace --stats --output-format csv -d $d -o t -- python $ROOT/bench.py "$@" > $d/bench.json 2> $d/err.log )
   cp $d/bench.json $OUT/${R}_${tag}_underprofiler.json
   local f=$(find $d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${R}_${tag}_kernel_stats.csv
   f=$(find $d -name "*kernel_trace.csv" | head -1)
@@ -76,7 +76,7 @@ for stage in "$@"; do
     chrom)   timeout 600 python tools/bench_chromosome.py ${CHROM_ARGS:---ref} 2>&1 | cut -c1-520 | tee $OUT/${R}_chromosome.json ;;
     chromtrace)
       d=$OUT/trace_chrom; rm -rf $d; mkdir -p $d
-      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o t -- python $ROOT/tools/bench_chromosome.py --repeat 1 > $d/out.json 2> $d/err.log )
+      ( cd /tmp && timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o t -- python $ROOT/tools/bench_chromosome.py --repeat 1 > $d/out.json 2> $d/err.log )
       f=$(find $d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${R}_chromosome_kernel_stats.csv && head -8 $f | cut -c1-170
       f=$(find $d -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $ROOT/tools/prof_summaries.py trace "$f" "$OUT/${R}_chromosome_kernel_trace_edlib.csv"
       rm -rf $d ;;
