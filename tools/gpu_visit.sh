@@ -34,7 +34,7 @@ trace() {   # $1 = tag, rest = bench args
 }
 pmc() {     # $1 = tag, $2 = counters (space separated), rest = bench args
   local tag=$1 ctr=$2; shift; shift; local d=$OUT/pmc_$tag; rm -rf $d; mkdir -p $d
-  ( cd /tmp && timeout -k 5 ${PMC_TIMEOUT:-420} rocprofv3 --pmc $ctr --output-format csv -d $d -o p -- python $ROOT/bench.py "$@" --no-cpu-baseline --no-e2e --no-secondary > $d/bench.json 2> $d/err.log )
+  ( cd /tmp && timeout -k 5 ${PMC_TIMEOUT:-240} rocprofv3 --pmc $ctr --output-format csv -d $d -o p -- python $ROOT/bench.py "$@" --no-cpu-baseline --no-e2e --no-secondary > $d/bench.json 2> $d/err.log )
   echo "== pmc $tag rc=$?"
   local f=$(find $d -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python $ROOT/tools/prof_summaries.py pmc "$f" "$OUT/${R}_pmc_${tag}.csv"
