@@ -107,3 +107,21 @@ def test_negative_lengths_are_errors_everywhere():
     assert L.edlibAlignBatchSharedTarget(qs, (C.c_int * 2)(4, 2), 2, b"ACGTT", -5, cfg, res) == 1
     L.edlibAmdFreeResults(res, 2)               # nothing to free, must not crash
     L.edlibAmdTrim()                            # empty cache, must not crash
+
+
+def test_every_environment_knob_is_documented():
+    """every EDLIB_AMD_* variable the library reads (getenv in edlib_amd/csrc, os.environ in the Python front) has its row in
+    INTEGRATION.md: a knob that steers routing is part of the boundary a maintainer sees"""
+    import glob
+    import re
+    names = set()
+    for path in glob.glob(os.path.join(ROOT, "edlib_amd", "csrc", "*")):
+        with open(path, errors="replace") as f:
+            names.update(re.findall(r'getenv\("(EDLIB_AMD_[A-Z0-9_]+)"\)', f.read()))
+    with open(os.path.join(ROOT, "edlib_amd", "__init__.py")) as f:
+        names.update(re.findall(r'environ(?:\.get)?\(?\[?"(EDLIB_AMD_[A-Z0-9_]+)"', f.read()))
+    assert len(names) > 20
+    with open(os.path.join(ROOT, "INTEGRATION.md")) as f:
+        doc = f.read()
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, missing
