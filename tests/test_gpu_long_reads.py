@@ -313,13 +313,17 @@ def test_tall_unrelated_queries_default_plan(engine):
     """the same path as planned by default (no EDLIB_AMD_TALL_MIN_WAVES): enough unrelated two-strip queries for one round of
     chained-strip waves -- nine read blocks x 97 target segments of a little more than one warm-up each (round 4's plan;
     rounds 2-3: four warm-ups per segment, which a target of this length cannot give 512 waves)"""
-    assert "EDLIB_AMD_TALL_MIN_WAVES" not in os.environ and "EDLIB_AMD_TALL_WAVES" not in os.environ
-    target = synth.random_dna(131, 400_000)
-    rng = np.random.default_rng(132)
-    lengths = [int(x) for x in rng.integers(1100, 1301, 520)]
-    reads = [_ACGT[rng.integers(0, 4, m)] for m in lengths]
-    st = _check(engine, reads, target, "distance")
-    assert st["path"] & 4            # (the filter ran; EDLIB_AMD_DEBUG=1 times the strips as "handed back (full height)": 19 ms here.
-    #                                   Bit 2 is set as well: the few queries whose end locations tie beyond a segment's list go on to kernel W)
-    reads += _reads(target, [1150, 1290, 2000], 133, max_err=0.04)                  # resolved by the filter, among them
-    _check(engine, reads, target, "locations")
+    saved = {k: os.environ.pop(k) for k in ("EDLIB_AMD_TALL_MIN_WAVES", "EDLIB_AMD_TALL_WAVES", "EDLIB_AMD_TALL_WARMS", "EDLIB_AMD_TALL")
+             if k in os.environ}
+    try:
+        target = synth.random_dna(131, 400_000)
+        rng = np.random.default_rng(132)
+        lengths = [int(x) for x in rng.integers(1100, 1301, 520)]
+        reads = [_ACGT[rng.integers(0, 4, m)] for m in lengths]
+        st = _check(engine, reads, target, "distance")
+        assert st["path"] & 4        # (the filter ran; EDLIB_AMD_DEBUG=1 times the strips as "handed back (full height)": 19 ms here.
+        #                               Bit 2 is set as well: the few queries whose end locations tie beyond a segment's list go on to kernel W)
+        reads += _reads(target, [1150, 1290, 2000], 133, max_err=0.04)              # resolved by the filter, among them
+        _check(engine, reads, target, "locations")
+    finally:
+        os.environ.update(saved)
