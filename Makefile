@@ -18,8 +18,8 @@ $(OBJDIR)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hpp) include/edlib.h include/e
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-edlib_amd/libedlib.so: $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+edlib_amd/libedlib.so: $(OBJS) $(CSRC)/exports.map
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,--version-script=$(CSRC)/exports.map -o $@ $(OBJS)
 
 # batch-aware CLI with the reference CLI's flags and output
 build/edlib-aligner-batch: apps/aligner_batch.cpp edlib_amd/libedlib.so include/edlib.h include/edlib_amd.h

@@ -11,10 +11,14 @@
                 e_coli_DH1.fasta, which is a missing blob: .MISSING_LARGE_BLOBS), tasks distance / locations / path.
                 Contains the §8(c) golden: the 250 bp read, HW -l => 108, (350889,351126) (350889,351127).
   prefixes/     test_data/E_coli_DH1/prefixes/*: SHW against the same chromosome (perf_tests.sh:167-177).
+  myers         the FIXED-k block of perf_tests.sh:195-219 ("Myers": HW on the 10 kbp reads with k = 100 / 1000 / 10000,
+                the same (file, k) selection), plus k = distance and distance - 1 for every file: distance and
+                locations.  (Against the 1 Mb chromosome these reads are unrelated sequence, distance ~4,880: k = 100 and
+                1000 answer -1 -- the band of a fixed k that never reaches the bottom row -- and k = 10000 finds them.)
 
 The FASTA files are the reference's test DATA (not source); /root/reference does not exist on the GPU box, so they travel
 as fixtures: the 1 Mb files xz-compressed (tests read them with lzma), the read files as they are.
-Run from the repo root:   python oracle/gen_realdata_golden.py [--only chromosome|mason|prefixes]
+Run from the repo root:   python oracle/gen_realdata_golden.py [--only chromosome|mason|prefixes|myers]
 """
 import argparse
 import hashlib
@@ -105,6 +109,45 @@ def batch_job(args):
     return {"dir": "%s/%s" % (kind, sub), "mode": mode, "cases": cases}
 
 
+MYERS_K = {100: ["e_coli_DH1_illumina_1x10000.fasta"],
+           1000: ["e_coli_DH1_illumina_1x10000.fasta", "mutated_97_perc.fasta", "mutated_94_perc.fasta", "mutated_90_perc.fasta"],
+           10000: None}                                   # None: every file of the directory (perf_tests.sh:214-219)
+
+
+def myers_job(name):
+    from oracle.oracle import load_ref
+    ref = load_ref()
+    t = read_fasta(os.path.join(REF, CHROM_DIR, CHROM))
+    q = read_fasta(os.path.join(REF, "E_coli_DH1", "mason_illumina_reads", "10kbp", name))
+    d = ref.align(q, t, "HW", "distance", -1)["editDistance"]
+    ks = sorted(set([k for k, files in MYERS_K.items() if files is None or name in files] + [d, d - 1]))
+    out = []
+    for k in ks:
+        c = {"file": name, "qlen": len(q), "k": k}
+        for task in ("distance", "locations"):
+            c[task] = summarise(ref, ref.align(q, t, "HW", task, k), False)
+        out.append(c)
+    print("myers", name, [(c["k"], c["distance"]["editDistance"]) for c in out], flush=True)
+    return out
+
+
+def myers_related_job(p):
+    """the same three thresholds on RELATED 10 kb reads: bases [500000, 510000) of mutated_<p>_perc.fasta (the reference's
+    Chromosome files, sliced here because its E. coli genome is a missing blob), HW against the chromosome"""
+    from oracle.oracle import load_ref
+    ref = load_ref()
+    t = read_fasta(os.path.join(REF, CHROM_DIR, CHROM))
+    q = read_fasta(os.path.join(REF, CHROM_DIR, "mutated_%d_perc.fasta" % p))[500000:510000]
+    out = []
+    for k in (100, 1000, 10000):
+        c = {"slice_of": "mutated_%d_perc.fasta.xz" % p, "from": 500000, "to": 510000, "qlen": len(q), "k": k}
+        for task in ("distance", "locations"):
+            c[task] = summarise(ref, ref.align(q, t, "HW", task, k), False)
+        out.append(c)
+    print("myers_related", p, [(c["k"], c["distance"]["editDistance"], c["locations"]["startLocations"]) for c in out], flush=True)
+    return out
+
+
 def copy_data():
     os.makedirs(os.path.join(DST, "chromosome"), exist_ok=True)
     for name in [CHROM] + ["mutated_%d_perc.fasta" % p for p in PERCENTS]:
@@ -137,8 +180,13 @@ def main():
             futs["prefixes"] = [ex.submit(batch_job, ("prefixes", s, "SHW")) for s in MASON]
         if a.only in ("", "chromosome"):
             futs["chromosome"] = [ex.submit(chrom_job, p) for p in PERCENTS]
+        if a.only in ("", "myers"):
+            futs["myers"] = [ex.submit(myers_job, n) for n in sorted(os.listdir(os.path.join(REF, "E_coli_DH1", "mason_illumina_reads", "10kbp")))]
+            futs["myers_related"] = [ex.submit(myers_related_job, p) for p in (99, 97, 94, 90)]
         for k, fs in futs.items():
             doc[k] = [f.result() for f in fs]
+            if k in ("myers", "myers_related"):
+                doc[k] = [c for part in doc[k] for c in part]
             with open(path, "w") as f:
                 json.dump(doc, f, indent=1)
     # the golden SURVEY.md §8c quotes

@@ -38,6 +38,17 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n)
 
 
+def test_library_exports_only_declared_symbols():
+    """The reference's shared library exports its five functions and nothing else; this one the
+    declarations of include/*.h and nothing else -- no kernel handles, no C++ symbols (edlib_amd/csrc/exports.map)."""
+    import edlib_amd
+    out = subprocess.run(["nm", "-D", "--defined-only", edlib_amd.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    defined = sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+    assert defined == declared_symbols(), sorted(set(defined) ^ set(declared_symbols()))
+    kinds = set(l.split()[-2] for l in out.splitlines() if l.strip())
+    assert kinds == {"T"}, kinds
+
+
 def test_struct_layout_matches_reference():
     import edlib_amd
     assert C.sizeof(edlib_amd.AlignConfig) == 32        # SURVEY.md §8b, x86-64 SysV

@@ -109,7 +109,60 @@ def test_oracle_reproduces_chromosome_99(oracle):
     assert (got["editDistance"], got["endLocations"], len(q)) == (9927, [999999], c["qlen"])
 
 
+def _myers_query(c):
+    if "file" in c:
+        return read_fasta(os.path.join(REAL, "mason_illumina_reads", "10kbp", c["file"]))
+    return read_fasta(os.path.join(REAL, "chromosome", c["slice_of"]))[c["from"]:c["to"]]
+
+
+def _myers_id(c):
+    return "%s-k%d" % (c.get("file", c.get("slice_of", "")).split(".")[0] + ("" if "file" in c else "-slice"), c["k"])
+
+
+MYERS = EXP.get("myers", []) + EXP.get("myers_related", [])
+
+
+def test_fixed_k_fixture_covers_the_reference_block():
+    """perf_tests.sh:195-219: HW on the 10 kbp reads with k = 100 (one file), 1000 (four files), 10000 (all seven)"""
+    got = {}
+    for c in EXP["myers"]:
+        got.setdefault(c["k"], set()).add(c["file"])
+    assert len(got[100]) == 1 and len(got[1000]) == 4 and len(got[10000]) == 7
+    assert all(c["distance"]["editDistance"] == -1 for c in EXP["myers"] if c["k"] in (100, 1000))
+    assert sorted(c["distance"]["editDistance"] for c in EXP["myers_related"] if c["k"] == 1000) == [108, 305, 657, 967]
+
+
+@pytest.mark.parametrize("case", [c for c in MYERS if c["k"] <= 1000], ids=_myers_id)
+def test_oracle_reproduces_fixed_k_fixtures(oracle, case):
+    """(the thresholds the restatement answers in about a second each; the rest on the GPU side)"""
+    q = _myers_query(case)
+    got = oracle.align(q, chromosome(), "HW", "locations", case["k"])
+    check_result(got, case["locations"], None, _myers_id(case))
+
+
 # ------------------------------------------------------------------ GPU
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", MYERS, ids=_myers_id)
+def test_gpu_fixed_k_single_calls(engine, case):
+    """the reference's "Myers" block (test_data/perf_tests.sh:195-219): a fixed k on 10 kbp HW queries, one edlibAlign() each"""
+    q = _myers_query(case)
+    for task in ("distance", "locations"):
+        got = engine.align_raw(q, chromosome(), "HW", task, case["k"])
+        assert got["status"] == 0
+        check_result(got, case[task], engine.cigar_from_alignment, "%s %s" % (_myers_id(case), task))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", sorted(set(c["k"] for c in MYERS)))
+def test_gpu_fixed_k_as_shared_target_batches(engine, k):
+    """every query that has a fixture at this k, as ONE shared-target batch (piece filter / verification with the caller's k)"""
+    cases = [c for c in MYERS if c["k"] == k]
+    got = engine.align_batch([_myers_query(c) for c in cases], chromosome(), mode="HW", task="locations", k=k, raw=True)
+    for g, c in zip(got, cases):
+        assert g["status"] == 0
+        check_result(g, c["locations"], engine.cigar_from_alignment, _myers_id(c))
+
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("batch", _batches(False), ids=lambda b: b["dir"])
