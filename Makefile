@@ -12,7 +12,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Iin
 SRCS := $(CSRC)/reads_kernels.hip $(CSRC)/reads_kernels_long.hip $(CSRC)/pair_kernels.hip $(CSRC)/wide_kernels.hip $(CSRC)/engine.hip $(CSRC)/long_reads.hip $(CSRC)/one_pair.hip $(CSRC)/api.hip
 OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 
-all: edlib_amd/libedlib.so build/edlib-aligner-batch build/latency
+all: edlib_amd/libedlib.so build/edlib-aligner-batch build/latency build/cu_hog
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hpp) include/edlib.h include/edlib_amd.h
 	@mkdir -p $(OBJDIR)
@@ -30,6 +30,11 @@ build/edlib-aligner-batch: apps/aligner_batch.cpp edlib_amd/libedlib.so include/
 build/latency: tools/latency.cpp
 	@mkdir -p build
 	g++ -O2 -std=c++14 tools/latency.cpp -ldl -o $@
+
+# a second process that holds most wave slots of the device for a few seconds (tests/test_gpu_wide.py)
+build/cu_hog: tools/cu_hog.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O2 tools/cu_hog.hip -o $@
 
 oracle:
 	$(MAKE) -C oracle all

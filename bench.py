@@ -506,7 +506,9 @@ def main():
         devices = [x[1] for x in tl]
     flat = None
     collect_ms = None
-    if args.dump or (rank == 0 and world == 1 and not args.no_cpu_baseline):
+    # (rank 0 also at world > 1: the line of a multi-rank run carries the reference baseline and the parity check of rank 0's
+    # OWN shard -- taken after the timed region, while the other ranks wait at the closing barrier)
+    if args.dump or (rank == 0 and not args.no_cpu_baseline):
         tc = time.perf_counter()
         flat = batch.results_flat()
         collect_ms = (time.perf_counter() - tc) * 1e3
@@ -527,9 +529,12 @@ def main():
         out["devices_distinct"] = len(set(devices))
         if args.share_gpu:
             out["dry_run_shared_gpu"] = True
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             sample = args.parity_sample if args.parity_sample is not None else (20000 if args.config == 2 else w["n"])
             base, parity = cpu_baseline_and_parity(w, flat, sample)
+            if world > 1:
+                base["sample"] += "; rank 0's shard of a %d-rank run (the other ranks idle at the barrier meanwhile)" % world
+                parity["shard"] = "rank 0 of %d" % world
             out["cpu_baseline"] = base
             out["parity_sample"] = parity
             if args.config == 2:

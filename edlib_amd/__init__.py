@@ -47,7 +47,7 @@ class AlignResult(C.Structure):           # edlib.h:162-218
 class BatchStats(C.Structure):            # edlib_amd.h EdlibAmdBatchStats
     _fields_ = [("run_ms", C.c_double), ("scan_ms", C.c_double), ("scan_launches", C.c_int),
                 ("cells", C.c_longlong), ("word_steps", C.c_longlong), ("algo_bytes", C.c_longlong),
-                ("path", C.c_int), ("overflow_units", C.c_int)]
+                ("path", C.c_int), ("overflow_units", C.c_int), ("wide_retries", C.c_int)]
 
 
 _lib = None

@@ -1377,7 +1377,11 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     }
     const int* count = score + n; const int* last = count + n;
     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-    if (ring == kWide && checkWide()) return 1;
+    if (ring == kWide) {
+        const int w = checkWide();
+        if (w == 2) return solveChunk(mode, wantPositions, wantPath, units, ua, ub, out, ring, ringH);     // (nothing of `out` was touched yet)
+        if (w) return 1;
+    }
     lap("chunk: kernels+D2H");
 
     // exact second pass for units with more end locations than kPosCap
@@ -1407,7 +1411,11 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
             ovfPos.resize((size_t)ovfOff.back());
             EDLIB_AMD_HIP(hipMemcpyAsync(ovfPos.data(), pool2.p, ovfPos.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
             EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-            if (ring == kWide && checkWide()) return 1;
+            if (ring == kWide) {
+                const int w = checkWide();
+                if (w == 2) return solveChunk(mode, wantPositions, wantPath, units, ua, ub, out, ring, ringH);
+                if (w) return 1;
+            }
             stats.overflow_units += (int)ovf.size();
             for (size_t j = 0; j < ovf.size(); ++j) {
                 const PairDesc& d = d2[j];
@@ -1459,6 +1467,9 @@ int Batch::planWide(int mode, PairDesc* descs, size_t n, WidePlan& plan)
     int want = 1;
     for (size_t i = 0; i < n; ++i) want = std::max(want, wide_slots_wanted(mode, descs[i].qlen, descs[i].tlen, descs[i].bandT, descs[i].kinit));
     if (const char* e = getenv("EDLIB_AMD_WIDE_SLOTS")) { if (atoi(e) > 0) want = atoi(e); }      // (tests: fewer slots than strips alive)
+    // after an aborted launch of this run (workgroups not resident together, a stalled hand-off): one slot per unit -- a wave
+    // then only reads granules it wrote itself and never waits, whatever else is on the device
+    if (wideSerial_) want = 1;
     plan.slots = std::min(want, wideCap_);
     plan.perLaunch = (size_t)std::max(1, wideCap_ / plan.slots);
     long long words = 0, most = 0;
@@ -1469,8 +1480,8 @@ int Batch::planWide(int mode, PairDesc* descs, size_t n, WidePlan& plan)
         most = std::max(most, words);
     }
     EDLIB_AMD_HIP(d_wide_.ensure((size_t)most));
-    if (!d_wabort_.p) { EDLIB_AMD_HIP(d_wabort_.alloc(1)); EDLIB_AMD_HIP(h_wabort_.alloc(sizeof(unsigned))); }
-    EDLIB_AMD_HIP(hipMemsetAsync(d_wabort_.p, 0, sizeof(unsigned), stream_));
+    if (!d_wabort_.p) { EDLIB_AMD_HIP(d_wabort_.alloc(2)); EDLIB_AMD_HIP(h_wabort_.alloc(sizeof(unsigned))); }    // {abort word, workgroups arrived}
+    EDLIB_AMD_HIP(hipMemsetAsync(d_wabort_.p, 0, 2 * sizeof(unsigned), stream_));
     return 0;
 }
 
@@ -1507,6 +1518,7 @@ int Batch::launchWide(int mode, const PairScanArgs& a0, const PairDesc* hostDesc
         const long long words = hostDescs[g1 - 1].auxOff + wide_stream_words(hostDescs[g1 - 1].tlen, plan.slots);
         // every polled word starts at zero (tags are strip + 1): a granule of an earlier launch must never look fresh
         EDLIB_AMD_HIP(hipMemsetAsync(d_wide_.p, 0, (size_t)words * sizeof(unsigned long long), stream_));
+        EDLIB_AMD_HIP(hipMemsetAsync(d_wabort_.p + 1, 0, sizeof(unsigned), stream_));     // the residency count of THIS launch
         PairScanArgs a = a0;
         a.descs = a0.descs + g0; a.numUnits = (int)(g1 - g0);
         a.outScore = a0.outScore + g0; a.outCount = a0.outCount + g0; a.outLast = a0.outLast + g0;
@@ -1517,14 +1529,19 @@ int Batch::launchWide(int mode, const PairScanArgs& a0, const PairDesc* hostDesc
     return 0;
 }
 
+// 0 = the launches since planWide() ran to their end; 2 = one of them gave up (its workgroups were not on the device
+// together, or a hand-off made no progress) and the caller runs its units again, which planWide() now gives one slot each;
+// 1 = that second attempt failed as well (cannot happen by construction: reported, not retried)
 int Batch::checkWide()
 {
     wideGateRelease();
-    if (h_wabort_.p && *reinterpret_cast<const unsigned*>(h_wabort_.p) != 0u) {
-        set_error("wide kernel: a strip hand-off timed out (launch aborted)");
-        return 1;
-    }
-    return 0;
+    const unsigned code = h_wabort_.p ? *reinterpret_cast<const unsigned*>(h_wabort_.p) : 0u;
+    if (code == 0u) return 0;
+    ++stats.wide_retries;
+    if (!wideSerial_) { wideSerial_ = true; return 2; }
+    set_error(code == 2u ? "wide kernel: the workgroups of a one-slot launch did not all start"
+                         : "wide kernel: a hand-off stalled inside a one-slot launch");
+    return 1;
 }
 
 // alphabetLength of the units the reads path does not cover (reference transformSequences, edlib.cpp:1417-1462:
@@ -2062,7 +2079,11 @@ int Batch::hirschbergLevel(const std::vector<PathPiece>& big, std::vector<int>& 
     std::vector<int> out(3 * np);
     EDLIB_AMD_HIP(hipMemcpyAsync(out.data(), d_out.p, out.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-    if (anyWide && checkWide()) return 1;
+    if (anyWide) {
+        const int w = checkWide();
+        if (w == 2) return hirschbergLevel(big, splitRow, leftScore, rightScore);
+        if (w) return 1;
+    }
     splitRow.resize(np); leftScore.resize(np); rightScore.resize(np);
     for (size_t q = 0; q < np; ++q) {
         const size_t p = order[q];
@@ -2135,7 +2156,11 @@ int Batch::solveWideSplit(const std::vector<UnitSpec>& units, std::vector<int>& 
     EDLIB_AMD_HIP(launch_split_min(sa, packed.p, maxRows, stream_));
     EDLIB_AMD_HIP(hipMemcpyAsync(out.data(), d_out.p, out.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-    if (checkWide()) return 1;
+    {
+        const int w = checkWide();
+        if (w == 2) return solveWideSplit(units, out);
+        if (w) return 1;
+    }
     return 0;
 }
 
@@ -2540,7 +2565,7 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
         for (size_t i = 0; i < n; ++i)
             if (direct.empty() ? std::min(units[i].qlen, units[i].tlen) >= 32768 : (direct[i] && !whole_ok(i))) {
                 UnitSpec u = units[i];
-                u.qlen = cut; u.tlen = cut + 512; u.kinit = cut;
+                u.qlen = cut; u.tlen = std::min(u.tlen, cut + 512); u.kinit = cut;       // (never past the unit's own target)
                 probe.push_back(u); who.push_back(i);
             }
         if (!probe.empty()) {
@@ -2679,7 +2704,20 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
 
 // --------------------------------------------------------------------- run
 
+// Every failure path of a run ends here: the device's wide gate goes back (another batch on the device -- a resident Python
+// batch kept after an error, a second host thread -- would otherwise wait for it for ever), behind a synchronisation so
+// that no spinning launch of this batch is still on the device when the next one takes the gate.
 int Batch::run()
+{
+    const int rc = runImpl();
+    if (rc && wideGateHeld_) {
+        if (stream_) { DeviceGuard guard(device_); (void)hipStreamSynchronize(stream_); (void)hipGetLastError(); }
+        wideGateRelease();
+    }
+    return rc;
+}
+
+int Batch::runImpl()
 {
     pool_quarantine(false);
     Lap lap;
@@ -2693,6 +2731,7 @@ int Batch::run()
     opsKeep_.clear();            // (the previous run's views die with the reset of their records below)
     knownSplits_.clear();
     wideGateRelease();           // (a run that failed between a wide launch and its check)
+    wideSerial_ = false;         // every run tries the pipelined strips first
     opsOwned_.clear();
     // TASK_DISTANCE over reads-path units only: nothing is assembled on the host until results() asks for it, so
     // the per-unit records (160 bytes each) are not even allocated in the timed run

@@ -116,6 +116,7 @@ public:
              const char* targets, const long long* toff, int numTargets,   // numTargets == 1: shared
              EdlibAlignConfig cfg, int device);
     int run();
+    int runImpl();
     int results(EdlibAlignResult* out);
     int resultsFlat(int* status, int* editDistance, int* numLocations, int* alphabetLength, long long* locOffsets,
                     int** endLocations, int** startLocations, long long* alnOffsets, unsigned char** alignment);
@@ -214,7 +215,8 @@ private:
     struct WidePlan { int slots = 1; size_t perLaunch = 1; };
     int planWide(int mode, PairDesc* descs, size_t n, WidePlan& plan);      // slots per unit, units per launch; assigns auxOff
     int launchWide(int mode, const PairScanArgs& a, const PairDesc* hostDescs, size_t n, const WidePlan& plan);
-    int checkWide();                             // after the stream is idle: did a hand-off time out?  Releases the device's wide gate.
+    int checkWide();                             // after the stream is idle: 0 fine, 2 a launch gave up (run the units again: one slot each), 1 error.  Releases the device's wide gate.
+    bool wideSerial_ = false;                    // this run's wide launches take one slot per unit (after an aborted launch)
     bool wideGateHeld_ = false;                  // this batch holds its device's wide gate (launchWide .. checkWide)
     void wideGateRelease();
     // NW distance of long units as two half scans that meet in the middle (forward over the left half of the target,

@@ -35,8 +35,10 @@
 //     best / count / positions (:658-673), no band.
 //
 // With slots >= (bw + 2048) / 2176 + 2 no wave ever waits for a free slot and a unit takes about T + bw dependent steps
-// whatever K is (0.074 us each on an MI355X).  Every spin is bounded (wall clock) and a launch-wide abort word turns a
-// stuck hand-off into EDLIB_STATUS_ERROR instead of a hung queue.
+// whatever K is (0.074 us each on an MI355X).  The workgroups of a launch check at entry that they are all on the device
+// together (wide_all_resident); every later spin is bounded by the wall clock PER WAIT; either failure sets the launch's
+// abort word, every wave leaves, and the host runs the same units with one slot each -- a wave that only reads granules it
+// wrote itself never waits -- so a call still returns its answer (the reference always does: edlib.cpp:197-217).
 #include "pair_kernels.hpp"
 #include "block64.hpp"
 #include "lds_check.hpp"
@@ -98,17 +100,54 @@ long long wide_word_steps(int mode, int qlen, int tlen, int bandT, int K)
 __device__ __forceinline__ u64 ld_agent(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// abort word of a launch: 0 = fine, kWideAbortStalled = a hand-off made no progress, kWideAbortNotResident = the launch's
+// workgroups were not all on the device together.  Either way every wave leaves at its next poll and the host runs the
+// units again with ONE slot each (a wave then only reads granules it wrote itself: nothing to wait for, edlib.cpp:197-217
+// always returns).
+constexpr unsigned kWideAbortStalled = 1u, kWideAbortNotResident = 2u;
+
 // One poll failed: sleep; every so often look at the launch's abort word and at the wall clock (100 MHz).  True = give up.
-__device__ __forceinline__ bool wide_spin_fail(unsigned& spins, const long long t0, unsigned* abortWord)
+// t0 belongs to ONE wait (the caller zeroes it before the wait's first poll): the limit measures how long THIS hand-off
+// has made no progress, not how long the launch has been running (a launch of many strips per slot may run for minutes).
+__device__ __forceinline__ bool wide_spin_fail(unsigned& spins, long long& t0, unsigned* abortWord)
 {
     __builtin_amdgcn_s_sleep(4);
     if ((++spins & 255u) != 0u) return false;
     if (__hip_atomic_load(abortWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
-    if ((long long)wall_clock64() - t0 > 3000000000LL) {                // 30 s without the upstream strip moving
-        __hip_atomic_store(abortWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long now = (long long)wall_clock64();
+    if (t0 == 0) t0 = now;
+    else if (now - t0 > 1000000000LL) {                                  // 10 s without the upstream strip moving
+        __hip_atomic_store(abortWord, kWideAbortStalled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return true;
     }
     return false;
+}
+
+// Residency by contract: the strips of a unit wait for each other across workgroups, which only ends if every workgroup of
+// the launch is on the device at the same time.  The host sizes a launch for that (wide_resident_waves), but it cannot see
+// another process on the device or a tool that holds workgroups back -- so the kernel checks: every workgroup counts
+// itself in and waits (0.2 s at most) until all have; one that gives up marks the launch "not resident".  A launch with
+// one slot per unit has no cross-workgroup hand-off and skips this.
+__device__ __forceinline__ bool wide_all_resident(unsigned* abortWord, const unsigned total)
+{
+    unsigned ok = 1u;
+    if (threadIdx.x == 0) {
+        unsigned* arrived = abortWord + 1;
+        __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long long t0 = 0; unsigned spins = 0;
+        while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) {
+            __builtin_amdgcn_s_sleep(8);
+            if ((++spins & 63u) != 0u) continue;
+            if (__hip_atomic_load(abortWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0u; break; }
+            const long long now = (long long)wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > 20000000LL) {                            // 0.2 s: a launch that fits is resident within microseconds
+                __hip_atomic_store(abortWord, kWideAbortNotResident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0u; break;
+            }
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(ok) != 0u;
 }
 
 #define BITOP3_OR_NOR32(a, b, c)  ((u32)__builtin_amdgcn_bitop3_b32((a), (b), (c), 0xf1))   /* a | ~(b | c)  */
@@ -122,6 +161,7 @@ scan_pairs_wide_kernel(const PairScanArgs a)
     extern __shared__ __attribute__((aligned(16))) u32 s_peq32[];    // [sigmaT][64] words of 32 rows
     const int lane = threadIdx.x;
     const int slot = blockIdx.x, W = gridDim.x, unit = blockIdx.y;
+    if (W > 1 && !wide_all_resident(a.wabort, gridDim.x * gridDim.y)) return;     // (before any other exit: everybody counts)
     const PairDesc d = a.descs[unit];
     const int m = d.qlen, T = d.tlen, K = d.kinit;
     const int nw = num_words(m), nb64 = num_blocks(m), nstrips = (nw + 63) >> 6;
@@ -141,7 +181,7 @@ scan_pairs_wide_kernel(const PairScanArgs a)
     const bool dumpCol = a.colP != nullptr && d.colOff >= 0;
     // a granule's data word: bit 15 - (c & 15) = "hout of column c is +1", bit 31 - (c & 15) = "is -1"
     const u32 rowAbove = (MODE == 2) ? 0u : 0x0000ffffu;             // 16 columns of row -1: HW 0, SHW / NW +1 (:584, 779)
-    const long long clk0 = (long long)wall_clock64();
+    long long waitT0 = 0;                                            // start of the current wait (wide_spin_fail)
     unsigned spins = 0;
     const u32 laneOff = 4u * (u32)lane;
 
@@ -179,8 +219,9 @@ scan_pairs_wide_kernel(const PairScanArgs a)
         int top = (int)r0;                                           // D[r0 - 1][-1] = r0 (edlib.cpp:575-579)
         if (c0 > 0) {
             u64 v = ld_agent(upS);
+            waitT0 = 0;
             while ((u32)(v >> 32) != tagUp) {
-                if (wide_spin_fail(spins, clk0, a.wabort)) return;
+                if (wide_spin_fail(spins, waitT0, a.wabort)) return;
                 v = ld_agent(upS);
             }
             top = (int)(u32)v;
@@ -227,8 +268,9 @@ scan_pairs_wide_kernel(const PairScanArgs a)
         // lane 0 enters the 64 columns from `base` on (tnext / hnext hold what was requested for them)
         auto enter_chunk = [&](const int base) {
             u64 v = hnext;
+            waitT0 = 0;
             while (__builtin_amdgcn_ballot_w64(!h_ok(base, v)) != 0ull) {
-                if (wide_spin_fail(spins, clk0, a.wabort)) { bail = true; break; }
+                if (wide_spin_fail(spins, waitT0, a.wabort)) { bail = true; break; }
                 v = load_h(base);
             }
             const u32 words = h_data(base, v);                       // lanes 4 g + q: the word of group q
@@ -415,10 +457,24 @@ int wide_resident_waves(int sigmaT)
     int dev = 0, cus = 0, perCu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    hipError_t e;
-    if (sigmaT <= 32) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, scan_pairs_wide_kernel<0, true>, 64, (size_t)sigmaT * 256 + 512);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, scan_pairs_wide_kernel<0, false>, 64, 512);
-    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+    // the smallest answer over the three instantiations a launch may be (MODE 1 / 2 carry tracker and position state)
+    perCu = 1 << 20;
+    for (int mode = 0; mode < 3; ++mode) {
+        int v = 0;
+        hipError_t e;
+        if (sigmaT <= 32) {
+            const size_t lds = (size_t)sigmaT * 256 + 512;
+            e = mode == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, scan_pairs_wide_kernel<0, true>, 64, lds)
+              : mode == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, scan_pairs_wide_kernel<1, true>, 64, lds)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, scan_pairs_wide_kernel<2, true>, 64, lds);
+        } else {
+            e = mode == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, scan_pairs_wide_kernel<0, false>, 64, 512)
+              : mode == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, scan_pairs_wide_kernel<1, false>, 64, 512)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, scan_pairs_wide_kernel<2, false>, 64, 512);
+        }
+        if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+        perCu = v < perCu ? v : perCu;
+    }
     if (perCu > 8) perCu = 8;                                        // two waves per SIMD: more only share its issue slots
     if (perCu > 1) perCu -= 1;                                       // margin (the occupancy query can be one block per CU high)
     return cus * perCu;

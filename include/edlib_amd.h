@@ -106,6 +106,7 @@ typedef struct {
     long long algo_bytes;   /* algorithmic bytes: target+query+Peq+results    */
     int path;               /* bit 0 reads-per-lane kernel, bit 1 block-per-lane kernel, bit 2 piece filter (long HW reads) */
     int overflow_units;     /* units whose end-location list needed the exact second pass    */
+    int wide_retries;       /* launches of the many-wave kernel that gave up (not resident together / stalled) and were run again with one slot per unit */
 } EdlibAmdBatchStats;
 
 EDLIB_API int edlibAmdBatchStats(EdlibAmdBatch* batch, EdlibAmdBatchStats* out);

@@ -116,7 +116,7 @@ def test_eight_ranks_dry_run_on_one_device(strong):
     and strong scaling; every rank reports, host pools are sized from the CPU quota divided by the world size, and the
     run finishes well inside two minutes"""
     import time
-    args = ["--reads", "64000" if strong else "8000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e",
+    args = ["--reads", "64000" if strong else "8000", "--steps", "2", "--warmup", "1", "--parity-sample", "400", "--no-e2e",
             "--gpus", "8", "--share-gpu"] + (["--strong"] if strong else [])
     t0 = time.time()
     out = _line(_run(args, timeout=300))
@@ -124,4 +124,8 @@ def test_eight_ranks_dry_run_on_one_device(strong):
     assert out["n_gpus"] == 8 and out["dry_run_shared_gpu"] and len(out["per_rank_ms_per_step"]) == 8
     assert out["scaling"] == ("strong" if strong else "weak") and out["devices_distinct"] == 1
     assert out["config"]["units_per_gpu"] == 8000
-    assert wall < 120, wall
+    # a multi-rank line carries its evidence: the reference over a sample of rank 0's shard, after the timed region
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] in ("reference", "port")
+    assert out["parity_sample"]["checked"] >= 400 and out["parity_sample"]["bit_exact"] == out["parity_sample"]["checked"]
+    assert out["parity_sample"]["shard"] == "rank 0 of 8" and all(v is True for k, v in out["invariants"].items() if k != "planted_position_reads_checked")
+    assert wall < 150, wall
