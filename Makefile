@@ -12,7 +12,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Iin
 SRCS := $(CSRC)/reads_kernels.hip $(CSRC)/reads_kernels_long.hip $(CSRC)/pair_kernels.hip $(CSRC)/wide_kernels.hip $(CSRC)/engine.hip $(CSRC)/long_reads.hip $(CSRC)/one_pair.hip $(CSRC)/api.hip
 OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 
-all: edlib_amd/libedlib.so build/edlib-aligner-batch build/latency build/cu_hog
+all: edlib_amd/libedlib.so build/edlib-aligner-batch build/latency build/cu_hog build/libcu_hog.so
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hpp) include/edlib.h include/edlib_amd.h
 	@mkdir -p $(OBJDIR)
@@ -35,6 +35,9 @@ build/latency: tools/latency.cpp
 build/cu_hog: tools/cu_hog.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O2 tools/cu_hog.hip -o $@
+build/libcu_hog.so: tools/cu_hog.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -DCU_HOG_LIBRARY -shared -fPIC tools/cu_hog.hip -o $@
 
 oracle:
 	$(MAKE) -C oracle all

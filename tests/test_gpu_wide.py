@@ -179,39 +179,54 @@ def test_concurrent_callers_take_turns_on_the_wide_kernel(engine, checker):
     assert got == [[w] * 3 for w in want]
 
 
-@pytest.mark.parametrize("leave", [12, 40])
-def test_wide_launch_survives_a_cu_hog_from_another_process(engine, checker, leave):
-    """A second PROCESS holds all but `leave` wave slots of the device (build/cu_hog) while a 30 k x 30 k NW call wants 30
-    workgroups that wait for each other: the launch fits only in part, its workgroups notice at entry
-    (wide_kernels.hip: wide_all_resident), and the units run again with one slot each, which never waits -- the call
-    returns the right distance, not EDLIB_STATUS_ERROR (the reference always returns: edlib.cpp:197-217)."""
+@pytest.mark.parametrize("where", ["process", "stream"])
+def test_wide_launch_survives_a_cu_hog(engine, checker, where):
+    """Something else holds all but 12 wave slots of the device (tools/cu_hog.hip) while a 30 k x 30 k NW call wants 30
+    workgroups that wait for each other.  "process": a second PROCESS (the device's scheduler decides what shares the CUs:
+    on this pool the call simply waits its turn); "stream": a second stream of THIS process -- the launch fits only in
+    part, its workgroups notice at entry (wide_kernels.hip: wide_all_resident), and the units run again with one slot
+    each, which never waits.  Either way the call returns the right distance, not EDLIB_STATUS_ERROR (the reference
+    always returns: edlib.cpp:197-217)."""
+    import ctypes
     import subprocess
     import time
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "build", "cu_hog")
-    if not os.path.exists(exe):
+    exe, so = os.path.join(root, "build", "cu_hog"), os.path.join(root, "build", "libcu_hog.so")
+    if not os.path.exists(exe if where == "process" else so):
         pytest.skip("build/cu_hog was not built")
-    rng = random.Random(9100 + leave + SEED_SHIFT)
+    rng = random.Random(9100 + SEED_SHIFT)
     q, t = _mut(rng, 30000, 0.05, 0.025, 0.025)
     want = checker.align(q, t, "NW", "distance", -1)
     b = engine.PairBatch([q], [t], mode="NW", task="distance", k=-1)
     try:
         st = b.run()                                  # undisturbed: pipelined strips, no retry
         assert st["wide_retries"] == 0 and b.results()[0]["editDistance"] == want["editDistance"]
-        hog = subprocess.Popen([exe, "--leave", str(leave), "--seconds", "4"], stdout=subprocess.PIPE, text=True)
-        try:
+        hog = lib = None
+        if where == "process":
+            hog = subprocess.Popen([exe, "--leave", "12", "--seconds", "4"], stdout=subprocess.PIPE, text=True)
             line = hog.stdout.readline().split()      # "resident <n> of <m>"
             assert line and line[0] == "resident", line
             resident, total = int(line[1]), int(line[3])
+        else:
+            lib = ctypes.CDLL(so)
+            lib.cu_hog_start.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_int)]
+            tot = ctypes.c_int(0)
+            resident = lib.cu_hog_start(12, 4.0, ctypes.byref(tot))
+            total = tot.value
+            assert resident >= 0
+        try:
             t0 = time.time()
             st = b.run()
             wall = time.time() - t0
             got = b.results()[0]
         finally:
-            hog.wait(timeout=60)
+            if hog is not None:
+                hog.wait(timeout=60)
+            else:
+                assert lib.cu_hog_wait() == 0
         assert got["status"] == 0 and got["editDistance"] == want["editDistance"] and got["endLocations"] == want["endLocations"]
-        if resident == total:                         # the hog really held the device: 30 workgroups could not all start
-            assert st["wide_retries"] >= 1, (st, wall)
+        if where == "stream" and resident == total:   # the hog really held the device: 30 workgroups could not all start
+            assert st["wide_retries"] >= 1 and wall < 3.0, (st, wall)
         assert wall < 20, wall
         st = b.run()                                  # the hog is gone: pipelined again
         assert st["wide_retries"] == 0 and b.results()[0]["editDistance"] == want["editDistance"]
