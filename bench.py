@@ -12,8 +12,12 @@ Workloads (BASELINE.json `configs`):
   --config 5 (configs[4]): per GPU 10,000 1 kb pairs (3 % sub, 1 % ins, 1 % del), NW, TASK_PATH; both CIGAR
       formats of every op string are part of the parity check.
 A "step" is one pass of the device path over the whole resident batch (edlibAmdBatchRun: target encoding /
-buildPeq, every scan pass, merges, for PATH the storing scan + traceback + D2H of the op strings).  Inputs are
-resident in HBM before the timed region.
+buildPeq, every scan pass, merges; for PATH the storing scan + traceback).  Inputs are resident in HBM before the
+timed region.  Config 5 is a PATH workload -- its product is the op strings and their CIGARs ON THE HOST -- so its
+step is run + collection: edlibAmdBatchRun, then edlibAmdBatchResultsView (the results laid out on the device, one
+block copied to pinned host memory) and edlibAmdBatchCigarView for both formats, all inside the timed region; `value`
+and `ms_per_step` are that whole.  For the distance workloads (configs 2, 4) a step ends with the results resident
+in HBM and `collection` reports what bringing them over costs, once, beside it.
 
 --gpus N: one process per GPU.  Under torch.distributed.run (RANK set) this process is one rank; without it and
 with N > 1 bench.py re-executes itself under torch.distributed.run with N ranks on 127.0.0.1.  It refuses to
@@ -143,7 +147,7 @@ def cigars_of(flat):
     return b"".join(ext), b"".join(std)
 
 
-def cpu_baseline_and_parity(w, flat, sample_target):
+def cpu_baseline_and_parity(w, flat, sample_target, batch=None):
     """The reference on all host cores over a bounded sample of the batch (native thread pool), compared
     field by field with the GPU results of the same units."""
     from oracle import oracle as O
@@ -193,6 +197,12 @@ def cpu_baseline_and_parity(w, flat, sample_target):
             ext, std = cigars_of(flat)
             detail = {"op_bytes_equal": bool(same), "cigar_extended_equal": ext == ref["cigExt"],
                       "cigar_standard_equal": std == ref["cigStd"], "op_bytes": int(ga[-1])}
+            if batch is not None:                   # the batch-wide CIGARs (made on the device) against the reference's as well
+                dext, dstd = device_cigars(batch)
+                detail["batch_cigar_extended_equal"] = dext == ref["cigExt"]
+                detail["batch_cigar_standard_equal"] = dstd == ref["cigStd"]
+                detail["cigar_bytes"] = [len(dext), len(dstd)]
+                same = same and detail["batch_cigar_extended_equal"] and detail["batch_cigar_standard_equal"]
             if not (same and detail["cigar_extended_equal"] and detail["cigar_standard_equal"]):
                 bad[:] = True
     cells = float(np.sum((w["qoff"][1:] - w["qoff"][:-1])[sel].astype(np.float64) *
@@ -378,12 +388,52 @@ def measure_chromosome(repeat=2):
             "bit_exact": sum(1 for r in pairs if r["bit_exact"]), "checked": len(pairs)}
 
 
+def measure_collection(cfg_id, batch, ms_per_step):
+    """the collection on its own clock: the results view (+ both CIGAR views for the PATH workload, after one more run --
+    the timed steps have already collected theirs)"""
+    if cfg_id == 5:
+        batch.run()
+    tc = time.perf_counter()
+    flat = batch.results_flat(copy=False)
+    t1 = time.perf_counter()
+    if cfg_id == 5:
+        batch.cigars(True, copy=False); batch.cigars(False, copy=False)
+    t2 = time.perf_counter()
+    note = collection_note((t2 - tc) * 1e3, ms_per_step)
+    if cfg_id == 5:
+        note["what"] = ("edlibAmdBatchResultsView (device-made arrays, one block D2H: %.3f ms) + edlibAmdBatchCigarView x 2 (%.3f ms); "
+                        "ALREADY INSIDE ms_per_step for this config" % ((t1 - tc) * 1e3, (t2 - t1) * 1e3))
+        note["ms_per_step_plus_one_collection"] = ms_per_step
+        note["inside_step"] = True
+    return note, flat
+
+
 def collection_note(collect_ms, ms_per_step):
     """A step (`Batch.run()`) ends with the results resident in HBM; bringing them to the host (download, per-unit records,
     flat arrays) happens in `results_flat()`, once per call whatever the number of steps.  Reported beside the step so that
     the lazily collected paths (reads path, flat pair batches incl. their op strings) do not hide that work."""
     return {"results_flat_ms": round(collect_ms, 3), "ms_per_step_plus_one_collection": round(ms_per_step + collect_ms, 3),
             "what": "results_flat() after the timed steps: D2H of what run() left in HBM + per-unit records + flat arrays"}
+
+
+def run_step(cfg_id, batch):
+    """one timed step: the device pass; for the PATH workload also the collection of everything a caller gets"""
+    st = batch.run()
+    if cfg_id == 5:
+        batch.results_flat(copy=False)
+        batch.cigars(True, copy=False)
+        batch.cigars(False, copy=False)
+    return st
+
+
+def device_cigars(batch):
+    """both CIGAR formats of the batch as the concatenation of the strings (no terminators), made by the library over the
+    whole batch (edlibAmdBatchCigarView)"""
+    out = []
+    for extended in (True, False):
+        chars, _ = batch.cigars(extended, copy=False)
+        out.append(chars[chars != 0].tobytes())
+    return out
 
 
 def measure_secondary(cfg_id, device, torch, steps=5, warmup=2):
@@ -393,21 +443,18 @@ def measure_secondary(cfg_id, device, torch, steps=5, warmup=2):
     batch = make_batch(w, device)
     try:
         for _ in range(warmup):
-            batch.run()
+            run_step(cfg_id, batch)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         scan_ms, launches, st = 0.0, 0, None
         for _ in range(steps):
-            st = batch.run()
+            st = run_step(cfg_id, batch)
             scan_ms += st["scan_ms"]; launches += st["scan_launches"]
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        tc = time.perf_counter()
-        flat = batch.results_flat()
-        collect_ms = (time.perf_counter() - tc) * 1e3
         out = report(cfg_id, w, st, scan_ms, launches, steps, warmup, dt, st["cells"] * steps / dt / 1e9, 1, "weak")
-        out["collection"] = collection_note(collect_ms, out["ms_per_step"])
-        out["cpu_baseline"], out["parity_sample"] = cpu_baseline_and_parity(w, flat, w["n"])
+        out["collection"], flat = measure_collection(cfg_id, batch, out["ms_per_step"])
+        out["cpu_baseline"], out["parity_sample"] = cpu_baseline_and_parity(w, flat, w["n"], batch if cfg_id == 5 else None)
     finally:
         batch.close()
     return out
@@ -480,14 +527,14 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        batch.run()
+        run_step(args.config, batch)
     sync()
     t0 = time.perf_counter()
     scan_ms = 0.0
     launches = 0
     st = batch.stats()
     for _ in range(args.steps):
-        st = batch.run()
+        st = run_step(args.config, batch)
         scan_ms += st["scan_ms"]
         launches += st["scan_launches"]
     torch.cuda.synchronize()
@@ -505,13 +552,11 @@ def main():
         per_rank_ms = [x[0] for x in tl]
         devices = [x[1] for x in tl]
     flat = None
-    collect_ms = None
+    coll_note = None
     # (rank 0 also at world > 1: the line of a multi-rank run carries the reference baseline and the parity check of rank 0's
     # OWN shard -- taken after the timed region, while the other ranks wait at the closing barrier)
     if args.dump or (rank == 0 and not args.no_cpu_baseline):
-        tc = time.perf_counter()
-        flat = batch.results_flat()
-        collect_ms = (time.perf_counter() - tc) * 1e3
+        coll_note, flat = measure_collection(args.config, batch, round(dt_sync / max(1, args.steps) * 1e3, 2))
     if args.dump:
         total = units if args.strong else units * world
         full = gather_int_results(flat["editDistance"], total, dist, coll_dev)    # shard order = rank order
@@ -522,8 +567,10 @@ def main():
     if rank == 0:
         out = report(args.config, w, st, scan_ms, launches, max(1, args.steps), args.warmup, dt, value, world,
                      "strong" if args.strong else "weak")
-        if collect_ms is not None:
-            out["collection"] = collection_note(collect_ms, out["ms_per_step"])
+        if coll_note is not None:
+            if not coll_note.get("inside_step"):
+                coll_note["ms_per_step_plus_one_collection"] = round(out["ms_per_step"] + coll_note["results_flat_ms"], 3)
+            out["collection"] = coll_note
         out["per_rank_ms_per_step"] = per_rank_ms
         out["devices"] = devices
         out["devices_distinct"] = len(set(devices))
@@ -531,7 +578,7 @@ def main():
             out["dry_run_shared_gpu"] = True
         if not args.no_cpu_baseline:
             sample = args.parity_sample if args.parity_sample is not None else (20000 if args.config == 2 else w["n"])
-            base, parity = cpu_baseline_and_parity(w, flat, sample)
+            base, parity = cpu_baseline_and_parity(w, flat, sample, batch if args.config == 5 else None)
             if world > 1:
                 base["sample"] += "; rank 0's shard of a %d-rank run (the other ranks idle at the barrier meanwhile)" % world
                 parity["shard"] = "rank 0 of %d" % world

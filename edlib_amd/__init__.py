@@ -50,6 +50,14 @@ class BatchStats(C.Structure):            # edlib_amd.h EdlibAmdBatchStats
                 ("path", C.c_int), ("overflow_units", C.c_int), ("wide_retries", C.c_int)]
 
 
+class ResultsView(C.Structure):          # edlib_amd.h EdlibAmdResultsView
+    _fields_ = [("numUnits", C.c_int), ("status", C.POINTER(C.c_int)), ("editDistance", C.POINTER(C.c_int)),
+                ("numLocations", C.POINTER(C.c_int)), ("alphabetLength", C.POINTER(C.c_int)),
+                ("locOffsets", C.POINTER(C.c_longlong)), ("endLocations", C.POINTER(C.c_int)),
+                ("startLocations", C.POINTER(C.c_int)), ("alnOffsets", C.POINTER(C.c_longlong)),
+                ("alignment", C.POINTER(C.c_ubyte))]
+
+
 _lib = None
 
 
@@ -81,6 +89,8 @@ def lib():
         L.edlibAmdBatchRun.argtypes = [C.c_void_p]
         L.edlibAmdBatchResults.argtypes = [C.c_void_p, C.POINTER(AlignResult)]
         L.edlibAmdBatchResultsFlat.argtypes = [C.c_void_p] + [C.c_void_p] * 9
+        L.edlibAmdBatchResultsView.argtypes = [C.c_void_p, C.POINTER(ResultsView)]
+        L.edlibAmdBatchCigarView.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         L.edlibAmdFreeResults.argtypes = [C.POINTER(AlignResult), C.c_int]
         L.edlibAmdFreeResults.restype = None
         L.edlibAmdTrim.restype = None
@@ -316,33 +326,54 @@ class _Batch:
             out.append(d if raw else _nice_result(d))
         return out
 
-    def results_flat(self):
-        """Every field of every result as flat numpy arrays (edlibAmdBatchResultsFlat: no per-unit malloc):
+    def results_flat(self, copy=True):
+        """Every field of every result as flat numpy arrays (edlibAmdBatchResultsView: no per-unit malloc):
         status / editDistance / numLocations / alphabetLength [n], locOff [n+1] into ends / starts
-        (starts is None unless the task produced start locations), alnOff [n+1] into alignment (op bytes)."""
+        (starts is None unless the task produced start locations), alnOff [n+1] into alignment (op bytes, None unless the
+        task produced paths).  copy=False: views of the batch's own pinned memory, valid until its next run() / close()."""
         L = lib()
         n = self.n
-        st = np.empty(max(n, 1), dtype=np.int32); ed = np.empty(max(n, 1), dtype=np.int32)
-        nl = np.empty(max(n, 1), dtype=np.int32); al = np.empty(max(n, 1), dtype=np.int32)
-        loc = np.zeros(n + 1, dtype=np.int64); aln = np.zeros(n + 1, dtype=np.int64)
-        pe, ps, pa = C.c_void_p(), C.c_void_p(), C.c_void_p()
-        if L.edlibAmdBatchResultsFlat(self._h, st.ctypes.data, ed.ctypes.data, nl.ctypes.data, al.ctypes.data,
-                                      loc.ctypes.data, C.addressof(pe), C.addressof(ps), aln.ctypes.data,
-                                      C.addressof(pa)) != 0:
+        v = ResultsView()
+        if L.edlibAmdBatchResultsView(self._h, C.byref(v)) != 0:
             raise RuntimeError("edlib_amd: results failed: " + last_error())
 
-        def take(ptr, count, ctype, dtype):
-            out = None
-            if ptr.value:
-                out = (np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(count,)).astype(dtype, copy=True)
-                       if count else np.zeros(0, dtype=dtype))
-                L.libc.free(ptr)
-            return out
-        ends = take(pe, int(loc[-1]), C.c_int, np.int32)
-        starts = take(ps, int(loc[-1]), C.c_int, np.int32)
-        ops = take(pa, int(aln[-1]), C.c_ubyte, np.uint8)
-        return {"status": st[:n], "editDistance": ed[:n], "numLocations": nl[:n], "alphabetLength": al[:n],
-                "locOff": loc, "ends": ends, "starts": starts, "alnOff": aln, "alignment": ops}
+        def arr(ptr, count, dtype):
+            if not ptr:
+                return None
+            if count == 0:
+                return np.zeros(0, dtype=dtype)
+            a = np.ctypeslib.as_array(ptr, shape=(count,))
+            return a.copy() if copy else a
+        loc = arr(v.locOffsets, n + 1, np.int64)
+        aln = arr(v.alnOffsets, n + 1, np.int64)
+        nloc, naln = int(loc[-1]), int(aln[-1])
+        ends = arr(v.endLocations, nloc, np.int32)
+        starts = arr(v.startLocations, nloc, np.int32)
+        ops = arr(v.alignment, naln, np.uint8)
+        if ops is None and naln == 0:
+            ops = np.zeros(0, dtype=np.uint8)
+        return {"status": arr(v.status, n, np.int32), "editDistance": arr(v.editDistance, n, np.int32),
+                "numLocations": arr(v.numLocations, n, np.int32), "alphabetLength": arr(v.alphabetLength, n, np.int32),
+                "locOff": loc, "ends": ends if ends is not None else np.zeros(0, dtype=np.int32), "starts": starts,
+                "alnOff": aln, "alignment": ops}
+
+    def cigars(self, extended=True, copy=True):
+        """edlibAlignmentToCigar over every op string of the last run (edlibAmdBatchCigarView; made on the device for a
+        batch of short pairs): (chars, off) -- the NUL-terminated strings one after the other as a uint8 array, and the
+        int64 offset of every string (off[n] = all bytes)."""
+        L = lib()
+        pc, po = C.c_void_p(), C.c_void_p()
+        if L.edlibAmdBatchCigarView(self._h, 1 if extended else 0, C.byref(pc), C.byref(po)) != 0:
+            raise RuntimeError("edlib_amd: cigars failed: " + last_error())
+        off = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_longlong)), shape=(self.n + 1,))
+        total = int(off[-1])
+        chars = np.ctypeslib.as_array(C.cast(pc, C.POINTER(C.c_ubyte)), shape=(max(total, 1),))[:total]
+        return (chars.copy(), off.copy()) if copy else (chars, off)
+
+    def cigar_list(self, extended=True):
+        chars, off = self.cigars(extended, copy=False)
+        raw = chars.tobytes()
+        return [raw[int(off[i]):int(off[i + 1]) - 1].decode() for i in range(self.n)]
 
     def results_arrays(self):
         """editDistance / numLocations / first end location / per-unit end lists (kept for older callers;

@@ -162,6 +162,16 @@ EDLIB_API int edlibAmdBatchResultsFlat(EdlibAmdBatch* b, int* status, int* editD
                                           startLocations, alnOffsets, alignment); }) ? EDLIB_STATUS_ERROR : EDLIB_STATUS_OK;
 }
 
+EDLIB_API int edlibAmdBatchResultsView(EdlibAmdBatch* b, EdlibAmdResultsView* out) {
+    if (!b || !out) { set_error("null argument"); return EDLIB_STATUS_ERROR; }
+    return guarded("edlibAmdBatchResultsView", 1, [&] { return b->impl.resultsView(out); }) ? EDLIB_STATUS_ERROR : EDLIB_STATUS_OK;
+}
+
+EDLIB_API int edlibAmdBatchCigarView(EdlibAmdBatch* b, EdlibCigarFormat cigarFormat, const char** chars, const long long** offsets) {
+    if (!b) { set_error("null argument"); return EDLIB_STATUS_ERROR; }
+    return guarded("edlibAmdBatchCigarView", 1, [&] { return b->impl.cigarView((int)cigarFormat, chars, offsets); }) ? EDLIB_STATUS_ERROR : EDLIB_STATUS_OK;
+}
+
 EDLIB_API void edlibAmdFreeResults(EdlibAlignResult* results, int n) {
     if (!results) return;
     for (int i = 0; i < n; ++i) {

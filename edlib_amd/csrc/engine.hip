@@ -15,6 +15,7 @@
 // (solveGlobalDistances).  Thresholds only steer work: every result is a function of the full DP
 // matrix, so the user's k merely filters it (SURVEY.md §7 "results are band-independent").
 #include "engine.hpp"
+#include "flat_results.hpp"
 #include <sched.h>
 
 #if defined(__x86_64__)
@@ -394,95 +395,6 @@ seed_thresholds_kernel(int* __restrict__ kinit, const int* __restrict__ best, co
     if (i < n && cnt[i] > 0 && best[i] < kinit[i]) kinit[i] = best[i];
 }
 
-// flat pair path: how many units have more end locations than their list keeps (they need the exact second pass)
-__global__ void __launch_bounds__(256)
-count_over_kernel(const int* __restrict__ count, int n, int cap, int* __restrict__ counter)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && count[i] > cap) atomicAdd(counter, 1);
-}
-
-// flat pair path, NW with the column store: units whose band level failed (score above the level's threshold while a
-// larger one was still allowed)
-__global__ void __launch_bounds__(256)
-count_failed_levels_kernel(const PairDesc* __restrict__ descs, const int* __restrict__ score, int n, int kcap, int* __restrict__ counter)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const PairDesc d = descs[i];
-    const int whole = d.qlen > d.tlen ? d.qlen : d.tlen;
-    if (score[i] > d.kinit && d.kinit < whole && d.kinit < kcap) atomicAdd(counter, 1);
-}
-
-// flat pair path, HW start locations (reference edlib.cpp:228-266): every end location e of every unit gets a reverse
-// prefix scan -- reversed query against the reversed prefix target[0..e], threshold = the distance, at most m + distance
-// columns (:253-257).  One thread per unit writes the descriptors of its (at most posCap) scans into slots it takes from
-// a counter; slotOf[u * posCap + j] remembers which scan answers location j.
-__global__ void __launch_bounds__(256)
-flat_start_descs_kernel(const PairDesc* __restrict__ descs, const int* __restrict__ score, const int* __restrict__ count,
-                        const int* __restrict__ pos, int n, int posCap, long long revPeqBase, int ring,
-                        PairDesc* __restrict__ out, int* __restrict__ slotOf, int* __restrict__ counter, int cap)
-{
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= n) return;
-    const PairDesc d = descs[u];
-    const int ed = score[u];
-    int c = ed < 0 ? 0 : count[u];
-    c = c > posCap ? posCap : c;
-    for (int j = 0; j < posCap; ++j) {
-        int slot = -1;
-        if (j < c) {
-            const int e = pos[(long long)u * posCap + j];
-            slot = atomicAdd(counter, 1);
-            if (slot < cap) {
-                PairDesc x{};
-                x.qoff = d.qoff + d.qlen - 1; x.qstep = -1; x.qlen = d.qlen;
-                x.toff = d.toff + e; x.tstep = -1;
-                const long long win = (long long)e + 1 < (long long)d.qlen + ed ? (long long)e + 1 : (long long)d.qlen + ed;
-                x.tlen = (int)win; x.kinit = ed;
-                x.peqOff = revPeqBase + d.peqOff;
-                x.posCap = 0; x.posOff = 0; x.storeOff = 0; x.auxOff = 0; x.colOff = -1; x.bandT = 0; x.skip = 0; x.ring = ring;
-                out[slot] = x;
-            } else slot = -1;
-        }
-        slotOf[(long long)u * posCap + j] = slot;
-    }
-}
-// start = e - (last position of the reverse scan)   (edlib.cpp:260)
-__global__ void __launch_bounds__(256)
-flat_starts_kernel(const int* __restrict__ slotOf, const int* __restrict__ pos, const int* __restrict__ lastOfScan, long long total,
-                   int* __restrict__ starts)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int s = slotOf[i];
-    starts[i] = s < 0 ? 0 : pos[i] - lastOfScan[s];
-}
-// flat pair path, TASK_PATH of SHW / HW units (edlib.cpp:276-289): NW of the query against target[start0 .. end0] of the
-// FIRST location, with the column store.  A unit without a solution, or whose first location is the empty prefix (-1:
-// the host writes its m inserts), gets an inactive descriptor (threshold below |T - m|).
-__global__ void __launch_bounds__(256)
-flat_path_descs_kernel(const PairDesc* __restrict__ descs, const int* __restrict__ score, const int* __restrict__ count,
-                       const int* __restrict__ pos, const int* __restrict__ starts, int n, int posCap,
-                       const long long* __restrict__ storeBase, int ring, PairDesc* __restrict__ out)
-{
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= n) return;
-    PairDesc x = descs[u];
-    const int m = x.qlen, ed = score[u];
-    const int nb = (m + 63) >> 6, W = 64 * nb - m;
-    const bool lead = W > 0 && ed == m;                              // position -1 comes first
-    x.posCap = 0; x.posOff = 0; x.ring = ring; x.storeOff = storeBase[u]; x.colOff = -1; x.bandT = 0; x.skip = 0; x.auxOff = 0;
-    if (ed < 0 || count[u] <= 0 || lead) { x.tlen = 1; x.kinit = -1; }
-    else {
-        const int e0 = pos[(long long)u * posCap];
-        const int s0 = starts ? starts[(long long)u * posCap] : 0;
-        x.toff += s0; x.tlen = e0 - s0 + 1;
-        x.kinit = m > x.tlen ? m : x.tlen;                           // every block sits on the ring: the whole matrix
-    }
-    out[u] = x;
-}
-
 // --------------------------------------------------------------- Batch: init
 
 Batch::~Batch() {
@@ -741,13 +653,13 @@ void finalize_semiglobal(UnitResult& r, int kcfg, int m, int best, const int* po
 }
 
 // a recycled record of the run before last, as a fresh one
-static inline void blank_record(UnitResult& r) {
+void blank_record(UnitResult& r) {
     r.status = EDLIB_STATUS_OK; r.editDistance = -1; r.alphabetLength = 0;
     r.hasEnds = r.hasStarts = r.hasAlignment = false;
     r.ends.clear(); r.starts.clear(); r.opsView = nullptr; r.opsViewLen = 0;
 }
 
-static void finalize_global(UnitResult& r, int kcfg, int mode, int T, int score) {
+void finalize_global(UnitResult& r, int kcfg, int mode, int T, int score) {
     if (kcfg >= 0 && score > kcfg) { r.editDistance = -1; r.hasEnds = false; return; }   // edlib.cpp:744-747, 917
     r.editDistance = score;
     if (mode == EDLIB_MODE_NW) { r.hasEnds = true; r.ends.assign(1, T - 1); }              // edlib.cpp:221-225
@@ -1185,11 +1097,11 @@ int Batch::collectGroup(ReadGroup& g, std::vector<UnitResult>& res)
 
 // ------------------------------------------------------ block-per-lane path
 
-static const int kPosCap = 16;
+
 
 // Row length of the LDS-resident Peq of the ring kernels: the next power of two up to 32 blocks, a
 // multiple of 32 above (bank-conflict-free lookups, scan_pairs_ring_kernel)
-static int peq_row_stride(long long nb) {
+int peq_row_stride(long long nb) {
     if (nb > 32) return (int)std::min<long long>((nb + 31) / 32 * 32, 1 << 20);
     int s = 1; while (s < nb) s <<= 1;
     return s;
@@ -1565,6 +1477,8 @@ int Batch::alphabetLengthsBegin()
                        d_qpool_.p, d_qoff_.p, d_tpool_.p, d_toff_.p, shared_ ? 1 : 0, d_presence_.p,
                        d_alphaIdx_.p, d_alphaOut_.p);
     EDLIB_AMD_HIP(hipGetLastError());
+    EDLIB_AMD_HIP(evB_.create());
+    EDLIB_AMD_HIP(hipEventRecord(evB_.e, side_));                   // (a flat batch's collection reads d_alphaOut_ on stream_ behind this)
     EDLIB_AMD_HIP(hipMemcpyAsync(alphaPin_.p, d_alphaOut_.p, n * sizeof(int), hipMemcpyDeviceToHost, side_));
     alphaPending_ = true;
     return 0;
@@ -1598,378 +1512,9 @@ int Batch::alphabetLengthsEnd(std::vector<UnitResult>& res)
 }
 
 
-// ------------------------------------------------------------ flat pair path
-
-static const int kFlatPosCap = 16;
-static bool needs_hirschberg(int m, int T);       // (edlib.cpp:1188-1190, defined with the Hirschberg levels below)
-
-// Batches of short independent pairs (the verification step of a seed-and-extend mapper: 262,144 x 150 bp in 400 bp
-// windows) were host-bound: every run rebuilt 88-byte descriptors for every unit, uploaded them, downloaded 16 end
-// positions per unit and walked 160-byte records five times (22..28 ns per pair with the kernels a fifth of it).  When
-// every unit is a pair of at most 16 blocks and only distances are asked for, nothing about the descriptors depends on a
-// run: they are built once, here, and stay resident; a run is Peq build + one ring scan (whole matrix on a 4- or 16-lane
-// ring: exact for any distance, no levels) + a census of overflowing end-location lists, and the results stay in HBM until
-// results() asks for them -- the lazy form the reads path has had since round 1.
-PairDesc Batch::flatDesc(int u) const
-{
-    const int mode = (int)cfg_.mode;
-    const int scanMode = (mode == EDLIB_MODE_HW || mode == EDLIB_MODE_SHW) ? mode : EDLIB_MODE_NW;
-    const int m = qlen(u);
-    const int T = scanMode == EDLIB_MODE_SHW ? (int)std::min<long long>(tlen(u), 2LL * m + 1) : tlen(u);   // (SHW: nothing beyond column 2m can tie the best)
-    PairDesc x{};
-    x.qoff = qoff_[u]; x.toff = tbase(u); x.qlen = m; x.tlen = T; x.qstep = 1; x.tstep = 1;
-    // NW: the ring holds every block of the unit, so the band is the whole matrix (threshold max(m, T)); SHW / HW:
-    // columns scoring <= min(k, m) are end-location candidates
-    x.kinit = scanMode == EDLIB_MODE_NW ? std::max(m, T) : ((cfg_.k < 0 || cfg_.k > m) ? m : cfg_.k);
-    // NW with the column store (flatNwStore_): the first level of solveGlobalDistances -- the ring's band limit for a unit of
-    // more blocks than the ring has lanes, capped by the caller's k; a unit that fails it sends the run to the general path
-    if (flatNwStore_) {
-        const int kcap = cfg_.k >= 0 ? cfg_.k : 0x3fffffff;
-        x.kinit = std::min(kcap, (m + 63) / 64 <= flatRing_ ? std::max(m, T) : ring_max_k(flatRing_));
-    }
-    x.peqOff = flatPeqOff_[u];
-    x.storeOff = 0; x.auxOff = 0; x.posCap = scanMode == EDLIB_MODE_NW ? 0 : kFlatPosCap; x.posOff = (long long)u * kFlatPosCap;
-    x.colOff = -1; x.bandT = 0; x.skip = 0; x.ring = flatRing_;
-    return x;
-}
-
-int Batch::initFlatPairs()
-{
-    static const bool on = !(getenv("EDLIB_AMD_FLATPAIRS") && getenv("EDLIB_AMD_FLATPAIRS")[0] == '0');
-    flatPairs_ = false;
-    static const bool locOn = !(getenv("EDLIB_AMD_FLATLOC") && getenv("EDLIB_AMD_FLATLOC")[0] == '0');
-    flatStarts_ = flatPaths_ = flatNwStore_ = false;
-    if (!on || !emptyUnits_.empty() || !groups_.empty() || !longUnits_.empty()) return 0;
-    if (cfg_.task != EDLIB_TASK_DISTANCE && !locOn) return 0;
-    if ((int)pairUnits_.size() != n_ || n_ < 1024) return 0;       // (a handful of units: the zero-copy path of solveChunk)
-    const int mode = (int)cfg_.mode;
-    if (mode != EDLIB_MODE_NW && mode != EDLIB_MODE_SHW && mode != EDLIB_MODE_HW) return 0;
-    const int scanMode = (mode == EDLIB_MODE_HW || mode == EDLIB_MODE_SHW) ? mode : EDLIB_MODE_NW;
-    int maxBlocks = 0, maxT = 0;
-    for (int u = 0; u < n_; ++u) { maxBlocks = std::max(maxBlocks, (qlen(u) + 63) / 64); maxT = std::max(maxT, tlen(u)); }
-    // (long targets: the general path cuts HW targets into segments when the batch alone does not fill the chip)
-    if (maxBlocks > 16 || maxT > 65536) return 0;
-    flatMaxBlocks_ = maxBlocks;
-    flatRing_ = maxBlocks <= 4 ? 4 : 16;
-    // window of a unit's alignment: the whole target (NW), at most 2 m + 1 columns (SHW: the scan stops there; HW: m + distance)
-    auto window = [&](int u) { return scanMode == EDLIB_MODE_NW ? tlen(u) : (int)std::min<long long>(tlen(u), 2LL * qlen(u) + 1); };
-    if (cfg_.task == EDLIB_TASK_PATH) {
-        // paths stay flat when every unit's store fits a 4-lane ring: SHW / HW queries of at most 4 blocks (whole matrix of
-        // the window), NW pairs of up to 16 blocks inside the first band level; never in the Hirschberg regime (:1188-1190)
-        if (scanMode != EDLIB_MODE_NW && maxBlocks > 4) return 0;
-        for (int u = 0; u < n_; ++u) if (needs_hirschberg(qlen(u), window(u))) return 0;
-        // (the resident column store and op slots are upper bounds per unit: a batch whose bounds add up to more than a
-        // slice of the HBM keeps the general path, which sizes them per chunk)
-        long long storeBytes = 0, opBytes = 0;
-        for (int u = 0; u < n_; ++u) {
-            storeBytes += 16LL * ring_store_entries(4, qlen(u), window(u));
-            opBytes += qlen(u) + window(u) + 8;
-        }
-        if (storeBytes > (32LL << 30) || opBytes > (8LL << 30)) return 0;
-        flatPaths_ = true;
-        flatNwStore_ = scanMode == EDLIB_MODE_NW;
-        flatRing_ = 4;
-    }
-    flatStarts_ = cfg_.task != EDLIB_TASK_DISTANCE && mode == EDLIB_MODE_HW;
-    PinBuf pin;
-    EDLIB_AMD_HIP(pin.alloc((size_t)n_ * sizeof(PairDesc)));
-    PairDesc* d = reinterpret_cast<PairDesc*>(pin.p);
-    long long peqWords = 0;
-    flatPeqOff_.resize((size_t)n_);
-    for (int u = 0; u < n_; ++u) {
-        const long long nb = (qlen(u) + 63) / 64;
-        flatPeqOff_[u] = peqWords; peqWords += nb * tab_.sigmaT;
-        d[u] = flatDesc(u);
-    }
-    EDLIB_AMD_HIP(d_flatDescs_.alloc((size_t)n_));
-    EDLIB_AMD_HIP(hipMemcpyAsync(d_flatDescs_.p, d, (size_t)n_ * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
-    EDLIB_AMD_HIP(d_peq64_.ensure((size_t)peqWords));
-    EDLIB_AMD_HIP(d_flatOut3_.alloc(3 * (size_t)n_));
-    EDLIB_AMD_HIP(d_flatPos_.alloc(scanMode == EDLIB_MODE_NW ? 1 : (size_t)n_ * kFlatPosCap));
-    EDLIB_AMD_HIP(d_flatCensus_.alloc(2));
-    EDLIB_AMD_HIP(h_flatCensus_.alloc(2 * sizeof(int)));
-    if (flatStarts_) {
-        // reversed-query Peq rows (same layout as the forward ones, behind them) and their builder's descriptors
-        flatRevPeqBase_ = peqWords;
-        EDLIB_AMD_HIP(d_peq64_.ensure((size_t)(2 * peqWords)));
-        PinBuf rp;
-        EDLIB_AMD_HIP(rp.alloc((size_t)n_ * sizeof(PairDesc)));
-        PairDesc* r = reinterpret_cast<PairDesc*>(rp.p);
-        for (int u = 0; u < n_; ++u) { r[u] = d[u]; r[u].qoff = d[u].qoff + d[u].qlen - 1; r[u].qstep = -1; r[u].peqOff = flatRevPeqBase_ + d[u].peqOff; }
-        EDLIB_AMD_HIP(d_flatRevDescs_.alloc((size_t)n_));
-        EDLIB_AMD_HIP(hipMemcpyAsync(d_flatRevDescs_.p, r, (size_t)n_ * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
-        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-        flatStartCap_ = 2 * (size_t)n_ + 1024;
-        EDLIB_AMD_HIP(d_flatStartDescs_.alloc(flatStartCap_));
-        EDLIB_AMD_HIP(d_flatStartOut3_.alloc(3 * flatStartCap_));
-        EDLIB_AMD_HIP(d_flatSlotOf_.alloc((size_t)n_ * kFlatPosCap));
-        EDLIB_AMD_HIP(d_flatStartsOut_.alloc((size_t)n_ * kFlatPosCap));
-    }
-    if (flatPaths_) {
-        // op slots (m + window + 8 bytes per unit, filled from the back) and store ranges (a 4-lane ring over the window):
-        // upper bounds that depend on the batch only, laid out once
-        flatOpsOffHost_.assign((size_t)n_ + 1, 0);
-        std::vector<long long> storeBase((size_t)n_);
-        long long entries = 0;
-        for (int u = 0; u < n_; ++u) {
-            flatOpsOffHost_[u + 1] = flatOpsOffHost_[u] + qlen(u) + window(u) + 8;
-            storeBase[u] = entries; entries += ring_store_entries(flatRing_, qlen(u), window(u));
-        }
-        flatOpsTotal_ = flatOpsOffHost_[n_];
-        EDLIB_AMD_HIP(d_flatOpsOff_.alloc((size_t)n_ + 1)); EDLIB_AMD_HIP(d_flatStoreBase_.alloc((size_t)n_));
-        EDLIB_AMD_HIP(hipMemcpyAsync(d_flatOpsOff_.p, flatOpsOffHost_.data(), ((size_t)n_ + 1) * sizeof(long long), hipMemcpyHostToDevice, stream_));
-        EDLIB_AMD_HIP(hipMemcpyAsync(d_flatStoreBase_.p, storeBase.data(), (size_t)n_ * sizeof(long long), hipMemcpyHostToDevice, stream_));
-        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-        EDLIB_AMD_HIP(d_flatOps_.alloc((size_t)flatOpsTotal_)); EDLIB_AMD_HIP(d_flatOpsLen_.alloc((size_t)n_));
-        EDLIB_AMD_HIP(d_store_.ensure((size_t)entries));
-        if (flatNwStore_) {
-            // the phase-1 descriptors ARE the storing scans: give them their store ranges
-            for (int u = 0; u < n_; ++u) d[u].storeOff = storeBase[u];
-            EDLIB_AMD_HIP(hipMemcpyAsync(d_flatDescs_.p, d, (size_t)n_ * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
-            EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-        } else {
-            EDLIB_AMD_HIP(d_flatPathDescs_.alloc((size_t)n_)); EDLIB_AMD_HIP(d_flatPathOut3_.alloc(3 * (size_t)n_));
-        }
-    }
-    // the word-steps of a run over the resident descriptors never change: counted here, once
-    {
-        unsigned long long* ctr = ringStepsCounter();
-        if (!ctr) return 1;
-        EDLIB_AMD_HIP(hipMemsetAsync(ctr, 0, sizeof(unsigned long long), stream_));
-        EDLIB_AMD_HIP(launch_count_ring_steps(d_flatDescs_.p, n_, scanMode, 1, ctr, stream_));
-        EDLIB_AMD_HIP(hipMemcpyAsync(h_ringSteps_.p, ctr, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
-    }
-    EDLIB_AMD_HIP(hipStreamSynchronize(stream_));                // `pin` dies here
-    flatWordSteps_ = (long long)*reinterpret_cast<unsigned long long*>(h_ringSteps_.p);
-    ringStepsUsed_ = false;
-    flatPairs_ = true;
-    return 0;
-}
-
-int Batch::runPairsFlat(bool& overflowed, bool& fellBack)
-{
-    fellBack = false;
-    const int mode = (int)cfg_.mode;
-    const int scanMode = (mode == EDLIB_MODE_HW || mode == EDLIB_MODE_SHW) ? mode : EDLIB_MODE_NW;
-    stats.path |= 2;
-    EDLIB_AMD_HIP(uploadEq8());
-    EDLIB_AMD_HIP(launch_build_peq_pairs(d_flatDescs_.p, n_, d_qpool_.p, d_eq8_.p, d_idToByte_.p, tab_.sigmaT, d_peq64_.p, stream_));
-    PairScanArgs a{};
-    a.descs = d_flatDescs_.p; a.numUnits = n_; a.qpool = d_qpool_.p; a.tpool = d_tpool_.p;
-    a.tlut = d_tlut_.p; a.sigmaT = tab_.sigmaT; a.peq = d_peq64_.p; a.aux = nullptr;
-    a.peqRowStride = peq_row_stride(std::max(flatRing_, flatMaxBlocks_));
-    a.peqFullStride = (int)std::min<long long>((long long)a.peqRowStride * tab_.sigmaT, 1 << 20);
-    a.store = flatNwStore_ ? d_store_.p : nullptr;
-    a.outScore = d_flatOut3_.p; a.outCount = d_flatOut3_.p + n_; a.outLast = d_flatOut3_.p + 2 * (size_t)n_; a.posPool = d_flatPos_.p;
-    a.wordSteps = nullptr;
-    stats.word_steps += flatWordSteps_;
-    scanTimerStart();
-    EDLIB_AMD_HIP(launch_scan_pairs_ring(flatRing_, scanMode, flatNwStore_, a, stream_));
-    scanTimerStop();
-    overflowed = false;
-    if (flatNwStore_) {
-        // NW paths: the distance scan was the storing scan (one band level); walk it, and see whether every unit got its answer
-        TracebackArgs tb{};
-        tb.descs = d_flatDescs_.p; tb.numUnits = n_; tb.score = d_flatOut3_.p; tb.store = d_store_.p;
-        tb.ops = d_flatOps_.p; tb.opsOff = d_flatOpsOff_.p; tb.opsLen = d_flatOpsLen_.p;
-        EDLIB_AMD_HIP(launch_traceback(tb, stream_));
-        EDLIB_AMD_HIP(hipMemsetAsync(d_flatCensus_.p, 0, 2 * sizeof(int), stream_));
-        hipLaunchKernelGGL(count_failed_levels_kernel, dim3((n_ + 255) / 256), dim3(256), 0, stream_, d_flatDescs_.p, d_flatOut3_.p, n_,
-                           cfg_.k >= 0 ? cfg_.k : 0x3fffffff, d_flatCensus_.p);
-        EDLIB_AMD_HIP(hipMemcpyAsync(h_flatCensus_.p, d_flatCensus_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
-        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-        if (*reinterpret_cast<const int*>(h_flatCensus_.p) > 0) { fellBack = true; return 0; }     // some unit needs the next level: the general path has them
-        return 0;
-    }
-    if (scanMode != EDLIB_MODE_NW) {
-        EDLIB_AMD_HIP(hipMemsetAsync(d_flatCensus_.p, 0, sizeof(int), stream_));
-        hipLaunchKernelGGL(count_over_kernel, dim3((n_ + 255) / 256), dim3(256), 0, stream_, d_flatOut3_.p + n_, n_, kFlatPosCap, d_flatCensus_.p);
-        EDLIB_AMD_HIP(hipMemcpyAsync(h_flatCensus_.p, d_flatCensus_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
-        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-        const int novf = *reinterpret_cast<const int*>(h_flatCensus_.p);
-        flatOvfUnit_.clear(); flatOvfOff_.assign(1, 0); flatOvfPos_.clear();
-        if (novf > 0) {
-            // exact second pass for the (rare) units with more end locations than a list keeps: their best score is already
-            // exact, so a scan with threshold = best and a list of the right size finds every location (strip kernel)
-            const size_t n = (size_t)n_;
-            PinBuf sc; EDLIB_AMD_HIP(sc.alloc(2 * n * sizeof(int)));
-            EDLIB_AMD_HIP(hipMemcpyAsync(sc.p, d_flatOut3_.p, 2 * n * sizeof(int), hipMemcpyDeviceToHost, stream_));
-            EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-            const int* score = reinterpret_cast<const int*>(sc.p); const int* count = score + n;
-            std::vector<PairDesc> d2;
-            for (int u = 0; u < n_; ++u)
-                if (count[u] > kFlatPosCap) {
-                    PairDesc x = flatDesc(u);
-                    x.kinit = score[u]; x.posCap = count[u]; x.posOff = flatOvfOff_.back(); x.ring = 0;
-                    d2.push_back(x); flatOvfUnit_.push_back(u); flatOvfOff_.push_back(flatOvfOff_.back() + count[u]);
-                }
-            DevBuf<PairDesc> dd; DevBuf<int> pool2, s2;
-            EDLIB_AMD_HIP(dd.alloc(d2.size())); EDLIB_AMD_HIP(pool2.alloc((size_t)flatOvfOff_.back())); EDLIB_AMD_HIP(s2.alloc(3 * d2.size()));
-            EDLIB_AMD_HIP(hipMemcpyAsync(dd.p, d2.data(), d2.size() * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
-            PairScanArgs a2 = a;
-            a2.descs = dd.p; a2.numUnits = (int)d2.size(); a2.posPool = pool2.p;
-            a2.outScore = s2.p; a2.outCount = s2.p + d2.size(); a2.outLast = s2.p + 2 * d2.size();
-            scanTimerStart();
-            EDLIB_AMD_HIP(launch_scan_pairs(scanMode, false, a2, stream_));
-            scanTimerStop();
-            flatOvfPos_.resize((size_t)flatOvfOff_.back());
-            EDLIB_AMD_HIP(hipMemcpyAsync(flatOvfPos_.data(), pool2.p, flatOvfPos_.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
-            EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-            stats.overflow_units += (int)d2.size();
-            for (const PairDesc& x : d2) stats.word_steps += 2LL * ((x.qlen + 63) / 64) * x.tlen;
-        }
-    }
-    if (flatStarts_ || flatPaths_) return runFlatStartsAndPaths(fellBack);
-    return 0;
-}
-
-// Phases 2 and 3 of a flat SHW / HW batch (reference edlib.cpp:228-289), everything on the device: descriptors of the
-// reverse prefix scans written by a kernel from the phase-1 results (HW), one ring scan over them, the starts; then one
-// storing NW scan per unit over its first location's window + the traceback into the resident op slots.
-int Batch::runFlatStartsAndPaths(bool& fellBack)
-{
-    const int mode = (int)cfg_.mode;
-    const int* score = d_flatOut3_.p; const int* count = d_flatOut3_.p + n_;
-    PairScanArgs a{};
-    a.qpool = d_qpool_.p; a.tpool = d_tpool_.p; a.tlut = d_tlut_.p; a.sigmaT = tab_.sigmaT; a.peq = d_peq64_.p; a.aux = nullptr;
-    a.peqRowStride = peq_row_stride(std::max(flatRing_, flatMaxBlocks_));
-    a.peqFullStride = (int)std::min<long long>((long long)a.peqRowStride * tab_.sigmaT, 1 << 20);
-    a.posPool = d_flatPos_.p; a.wordSteps = nullptr;
-    if (flatStarts_) {
-        EDLIB_AMD_HIP(hipMemsetAsync(d_flatCensus_.p, 0, 2 * sizeof(int), stream_));
-        hipLaunchKernelGGL(flat_start_descs_kernel, dim3((n_ + 255) / 256), dim3(256), 0, stream_, d_flatDescs_.p, score, count, d_flatPos_.p,
-                           n_, kFlatPosCap, flatRevPeqBase_, flatRing_, d_flatStartDescs_.p, d_flatSlotOf_.p, d_flatCensus_.p, (int)flatStartCap_);
-        EDLIB_AMD_HIP(hipMemcpyAsync(h_flatCensus_.p, d_flatCensus_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
-        // (the reversed queries' Peq rows do not depend on the count: built while it travels)
-        EDLIB_AMD_HIP(launch_build_peq_pairs(d_flatRevDescs_.p, n_, d_qpool_.p, d_eq8_.p, d_idToByte_.p, tab_.sigmaT, d_peq64_.p, stream_));
-        EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-        const int nscan = *reinterpret_cast<const int*>(h_flatCensus_.p);
-        if ((size_t)nscan > flatStartCap_) { fellBack = true; return 0; }
-        if (nscan > 0) {
-            PairScanArgs b = a;
-            b.descs = d_flatStartDescs_.p; b.numUnits = nscan; b.store = nullptr;
-            b.outScore = d_flatStartOut3_.p; b.outCount = d_flatStartOut3_.p + flatStartCap_; b.outLast = d_flatStartOut3_.p + 2 * flatStartCap_;
-            scanTimerStart();
-            EDLIB_AMD_HIP(launch_scan_pairs_ring(flatRing_, EDLIB_MODE_SHW, false, b, stream_));
-            scanTimerStop();
-        }
-        const long long total = (long long)n_ * kFlatPosCap;
-        hipLaunchKernelGGL(flat_starts_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, d_flatSlotOf_.p, d_flatPos_.p,
-                           d_flatStartOut3_.p + 2 * flatStartCap_, total, d_flatStartsOut_.p);
-        EDLIB_AMD_HIP(hipGetLastError());
-    }
-    if (flatPaths_ && !flatNwStore_) {
-        hipLaunchKernelGGL(flat_path_descs_kernel, dim3((n_ + 255) / 256), dim3(256), 0, stream_, d_flatDescs_.p, score, count, d_flatPos_.p,
-                           mode == EDLIB_MODE_HW ? d_flatStartsOut_.p : nullptr, n_, kFlatPosCap, d_flatStoreBase_.p, flatRing_, d_flatPathDescs_.p);
-        PairScanArgs b = a;
-        b.descs = d_flatPathDescs_.p; b.numUnits = n_; b.store = d_store_.p;
-        b.outScore = d_flatPathOut3_.p; b.outCount = d_flatPathOut3_.p + n_; b.outLast = d_flatPathOut3_.p + 2 * (size_t)n_;
-        scanTimerStart();
-        EDLIB_AMD_HIP(launch_scan_pairs_ring(flatRing_, EDLIB_MODE_NW, true, b, stream_));
-        scanTimerStop();
-        TracebackArgs tb{};
-        tb.descs = d_flatPathDescs_.p; tb.numUnits = n_; tb.score = d_flatPathOut3_.p; tb.store = d_store_.p;
-        tb.ops = d_flatOps_.p; tb.opsOff = d_flatOpsOff_.p; tb.opsLen = d_flatOpsLen_.p;
-        EDLIB_AMD_HIP(launch_traceback(tb, stream_));
-    }
-    return 0;
-}
-
-int Batch::collectPairsFlat(std::vector<UnitResult>& res)
-{
-    const int mode = (int)cfg_.mode;
-    const int scanMode = (mode == EDLIB_MODE_HW || mode == EDLIB_MODE_SHW) ? mode : EDLIB_MODE_NW;
-    const size_t n = (size_t)n_, npos = scanMode == EDLIB_MODE_NW ? 0 : n * kFlatPosCap;
-    PinBuf stage;
-    EDLIB_AMD_HIP(stage.alloc((3 * n + npos) * sizeof(int)));
-    int* h = reinterpret_cast<int*>(stage.p);
-    EDLIB_AMD_HIP(hipMemcpyAsync(h, d_flatOut3_.p, 3 * n * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    if (npos) EDLIB_AMD_HIP(hipMemcpyAsync(h + 3 * n, d_flatPos_.p, npos * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-    const int* score = h; const int* count = h + n; const int* pos = h + 3 * n;
-    // start locations / op strings of a flat LOC / PATH batch: downloaded now, into staging the records may point into
-    const bool wantStarts = cfg_.task != EDLIB_TASK_DISTANCE;
-    const int* starts = nullptr; const int* opsLen = nullptr; const uint8_t* ops = nullptr;
-    PinBuf stageStarts;
-    if (flatStarts_) {
-        EDLIB_AMD_HIP(stageStarts.alloc(n * kFlatPosCap * sizeof(int)));
-        EDLIB_AMD_HIP(hipMemcpyAsync(stageStarts.p, d_flatStartsOut_.p, n * kFlatPosCap * sizeof(int), hipMemcpyDeviceToHost, stream_));
-        starts = reinterpret_cast<const int*>(stageStarts.p);
-    }
-    if (flatPaths_) {
-        auto blk = std::make_shared<PinBuf>();
-        EDLIB_AMD_HIP(blk->alloc((size_t)flatOpsTotal_ + n * sizeof(int)));
-        EDLIB_AMD_HIP(hipMemcpyAsync(blk->p, d_flatOpsLen_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
-        EDLIB_AMD_HIP(hipMemcpyAsync(blk->p + n * sizeof(int), d_flatOps_.p, (size_t)flatOpsTotal_, hipMemcpyDeviceToHost, stream_));
-        opsLen = reinterpret_cast<const int*>(blk->p); ops = blk->p + n * sizeof(int);
-        opsKeep_.push_back(blk);
-    }
-    if (flatStarts_ || flatPaths_) EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-    std::vector<UnitSpec> lateUnits; std::vector<std::pair<int, int>> lateWhere;
-    size_t oi = 0;
-    for (size_t u = 0; u < n; ++u) {
-        UnitResult& r = res[u];
-        r.status = EDLIB_STATUS_OK; r.hasStarts = r.hasAlignment = false;
-        if (scanMode == EDLIB_MODE_NW) finalize_global(r, cfg_.k, mode, tlen((int)u), score[u]);
-        else if (oi < flatOvfUnit_.size() && flatOvfUnit_[oi] == (int)u) {
-            finalize_semiglobal(r, cfg_.k, qlen((int)u), score[u], flatOvfPos_.data() + flatOvfOff_[oi], flatOvfOff_[oi + 1] - flatOvfOff_[oi]);
-            ++oi;
-        } else finalize_semiglobal(r, cfg_.k, qlen((int)u), score[u], pos + u * kFlatPosCap, score[u] < 0 ? 0 : std::max(count[u], 0));
-        if (!wantStarts || r.editDistance < 0 || !r.hasEnds) continue;
-        // start locations (edlib.cpp:228-272): 0 for NW / SHW and for the empty prefix (-1); HW: what the reverse scans found.
-        // (finalize_semiglobal puts the -1 location, when there is one, in front of the kernel's list)
-        r.hasStarts = true;
-        r.starts.assign(r.ends.size(), 0);
-        if (starts) {
-            const size_t lead = (!r.ends.empty() && r.ends[0] == -1) ? 1 : 0;
-            for (size_t j = lead; j < r.ends.size(); ++j) {
-                if (j - lead < (size_t)kFlatPosCap) r.starts[j] = starts[u * kFlatPosCap + (j - lead)];
-                else {
-                    // beyond the 16 locations the flat layout keeps (a unit of the exact second pass): its reverse scan runs now
-                    const int m = qlen((int)u), e = r.ends[j];
-                    const long long win = std::min<long long>((long long)e + 1, (long long)m + r.editDistance);
-                    lateUnits.push_back(UnitSpec{qoff_[u] + m - 1, m, -1, tbase((int)u) + e, (int)win, -1, r.editDistance});
-                    lateWhere.push_back({(int)u, (int)j});
-                }
-            }
-        }
-        if (cfg_.task != EDLIB_TASK_PATH || r.ends.empty()) continue;
-        // the path of the first location (:276-289); an empty window is all inserts (:1168-1175)
-        r.hasAlignment = true;
-        if (r.ends[0] - r.starts[0] + 1 <= 0) {
-            opsOwned_.emplace_back((size_t)qlen((int)u), (uint8_t)EDLIB_EDOP_INSERT);
-            r.opsView = opsOwned_.back().data(); r.opsViewLen = (int)opsOwned_.back().size();
-        } else {
-            r.opsView = ops + flatOpsOffHost_[u + 1] - opsLen[u]; r.opsViewLen = opsLen[u];
-        }
-    }
-    if (!lateUnits.empty()) {
-        SolveOut so;
-        if (solveSemiGlobal(EDLIB_MODE_SHW, false, lateUnits, so)) return 1;
-        for (size_t i = 0; i < lateUnits.size(); ++i) {
-            UnitResult& r = res[(size_t)lateWhere[i].first];
-            r.starts[(size_t)lateWhere[i].second] = r.ends[(size_t)lateWhere[i].second] - so.last[i];     // (edlib.cpp:260)
-        }
-    }
-    if (alphabetLengthsEnd(res)) return 1;
-    pairsCollected_ = true;
-    return 0;
-}
-
-int Batch::ensureCollected()
-{
-    if (readsCollected_ && pairsCollected_) return 0;
-    DeviceGuard guard(device_);
-    EDLIB_AMD_HIP(guard.status);
-    if (results_.size() != (size_t)n_) results_.assign((size_t)n_, UnitResult{});
-    if (!readsCollected_ && collectReads(results_)) return 1;
-    if (!pairsCollected_ && collectPairsFlat(results_)) return 1;
-    return 0;
-}
-
 // ------------------------------------------------------------- Hirschberg
 
-static bool needs_hirschberg(int m, int T) {
+bool needs_hirschberg(int m, int T) {
     const long long nb = (m + 63) / 64;
     return (2LL * 8 + 4) * nb * T + 8LL * T >= 1024 * 1024;              // edlib.cpp:1188-1190
 }
@@ -2732,6 +2277,7 @@ int Batch::runImpl()
     knownSplits_.clear();
     wideGateRelease();           // (a run that failed between a wide launch and its check)
     wideSerial_ = false;         // every run tries the pipelined strips first
+    viewReady_ = false; cigar_[0].ready = cigar_[1].ready = false; lastRunFlat_ = false;      // (views of the previous run end here)
     opsOwned_.clear();
     // TASK_DISTANCE over reads-path units only: nothing is assembled on the host until results() asks for it, so
     // the per-unit records (160 bytes each) are not even allocated in the timed run
@@ -2775,7 +2321,7 @@ int Batch::runImpl()
             // level that failed): this run takes the general path from the start
             res.resize((size_t)n_);
             for (size_t u = 0; u < res.size(); ++u) blank_record(res[u]);
-        } else { flatDone = true; pairsCollected_ = false; }
+        } else { flatDone = true; pairsCollected_ = false; lastRunFlat_ = true; }
         lap("run: flat pairs");
     }
     // ---- phase 1: distance + end locations
@@ -3086,7 +2632,55 @@ int Batch::results(EdlibAlignResult* out)
     return 0;
 }
 
-// Flat form of results(): one array per field instead of one malloc per unit (edlibAmdBatchResultsFlat).
+// The caller-facing arrays of a general batch, from its records (a flat batch makes them on the device: engine_flat.hip).
+int Batch::buildHostView()
+{
+    if (viewReady_) return 0;
+    if (ensureCollected()) return 1;
+    const size_t n = (size_t)n_;
+    long long nloc = 0, naln = 0;
+    bool anyStarts = false;
+    for (size_t u = 0; u < n; ++u) {
+        const UnitResult& r = results_[u];
+        nloc += r.hasEnds ? (long long)r.ends.size() : 0;
+        naln += r.hasAlignment ? (long long)r.opsViewLen : 0;
+        anyStarts = anyStarts || r.hasStarts;
+    }
+    viewInts_.assign(4 * n + 2 * (size_t)nloc + 2, 0); viewOffs_.assign(2 * (n + 1), 0); viewOps_.assign((size_t)naln + 1, 0);
+    int* st = viewInts_.data(); int* ed = st + n; int* nl = ed + n; int* al = nl + n; int* ends = al + n; int* starts = ends + nloc;
+    long long* lo = viewOffs_.data(); long long* ao = lo + n + 1;
+    long long li = 0, ai = 0;
+    for (size_t u = 0; u < n; ++u) {
+        const UnitResult& r = results_[u];
+        st[u] = r.status; ed[u] = r.editDistance; al[u] = r.alphabetLength;
+        const size_t c = r.hasEnds ? r.ends.size() : 0;
+        nl[u] = (int)c; lo[u] = li; ao[u] = ai;
+        if (c) memcpy(ends + li, r.ends.data(), c * sizeof(int));
+        for (size_t i = 0; i < c; ++i) starts[li + (long long)i] = r.hasStarts ? r.starts[i] : -1;
+        li += (long long)c;
+        if (r.hasAlignment && r.opsViewLen > 0) { memcpy(viewOps_.data() + ai, r.opsView, (size_t)r.opsViewLen); ai += r.opsViewLen; }
+    }
+    lo[n] = li; ao[n] = ai;
+    view_ = EdlibAmdResultsView{};
+    view_.numUnits = n_; view_.status = st; view_.editDistance = ed; view_.numLocations = nl; view_.alphabetLength = al;
+    view_.locOffsets = lo; view_.endLocations = ends; view_.startLocations = anyStarts ? starts : nullptr;
+    view_.alnOffsets = ao; view_.alignment = cfg_.task == EDLIB_TASK_PATH ? viewOps_.data() : nullptr;
+    viewAlnDev_ = nullptr; viewAlnOffDev_ = nullptr;
+    viewReady_ = true;
+    return 0;
+}
+
+int Batch::resultsView(EdlibAmdResultsView* out)
+{
+    if (!haveResults_) { set_error("results before a successful run()"); return 1; }
+    DeviceGuard guard(device_);
+    EDLIB_AMD_HIP(guard.status);
+    if (!viewReady_ && (lastRunFlat_ ? buildFlatView() : buildHostView())) return 1;
+    if (out) *out = view_;
+    return 0;
+}
+
+// Flat form of results() as malloc'd copies of the view (edlibAmdBatchResultsFlat).
 int Batch::resultsFlat(int* status, int* editDistance, int* numLocations, int* alphabetLength,
                        long long* locOffsets, int** endLocations, int** startLocations,
                        long long* alnOffsets, unsigned char** alignment)
@@ -3094,49 +2688,92 @@ int Batch::resultsFlat(int* status, int* editDistance, int* numLocations, int* a
     if (endLocations) *endLocations = nullptr;
     if (startLocations) *startLocations = nullptr;
     if (alignment) *alignment = nullptr;
-    if (!haveResults_) { set_error("results() before a successful run()"); return 1; }
-    if (ensureCollected()) return 1;
-    long long nloc = 0, naln = 0;
-    for (int u = 0; u < n_; ++u) {
-        const UnitResult& r = results_[u];
-        if (status) status[u] = r.status;
-        if (editDistance) editDistance[u] = r.editDistance;
-        if (numLocations) numLocations[u] = r.hasEnds ? (int)r.ends.size() : 0;
-        if (alphabetLength) alphabetLength[u] = r.alphabetLength;
-        if (locOffsets) locOffsets[u] = nloc;
-        if (alnOffsets) alnOffsets[u] = naln;
-        nloc += r.hasEnds ? (long long)r.ends.size() : 0;
-        naln += r.hasAlignment ? (long long)r.opsViewLen : 0;
-    }
-    if (locOffsets) locOffsets[n_] = nloc;
-    if (alnOffsets) alnOffsets[n_] = naln;
+    EdlibAmdResultsView v;
+    if (resultsView(&v)) return 1;
+    const size_t n = (size_t)n_;
+    if (status) memcpy(status, v.status, n * sizeof(int));
+    if (editDistance) memcpy(editDistance, v.editDistance, n * sizeof(int));
+    if (numLocations) memcpy(numLocations, v.numLocations, n * sizeof(int));
+    if (alphabetLength) memcpy(alphabetLength, v.alphabetLength, n * sizeof(int));
+    if (locOffsets) memcpy(locOffsets, v.locOffsets, (n + 1) * sizeof(long long));
+    if (alnOffsets) memcpy(alnOffsets, v.alnOffsets, (n + 1) * sizeof(long long));
+    const long long nloc = v.locOffsets[n], naln = v.alnOffsets[n];
     int* ends = endLocations ? static_cast<int*>(malloc(sizeof(int) * (size_t)std::max<long long>(nloc, 1))) : nullptr;
-    bool anyStarts = false;
-    for (int u = 0; u < n_ && !anyStarts; ++u) anyStarts = results_[u].hasStarts;
-    int* starts = (startLocations && anyStarts) ? static_cast<int*>(malloc(sizeof(int) * (size_t)std::max<long long>(nloc, 1))) : nullptr;
+    int* starts = (startLocations && v.startLocations) ? static_cast<int*>(malloc(sizeof(int) * (size_t)std::max<long long>(nloc, 1))) : nullptr;
     unsigned char* aln = alignment ? static_cast<unsigned char*>(malloc((size_t)std::max<long long>(naln, 1))) : nullptr;
-    if ((endLocations && !ends) || (startLocations && anyStarts && !starts) || (alignment && !aln)) {
+    if ((endLocations && !ends) || (startLocations && v.startLocations && !starts) || (alignment && !aln)) {
         free(ends); free(starts); free(aln); set_error("out of memory"); return 1;
     }
-    long long li = 0, ai = 0;
-    for (int u = 0; u < n_; ++u) {
-        const UnitResult& r = results_[u];
-        if (r.hasEnds) {
-            const size_t c = r.ends.size();
-            if (ends && c) memcpy(ends + li, r.ends.data(), c * sizeof(int));
-            if (starts) for (size_t i = 0; i < c; ++i) starts[li + i] = r.hasStarts ? r.starts[i] : -1;
-            li += (long long)c;
-        }
-        if (r.hasAlignment) {
-            const uint8_t* src = r.opsView;
-            const size_t len = (size_t)r.opsViewLen;
-            if (aln && len) memcpy(aln + ai, src, len);
-            ai += (long long)len;
-        }
-    }
+    if (ends && nloc) memcpy(ends, v.endLocations, (size_t)nloc * sizeof(int));
+    if (starts && nloc) memcpy(starts, v.startLocations, (size_t)nloc * sizeof(int));
+    if (aln && naln && v.alignment) memcpy(aln, v.alignment, (size_t)naln);
     if (endLocations) *endLocations = ends;
     if (startLocations) *startLocations = starts;
     if (alignment) *alignment = aln;
+    return 0;
+}
+
+// edlibAlignmentToCigar (edlib.cpp:303-350) over every op string of the last run.  A flat batch's op bytes are dense on the
+// device: lengths, a prefix sum and the strings are three launches there (flat_results.hip) and one block comes back;
+// other batches run-length encode their view on the host.
+int Batch::cigarView(int format, const char** chars, const long long** offsets)
+{
+    if (format != EDLIB_CIGAR_STANDARD && format != EDLIB_CIGAR_EXTENDED) { set_error("unknown CIGAR format"); return 1; }
+    EdlibAmdResultsView v;
+    if (resultsView(&v)) return 1;
+    CigarOut& c = cigar_[format == EDLIB_CIGAR_STANDARD ? 1 : 0];
+    const size_t n = (size_t)n_;
+    if (!c.ready) {
+        DeviceGuard guard(device_);
+        EDLIB_AMD_HIP(guard.status);
+        if (viewAlnDev_ && v.alignment) {
+            const size_t nblocks = (n + 255) / 256;
+            EDLIB_AMD_HIP(d_cigWork_.ensure(3 * n + nblocks + 4));
+            long long* cigLen = d_cigWork_.p; long long* cigRel = cigLen + n; long long* blockTot = cigRel + n;
+            long long* totals = blockTot + nblocks; long long* cigOff = totals + 2;
+            const int standard = format == EDLIB_CIGAR_STANDARD ? 1 : 0;
+            EDLIB_AMD_HIP(launch_cigars(viewAlnDev_, viewAlnOffDev_, n_, standard, cigLen, cigRel, blockTot, totals, nullptr, cigOff, 0, stream_));
+            if (c.offs.n < (n + 1) * sizeof(long long)) EDLIB_AMD_HIP(c.offs.alloc((n + 1) * sizeof(long long)));
+            long long total = 0;
+            EDLIB_AMD_HIP(hipMemcpyAsync(c.offs.p, totals, sizeof(long long), hipMemcpyDeviceToHost, stream_));
+            EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+            total = *reinterpret_cast<const long long*>(c.offs.p);
+            if (total < (long long)n) { set_error("CIGAR: bad total"); return 1; }
+            EDLIB_AMD_HIP(d_cigChars_.ensure((size_t)total));
+            if (c.chars.n < (size_t)total) EDLIB_AMD_HIP(c.chars.alloc((size_t)total));
+            EDLIB_AMD_HIP(launch_cigars(viewAlnDev_, viewAlnOffDev_, n_, standard, cigLen, cigRel, blockTot, totals, d_cigChars_.p, cigOff, 1, stream_));
+            EDLIB_AMD_HIP(hipMemcpyAsync(c.chars.p, d_cigChars_.p, (size_t)total, hipMemcpyDeviceToHost, stream_));
+            EDLIB_AMD_HIP(hipMemcpyAsync(c.offs.p, cigOff, (n + 1) * sizeof(long long), hipMemcpyDeviceToHost, stream_));
+            EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+            c.p = reinterpret_cast<const char*>(c.chars.p); c.off = reinterpret_cast<const long long*>(c.offs.p);
+        } else {
+            static const char ext[4] = {'=', 'I', 'D', 'X'}, stdc[4] = {'M', 'I', 'D', 'M'};
+            const char* letters = format == EDLIB_CIGAR_STANDARD ? stdc : ext;
+            c.hostChars.clear(); c.hostOffs.assign(n + 1, 0);
+            for (size_t u = 0; u < n; ++u) {
+                c.hostOffs[u] = (long long)c.hostChars.size();
+                const long long a0 = v.alnOffsets[u], a1 = v.alnOffsets[u + 1];
+                long long i = a0;
+                while (v.alignment && i < a1) {
+                    const unsigned char op = v.alignment[i];
+                    if (op > 3) { set_error("CIGAR: invalid op code"); return 1; }
+                    const char ch = letters[op];
+                    long long run = 0;
+                    while (i < a1 && v.alignment[i] <= 3 && letters[v.alignment[i]] == ch) { ++run; ++i; }
+                    char buf[24];
+                    const int w = snprintf(buf, sizeof buf, "%lld", run);
+                    c.hostChars.insert(c.hostChars.end(), buf, buf + w);
+                    c.hostChars.push_back(ch);
+                }
+                c.hostChars.push_back('\0');
+            }
+            c.hostOffs[n] = (long long)c.hostChars.size();
+            c.p = c.hostChars.data(); c.off = c.hostOffs.data();
+        }
+        c.ready = true;
+    }
+    if (chars) *chars = c.p;
+    if (offsets) *offsets = c.off;
     return 0;
 }
 

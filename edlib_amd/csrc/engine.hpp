@@ -120,6 +120,8 @@ public:
     int results(EdlibAlignResult* out);
     int resultsFlat(int* status, int* editDistance, int* numLocations, int* alphabetLength, long long* locOffsets,
                     int** endLocations, int** startLocations, long long* alnOffsets, unsigned char** alignment);
+    int resultsView(EdlibAmdResultsView* out);
+    int cigarView(int format, const char** chars, const long long** offsets);
     EdlibAmdBatchStats stats{};
     void finishStats();          // fills the fields of `stats` that cost a walk over the records (algo_bytes)
 
@@ -133,7 +135,7 @@ private:
     std::vector<long long> qoff_, toff_;
     Tables tab_;
     hipStream_t stream_ = nullptr;
-    Event evRun0_, evRun1_, evA_, evB_;
+    Event evRun0_, evRun1_, evA_, evB_;           // evB_: the side stream's alphabet kernel is done
 
     // ---- resident inputs
     DevBuf<uint8_t> d_in_;                       // offsets + small tables (+ small sequence pools) in one block
@@ -272,7 +274,7 @@ private:
     std::vector<OpsOut> fusedOps_;
     // ---- flat pair path (TASK_DISTANCE, every unit a pair of at most 16 blocks): descriptors built once and resident, a
     // run is Peq build + ONE ring scan + an overflow census, results stay in HBM until results() (like the reads path)
-    bool flatPairs_ = false, pairsCollected_ = true;
+    bool flatPairs_ = false, pairsCollected_ = true, lastRunFlat_ = false;
     int flatRing_ = 0;
     long long flatWordSteps_ = 0;               // word-steps inside the bands of one run over the flat descriptors
     DevBuf<PairDesc> d_flatDescs_;
@@ -298,6 +300,21 @@ private:
     std::vector<long long> flatOpsOffHost_;
     int runFlatStartsAndPaths(bool& fellBack);
     int collectPairsFlat(std::vector<UnitResult>& res);
+    // rings of 32-row words for the storing scans and walks of a flat PATH batch (ring32_kernels.hip)
+    bool flatRing32_ = false; int flatG32_ = 8, flatMaxWords_ = 0;
+    DevBuf<uint8_t> d_tsym_;
+    // the caller-facing arrays of the last run: made on the device for a flat batch (buildFlatView), from the records otherwise
+    DevBuf<uint8_t> d_view_; PinBuf h_view_; bool viewReady_ = false;
+    EdlibAmdResultsView view_{};
+    const uint8_t* viewAlnDev_ = nullptr; const long long* viewAlnOffDev_ = nullptr;     // the dense op bytes on the device (CIGARs)
+    std::vector<int> viewInts_; std::vector<long long> viewOffs_; std::vector<uint8_t> viewOps_;   // host-made view of a general batch
+    DevBuf<int> d_flatOvfAt_, d_flatOvfPool_; DevBuf<long long> d_flatOvfOff_;
+    int buildFlatView();
+    int buildHostView();
+    // CIGAR strings of the last run (edlibAlignmentToCigar, edlib.cpp:303-350, over the batch): [0] extended, [1] standard
+    struct CigarOut { bool ready = false; PinBuf chars, offs; std::vector<char> hostChars; std::vector<long long> hostOffs; const char* p = nullptr; const long long* off = nullptr; };
+    CigarOut cigar_[2];
+    DevBuf<long long> d_cigWork_; DevBuf<char> d_cigChars_;
     int ensureCollected();                       // results of the last run that are still on the device -> results_
 };
 
@@ -306,6 +323,12 @@ int align_one(const char* q, int qn, const char* t, int tn, EdlibAlignConfig cfg
 // one small pair in one kernel launch (one_pair.hip): 0 = answered, 1 = error, 2 = not handled here (take align_one)
 int align_one_fused(const char* q, int qn, const char* t, int tn, EdlibAlignConfig cfg, EdlibAlignResult* out);
 
+// helpers shared by the translation units of the host side
+const int kPosCap = 16;                           // end positions kept beside a pair unit's results (longer lists: exact second pass)
+int peq_row_stride(long long nb);                 // row length of the LDS-resident Peq of the ring kernels
+bool needs_hirschberg(int m, int T);              // the reference's 1 MiB rule (edlib.cpp:1188-1190)
+void blank_record(UnitResult& r);
+void finalize_global(UnitResult& r, int kcfg, int mode, int T, int score);
 // helpers shared by engine.hip and long_reads.hip
 int roundup(int x, int q);
 void plan_segments(int nlanes, int T, int mode, int warmFull, long long wantWaves, int& S, int& segLen, int& warm);

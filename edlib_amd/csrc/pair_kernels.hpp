@@ -52,6 +52,7 @@ struct PairScanArgs {
     const uint8_t* qpool;
     const uint8_t* tpool;
     const uint8_t* tlut;        // [256] target byte -> symbol id (row of Peq)
+    const uint8_t* tsym;        // ring32 kernels: the target pool as symbol ids (launch_target_symbols), same offsets as tpool
     int sigmaT;                 // number of target symbols (rows of Peq)
     const unsigned long long* peq;   // Peq pool, built by launch_build_peq_pairs
     int peqFullStride;          // ring kernel: sigmaT * peqRowStride, 0 = unknown
@@ -116,6 +117,18 @@ hipError_t launch_build_peq_pairs(const PairDesc* descs, int numUnits, const uin
                                   const uint8_t* eq8, const uint8_t* idToByte, int sigmaT,
                                   unsigned long long* peq, hipStream_t stream);
 
+// ---- lane rings of 32-row words (ring32_kernels.hip): NW pairs of a batch too small to fill the chip (lone waves: bound
+// by the latency of their own instruction stream), with the column store as 8-byte entries (the two planes of StoreEntry on
+// 32 rows) at (storeOff + (column + word) * G + word % G) of the u64 view of PairScanArgs::store, and a lane-parallel walk.
+// G in {4, 8, 16}; the band of desc.kinit must fit the ring (kinit <= ring32_max_k(G)) or all words sit on it (any kinit).
+// Forward units only (qstep = tstep = 1, no bandT / colOff); needs PairScanArgs::tsym; a launch's store stays below 4 GB.
+constexpr int ring32_max_k(int G) { return 32 * (G - 2); }
+long long ring32_store_entries(int ringLanes, int qlen, int tlen);          // u64 entries of one unit
+size_t ring32_lds_bytes(int ringLanes, int sigmaT, int maxWords);           // dynamic LDS of a wave (the launcher refuses > 48 KB)
+long long ring32_word_steps(int ringLanes, const PairDesc* hostDescs, int n);   // 32-row word-columns inside the bands (host)
+hipError_t launch_target_symbols(const uint8_t* tpool, const uint8_t* tlut, long long n, uint8_t* tsym, hipStream_t stream);
+hipError_t launch_scan_pairs_ring32(int ringLanes, bool store, const PairScanArgs& a, int maxWords, hipStream_t stream);
+
 struct TracebackArgs {
     const PairDesc* descs;
     int numUnits;
@@ -127,6 +140,8 @@ struct TracebackArgs {
 };
 // reference obtainAlignmentTraceback (edlib.cpp:942-1141)
 hipError_t launch_traceback(const TracebackArgs& a, hipStream_t stream);
+// the same walk on the store of launch_scan_pairs_ring32 (store entries of 8 bytes, PairDesc::storeOff in those)
+hipError_t launch_traceback32(const TracebackArgs& a, int ringLanes, hipStream_t stream);
 
 // number of block-steps the column store of a unit needs
 long long pair_store_entries(int qlen, int tlen);

@@ -91,6 +91,31 @@ EDLIB_API int edlibAmdBatchResultsFlat(EdlibAmdBatch* batch, int* status, int* e
                                        int* alphabetLength, long long* locOffsets, int** endLocations,
                                        int** startLocations, long long* alnOffsets, unsigned char** alignment);
 
+/* The same arrays WITHOUT copies: pointers into pinned host memory the batch owns, valid until the next Run / Destroy of
+ * this batch.  For a batch of short pairs ("flat": every unit a pair of at most 16 blocks) the arrays are laid out by
+ * device kernels -- the k filter, the -1 location of the padded last block, start locations, the dense op bytes, their
+ * offsets by a prefix sum -- and arrive as one block at link rate; other batches build them once on the host.
+ * startLocations is NULL unless the task produced start locations, alignment NULL unless it produced paths. */
+typedef struct {
+    int numUnits;
+    const int* status;              /* [numUnits] EDLIB_STATUS_*                                  */
+    const int* editDistance;        /* [numUnits] -1: no alignment within k                       */
+    const int* numLocations;        /* [numUnits]                                                 */
+    const int* alphabetLength;      /* [numUnits]                                                 */
+    const long long* locOffsets;    /* [numUnits + 1] into endLocations / startLocations          */
+    const int* endLocations;
+    const int* startLocations;
+    const long long* alnOffsets;    /* [numUnits + 1] into alignment (EDLIB_EDOP_* bytes)         */
+    const unsigned char* alignment;
+} EdlibAmdResultsView;
+EDLIB_API int edlibAmdBatchResultsView(EdlibAmdBatch* batch, EdlibAmdResultsView* out);
+
+/* edlibAlignmentToCigar() over every op string of the last Run (a TASK_PATH batch): *chars = the NUL-terminated CIGAR
+ * strings one after the other, (*offsets)[i] = where string i starts ((*offsets)[numUnits] = all bytes); a unit without
+ * an alignment has the empty string.  Same lifetime as the view.  Flat batches: made on the device. */
+EDLIB_API int edlibAmdBatchCigarView(EdlibAmdBatch* batch, EdlibCigarFormat cigarFormat,
+                                     const char** chars, const long long** offsets);
+
 /* edlibFreeAlignResult() over results[0..n) (one call instead of n for binding languages). */
 EDLIB_API void edlibAmdFreeResults(EdlibAlignResult* results, int n);
 

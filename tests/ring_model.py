@@ -15,9 +15,13 @@ whether consecutive tenants of a lane never overlap in steps (the condition ring
 
 M64 = (1 << 64) - 1
 
+# RH: rows per ring lane -- 64 (scan_pairs_ring_kernel) or 32 (scan_pairs_ring32_kernel, ring32_kernels.hip: the same
+# rules on 32-row words).  geom = (dmin, dmax): a band WIDER than the unit's own, as the ring32 kernel uses when the
+# units of a wave share one geometry (the extremes over the wave, accepted while dmax - dmin <= RH (G - 2)).
 
-def ring_max_k(G):
-    return 64 * G - 128
+
+def ring_max_k(G, RH=64):
+    return RH * (G - 2)
 
 
 def band(m, T, K):
@@ -26,20 +30,20 @@ def band(m, T, K):
     return min(0, D) - p, max(0, D) + p
 
 
-def lives(m, T, K):
-    nb = (m + 63) // 64
-    dmin, dmax = band(m, T, K)
+def lives(m, T, K, RH=64, geom=None):
+    nb = (m + RH - 1) // RH
+    dmin, dmax = geom if geom else band(m, T, K)
     out = []
     for b in range(nb):
-        f, l = max(0, 64 * b + dmin), min(T - 1, 64 * b + 63 + dmax)
+        f, l = max(0, RH * b + dmin), min(T - 1, RH * b + RH - 1 + dmax)
         out.append((f, l) if f <= l else None)
     return out
 
 
-def ring_fits(m, T, K, G):
+def ring_fits(m, T, K, G, RH=64, geom=None):
     """block b + G starts (step first + b + G) strictly after the step at which block b closes (last + b + 1 is its
     closing event; the kernel lets the next tenant start in that same step)"""
-    lv = lives(m, T, K)
+    lv = lives(m, T, K, RH, geom)
     for b in range(len(lv) - G):
         if lv[b] is None or lv[b + G] is None:
             continue
@@ -52,21 +56,22 @@ def popc(x):
     return bin(x).count("1")
 
 
-def banded_nw(q, t, K):
+def banded_nw(q, t, K, RH=64, geom=None):
     """the model's score: exact when the true distance is <= K, some value > K otherwise (None: K < |T - m|)"""
     m, T = len(q), len(t)
     if K < abs(T - m):
         return None
-    nb = (m + 63) // 64
+    M64 = (1 << RH) - 1
+    nb = (m + RH - 1) // RH
     peq = {}
     for s in set(t):
         v = 0
         for i, ch in enumerate(q):
             if ch == s:
                 v |= 1 << i
-        peq[s] = [(v >> (64 * b)) & M64 for b in range(nb)]
+        peq[s] = [(v >> (RH * b)) & M64 for b in range(nb)]
     zero = [0] * nb
-    lv = lives(m, T, K)
+    lv = lives(m, T, K, RH, geom)
     P = [M64] * nb
     Mv = [0] * nb
     bscore = [0] * nb                                  # bottom score of block b after its last update
@@ -84,8 +89,8 @@ def banded_nw(q, t, K):
                 P[b], Mv[b] = M64, 0
                 # (block 0 always starts at column 0; a later block starts while the block above is alive, so
                 # bscore[b - 1] is that block's computed bottom at column j - 1)
-                above = 64 * b if j == 0 else bscore[b - 1]
-                cur = above + 64
+                above = RH * b if j == 0 else bscore[b - 1]
+                cur = above + RH
             else:
                 cur = bscore[b]
             hin = 1 if (b == 0 or not prev_alive) else hout_prev
@@ -97,7 +102,7 @@ def banded_nw(q, t, K):
             xh = ((((eq2 & pv) + pv) & M64) ^ pv) | eq2
             ph = mv | (~(xh | pv) & M64)
             mh = pv & xh
-            hout = ((ph >> 63) & 1) - ((mh >> 63) & 1)
+            hout = ((ph >> (RH - 1)) & 1) - ((mh >> (RH - 1)) & 1)
             ph = (ph << 1) & M64
             mh = (mh << 1) & M64
             if hin < 0:
@@ -113,6 +118,6 @@ def banded_nw(q, t, K):
     last = nb - 1
     if lv[last] is None or lv[last][1] != T - 1:
         return K + 1                                     # the last block is not alive at the stop column: above K
-    sh = (m - 1) & 63
-    below = 0 if sh == 63 else (M64 << (sh + 1)) & M64
+    sh = (m - 1) & (RH - 1)
+    below = 0 if sh == RH - 1 else (M64 << (sh + 1)) & M64
     return bscore[last] - popc(P[last] & below) + popc(Mv[last] & below)

@@ -144,3 +144,94 @@ def test_flat_paths_with_the_empty_prefix_first(engine):
     ts = [np.frombuffer(b"C" * int(rng.choice([1, 30, 200])), dtype=np.uint8) for _ in range(1200)]
     for mode in ("HW", "SHW"):
         _check_task(engine, qs, ts, mode, "path", what="all mismatching")
+
+
+# ---------------------------------------------------------------- rings of 32-row words, device-made views and CIGARs (round 5)
+
+def _nw_pairs(n, seed, lengths, rates, gaps=False):
+    rng = np.random.default_rng(seed)
+    qs, ts = [], []
+    for i in range(n):
+        T = int(rng.choice(lengths))
+        t = _ACGT[rng.integers(0, 4, T)]
+        sub, indel = rates[i % len(rates)]
+        q, _ = synth.mutate(t, int(rng.integers(1 << 30)), sub, indel, indel)
+        q = np.ascontiguousarray(q)
+        if gaps and i % 5 == 0 and len(q) > 120:           # a long gap: runs of up / left moves across 32-row words
+            a = int(rng.integers(0, len(q) - 100))
+            g = int(rng.choice([33, 40, 70]))
+            q = np.concatenate([q[:a], q[a + g:]]) if i % 10 == 0 else np.concatenate([q[:a], _ACGT[rng.integers(0, 4, g)], q[a:]])
+        if len(q) > 1024:
+            q = q[:1024]
+        if len(q) == 0:
+            q = _ACGT[:1].copy()
+        qs.append(np.ascontiguousarray(q)); ts.append(t)
+    return qs, ts
+
+
+@pytest.mark.parametrize("lengths,rates", [
+    ((1000,), ((0.03, 0.01),)),                                       # BASELINE config 5's shape: K = 128 on 8 words of 32 rows
+    ((257, 300, 511, 512, 513, 777, 1023), ((0.01, 0.005), (0.05, 0.02))),   # every word edge, mixed T - m inside a wave
+    ((1, 2, 31, 32, 33, 64, 100, 255, 256), ((0.1, 0.05), (0.0, 0.0))),      # queries that sit whole on their ring
+])
+def test_ring32_paths(engine, lengths, rates):
+    qs, ts = _nw_pairs(2100, 7 + len(lengths), lengths, rates, gaps=True)
+    _check_task(engine, qs, ts, "NW", "path", what="ring32 %r" % (lengths,))
+    _check_task(engine, qs[:1100], ts[:1100], "NW", "path", k=60, what="ring32 fixed k")
+
+
+def test_views_and_records_agree(engine):
+    """edlibAmdBatchResultsView (device-made for a flat batch) against the per-unit records of edlibAmdBatchResults"""
+    for mode, task in (("HW", "path"), ("NW", "path"), ("SHW", "locations"), ("HW", "distance")):
+        qs, ts = _window_pairs(1300, 5, 150, 400)
+        b = engine.PairBatch(qs, ts, mode=mode, task=task, k=-1)
+        try:
+            b.run()
+            v = b.results_flat(copy=False)
+            rec = b.results()
+        finally:
+            pass
+        try:
+            for u, r in enumerate(rec):
+                lo, hi = int(v["locOff"][u]), int(v["locOff"][u + 1])
+                assert r["editDistance"] == v["editDistance"][u] and r["numLocations"] == hi - lo and r["alphabetLength"] == v["alphabetLength"][u]
+                assert (r["endLocations"] or []) == list(v["ends"][lo:hi])
+                if r["startLocations"] is not None:
+                    assert r["startLocations"] == list(v["starts"][lo:hi])
+                if r["alignment"] is not None:
+                    assert r["alignment"] == v["alignment"][int(v["alnOff"][u]):int(v["alnOff"][u + 1])].tobytes()
+        finally:
+            b.close()
+
+
+@pytest.mark.parametrize("n", [1500, 40])       # a flat batch (CIGARs made on the device) and a general one (on the host)
+def test_batch_cigars_equal_edlibAlignmentToCigar(engine, n):
+    qs, ts = _nw_pairs(n, 91, (5, 64, 150, 700, 1000), ((0.03, 0.01), (0.2, 0.1)), gaps=True)
+    qs[3] = np.frombuffer(b"A" * 300, dtype=np.uint8); ts[3] = np.frombuffer(b"A" * 300, dtype=np.uint8)     # one run of 300
+    b = engine.PairBatch(qs, ts, mode="NW", task="path", k=-1)
+    try:
+        b.run()
+        flat = b.results_flat()
+        for extended in (True, False):
+            got = b.cigar_list(extended)
+            again = b.cigar_list(extended)
+            assert got == again
+            for u in range(n):
+                ops = flat["alignment"][int(flat["alnOff"][u]):int(flat["alnOff"][u + 1])].tobytes()
+                assert got[u] == engine.cigar_from_alignment(ops, extended), (u, extended)
+        assert b.cigar_list(True)[3] == "300=" and b.cigar_list(False)[3] == "300M"
+        # with a threshold some units have no alignment: their CIGAR is the empty string
+        b2 = engine.PairBatch(qs, ts, mode="NW", task="path", k=3)
+        try:
+            b2.run()
+            f2 = b2.results_flat()
+            c2 = b2.cigar_list(True)
+            for u in range(n):
+                if f2["editDistance"][u] < 0:
+                    assert c2[u] == ""
+                else:
+                    assert c2[u] == engine.cigar_from_alignment(f2["alignment"][int(f2["alnOff"][u]):int(f2["alnOff"][u + 1])].tobytes(), True)
+        finally:
+            b2.close()
+    finally:
+        b.close()

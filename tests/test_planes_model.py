@@ -107,3 +107,70 @@ def test_planes_answer_the_walk():
         if it % 5 == 0:
             t = [rng.randrange(sigma) for _ in range(rng.choice([1, 7, 90]))]
         assert walk(planes(q, t, sigma), len(q), len(t)) == textbook(q, t), (it, m, len(t))
+
+
+def walk_diagonals(store, m, T, L=32):
+    """traceback32_kernel (ring32_kernels.hip) without the lanes: L cells of the current diagonal per trip, the run of
+    diagonal moves up to the first cell where an indel move is possible, then up-moves (as many as the "up" plane shows
+    in the cell's word) or one left move; the matrix boundary leaves a tail.  Ops from the end of the alignment to its start."""
+    def xy(r, c):
+        x, y = store[r >> 6][c]
+        return (x >> (r & 63)) & 1, (y >> (r & 63)) & 1
+    ops, r, c = [], m - 1, T - 1
+    while True:
+        j = L
+        for i in range(L):
+            ri, ci = r - i, c - i
+            if ri < 0 or ci < 0 or xy(ri, ci)[0]:
+                j = i
+                break
+        ops += [0 if xy(r - i, c - i)[1] else 3 for i in range(j)]
+        r -= j; c -= j
+        if j == L:
+            continue
+        if r < 0 or c < 0:
+            return ops + ([1] * (r + 1) if c < 0 else [2] * (c + 1))
+        # the cell that stopped the run: up-moves inside its 32-row word, else one left move
+        ups = 0
+        while ups <= (r & 31):
+            x, y = xy(r - ups, c)
+            if not (x and not y):
+                break
+            ups += 1
+        if ups:
+            ops += [1] * ups; r -= ups
+        else:
+            x, y = xy(r, c)
+            assert x and y
+            ops.append(2); c -= 1
+        if r < 0 or c < 0:
+            if r < 0 and c < 0:
+                return ops
+            return ops + ([1] * (r + 1) if c < 0 else [2] * (c + 1))
+
+
+def test_diagonal_runs_walk_like_the_reference():
+    rng = random.Random(12)
+    for it in range(160):
+        sigma = rng.choice([2, 3, 4])
+        m = rng.choice([1, 5, 31, 32, 33, 63, 64, 65, 100, 128, 129, 150, 200])
+        q = [rng.randrange(sigma) for _ in range(m)]
+        t = []
+        for ch in q:
+            r = rng.random()
+            if r < 0.05:
+                continue
+            if r < 0.10:
+                t.append(rng.randrange(sigma))
+            t.append(ch if r >= 0.15 else rng.randrange(sigma))
+        if it % 7 == 3:                                  # a long gap on either side: runs of up / left moves across words
+            cut = rng.randrange(len(t) + 1)
+            t = t[:cut] + [rng.randrange(sigma) for _ in range(rng.choice([40, 70]))] + t[cut:]
+        if it % 7 == 5 and len(t) > 80:
+            cut = rng.randrange(len(t) - 70)
+            t = t[:cut] + t[cut + 70:]
+        t = t or [0]
+        if it % 5 == 0:
+            t = [rng.randrange(sigma) for _ in range(rng.choice([1, 7, 90]))]
+        for L in (32, 64):
+            assert walk_diagonals(planes(q, t, sigma), len(q), len(t), L) == textbook(q, t), (it, m, len(t), L)

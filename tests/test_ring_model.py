@@ -79,3 +79,45 @@ def test_config4_shape_on_the_21_lane_ring(oracle):
     assert banded_nw(q, t, ring_max_k(21)) == d
     assert banded_nw(q, t, d - 1) > d - 1
     assert ring_fits(len(q), len(t), ring_max_k(21), 21)
+
+
+# ---------------------------------------------------------------- rings of 32-row words (ring32_kernels.hip)
+
+@pytest.mark.parametrize("G", [4, 8, 16])
+def test_ring32_keeps_tenants_apart_also_with_a_shared_geometry(G):
+    """words of 32 rows: K <= 32 (G - 2) keeps the tenants of a ring lane apart, and so does ANY band with
+    dmax - dmin <= 32 (G - 2) -- the geometry the units of a wave share (the extremes over the wave)"""
+    rng = random.Random(100 + G)
+    K = ring_max_k(G, 32)
+    for _ in range(300):
+        m = rng.randrange(1, 32 * 3 * G)
+        T = max(1, m + rng.randrange(-min(K, m - 1), K + 1))
+        assert ring_fits(m, T, K, G, 32), (m, T, K, G)
+        lo, hi = band(m, T, K)
+        # a neighbour in the wave with another T - m widens the band on either side
+        lo2, hi2 = lo - rng.randrange(0, 12), hi + rng.randrange(0, 12)
+        if hi2 - lo2 <= 32 * (G - 2):
+            assert ring_fits(m, T, K, G, 32, (lo2, hi2)), (m, T, K, G, lo2, hi2)
+            lv = [x for x in lives(m, T, K, 32, (lo2, hi2)) if x]
+            for j in (0, T // 3, T // 2, T - 1):
+                assert sum(1 for f, l in lv if f <= j <= l) <= G
+
+
+def test_ring32_band_is_exact_up_to_k_also_when_widened(oracle):
+    rng = random.Random(77)
+    for it in range(60):
+        m = rng.choice([1, 31, 32, 33, 64, 100, 257, 300, 700])
+        q = bytes(rng.choice(ACGT) for _ in range(m))
+        t = _mutate(rng, q, rng.choice([0.02, 0.1, 0.3]))
+        if it % 6 == 0:
+            t = bytes(rng.choice(ACGT) for _ in range(rng.randrange(1, m + 40)))
+        want = oracle.align(q, t, "NW", "distance", -1)["editDistance"]
+        for K in (want, max(want, abs(len(t) - m)) + 7, 128, 192):
+            got = banded_nw(q, t, K, 32)
+            if K < abs(len(t) - m):
+                assert got is None
+                continue
+            assert (got == want) if want <= K else (got > K), (it, m, len(t), K, got, want)
+            lo, hi = band(m, len(t), K)
+            wide = banded_nw(q, t, K, 32, (lo - rng.randrange(0, 20), hi + rng.randrange(0, 20)))
+            assert (wide == want) if want <= K else (wide > K), (it, "widened", K, wide, want)
