@@ -145,6 +145,7 @@ int Batch::initFlatPairs()
     flatPairs_ = false;
     static const bool locOn = !(getenv("EDLIB_AMD_FLATLOC") && getenv("EDLIB_AMD_FLATLOC")[0] == '0');
     flatStarts_ = flatPaths_ = flatNwStore_ = flatRing32_ = false;
+    flatOvfUnit_.clear(); flatOvfOff_.assign(1, 0);
     if (!on || !emptyUnits_.empty() || !groups_.empty() || !longUnits_.empty()) return 0;
     if (cfg_.task != EDLIB_TASK_DISTANCE && !locOn) return 0;
     if ((int)pairUnits_.size() != n_ || n_ < 1024) return 0;       // (a handful of units: the zero-copy path of solveChunk)
@@ -422,7 +423,7 @@ int Batch::buildFlatView()
     const size_t n = (size_t)n_;
     const bool wantStarts = cfg_.task != EDLIB_TASK_DISTANCE, wantPath = flatPaths_;
     const size_t nblocks = (n + 255) / 256;
-    const long long capLoc = (scanMode == EDLIB_MODE_NW ? (long long)n : (long long)n * (kFlatPosCap + 1)) + flatOvfOff_.back();
+    const long long capLoc = (scanMode == EDLIB_MODE_NW ? (long long)n : (long long)n * (kFlatPosCap + 1)) + (flatOvfOff_.empty() ? 0 : flatOvfOff_.back());
     const long long capAln = wantPath ? flatOpsTotal_ : 0;
     // ---- layout of the block (the same offsets on the device and in pinned host memory)
     size_t at = 0;
