@@ -1435,6 +1435,9 @@ int Batch::launchWide(int mode, const PairScanArgs& a0, const PairDesc* hostDesc
         a.descs = a0.descs + g0; a.numUnits = (int)(g1 - g0);
         a.outScore = a0.outScore + g0; a.outCount = a0.outCount + g0; a.outLast = a0.outLast + g0;
         a.wstream = d_wide_.p; a.wabort = d_wabort_.p;
+        // (tests: the residency check of a pipelined launch waits for one workgroup more than there are -- it gives up after
+        // 0.2 s as if part of the launch had not fitted the device, and the units run again with one slot each)
+        a.wideExpect = (!wideSerial_ && getenv("EDLIB_AMD_WIDE_TEST_NOT_RESIDENT")) ? (unsigned)(plan.slots * (g1 - g0) + 1) : 0u;
         EDLIB_AMD_HIP(launch_scan_pairs_wide(mode, a, plan.slots, stream_));
     }
     EDLIB_AMD_HIP(hipMemcpyAsync(h_wabort_.p, d_wabort_.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream_));

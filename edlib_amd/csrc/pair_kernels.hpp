@@ -75,7 +75,8 @@ struct PairScanArgs {
     // wide kernel (wide_kernels.hip): hand-off granules of the strip pipelines (PairDesc::auxOff = the unit's first granule,
     // wide_stream_words() per unit, zeroed before every launch) and the launch's abort word
     unsigned long long* wstream;
-    unsigned* wabort;
+    unsigned* wabort;           // {abort word, workgroups arrived}
+    unsigned wideExpect;        // workgroups the residency check waits for; 0 = the grid (a test passes one more: the check must fail)
 };
 
 // mode: 0 NW, 1 SHW, 2 HW.  store: also write the column store.

@@ -161,7 +161,7 @@ scan_pairs_wide_kernel(const PairScanArgs a)
     extern __shared__ __attribute__((aligned(16))) u32 s_peq32[];    // [sigmaT][64] words of 32 rows
     const int lane = threadIdx.x;
     const int slot = blockIdx.x, W = gridDim.x, unit = blockIdx.y;
-    if (W > 1 && !wide_all_resident(a.wabort, gridDim.x * gridDim.y)) return;     // (before any other exit: everybody counts)
+    if (W > 1 && !wide_all_resident(a.wabort, a.wideExpect ? a.wideExpect : gridDim.x * gridDim.y)) return;     // (before any other exit: everybody counts)
     const PairDesc d = a.descs[unit];
     const int m = d.qlen, T = d.tlen, K = d.kinit;
     const int nw = num_words(m), nb64 = num_blocks(m), nstrips = (nw + 63) >> 6;

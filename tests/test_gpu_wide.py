@@ -182,11 +182,11 @@ def test_concurrent_callers_take_turns_on_the_wide_kernel(engine, checker):
 @pytest.mark.parametrize("where", ["process", "stream"])
 def test_wide_launch_survives_a_cu_hog(engine, checker, where):
     """Something else holds all but 12 wave slots of the device (tools/cu_hog.hip) while a 30 k x 30 k NW call wants 30
-    workgroups that wait for each other.  "process": a second PROCESS (the device's scheduler decides what shares the CUs:
-    on this pool the call simply waits its turn); "stream": a second stream of THIS process -- the launch fits only in
-    part, its workgroups notice at entry (wide_kernels.hip: wide_all_resident), and the units run again with one slot
-    each, which never waits.  Either way the call returns the right distance, not EDLIB_STATUS_ERROR (the reference
-    always returns: edlib.cpp:197-217)."""
+    workgroups that wait for each other: a second PROCESS, or a second stream of THIS process.  Whatever the device's
+    scheduler makes of it -- on this pool the call waits its turn in both cases; a launch that fitted only in part
+    would notice at entry (wide_kernels.hip: wide_all_resident) and run again with one slot per unit -- the call
+    returns the right distance, not EDLIB_STATUS_ERROR, and does not hang (the reference always returns:
+    edlib.cpp:197-217).  The rerun itself is exercised by the next test."""
     import ctypes
     import subprocess
     import time
@@ -225,10 +225,40 @@ def test_wide_launch_survives_a_cu_hog(engine, checker, where):
             else:
                 assert lib.cu_hog_wait() == 0
         assert got["status"] == 0 and got["editDistance"] == want["editDistance"] and got["endLocations"] == want["endLocations"]
-        if where == "stream" and resident == total:   # the hog really held the device: 30 workgroups could not all start
-            assert st["wide_retries"] >= 1 and wall < 3.0, (st, wall)
-        assert wall < 20, wall
+        assert resident <= total and wall < 20, (resident, total, wall, st["wide_retries"])
         st = b.run()                                  # the hog is gone: pipelined again
         assert st["wide_retries"] == 0 and b.results()[0]["editDistance"] == want["editDistance"]
     finally:
         b.close()
+
+
+def test_wide_rerun_with_one_slot_after_a_launch_that_is_not_resident(engine, checker, ref):
+    """EDLIB_AMD_WIDE_TEST_NOT_RESIDENT makes the residency check of every pipelined launch wait for one workgroup more
+    than the launch has: it gives up after 0.2 s exactly as if part of the launch had not fitted the device, the launch's
+    waves leave, and the same units run again with ONE slot each (a wave then only reads granules it wrote itself) --
+    right answers for distances (two half scans), Hirschberg paths on the wide band, long SHW / HW queries; the next run
+    without the hook is pipelined again."""
+    rng = random.Random(9200 + SEED_SHIFT)
+    q, t = _mut(rng, 30000, 0.05, 0.025, 0.025)
+    want = checker.align(q, t, "NW", "distance", -1)
+    b = engine.PairBatch([q], [t], mode="NW", task="distance", k=-1)
+    try:
+        with _env(EDLIB_AMD_WIDE_TEST_NOT_RESIDENT="1"):
+            st = b.run()
+        assert st["wide_retries"] >= 1 and b.results()[0]["editDistance"] == want["editDistance"]
+        st = b.run()
+        assert st["wide_retries"] == 0 and b.results()[0]["editDistance"] == want["editDistance"]
+    finally:
+        b.close()
+    with _env(EDLIB_AMD_WIDE_TEST_NOT_RESIDENT="1"):
+        qs, ts = [], []
+        for n, rate in ((33000, 0.06), (36000, 0.25)):
+            a, c = _mut(rng, n, rate / 2, rate / 4, rate / 4)
+            qs.append(a); ts.append(c)
+        _check(engine, checker, qs, ts, "NW", "distance", -1, "rerun: distances")
+        if ref is not None:
+            _check(engine, ref, qs[:1], ts[:1], "NW", "path", -1, "rerun: Hirschberg on the wide band")
+        tq = synth.random_dna(31, 9000).tobytes()
+        tt = synth.random_dna(32, 20000).tobytes()
+        for mode in ("SHW", "HW"):
+            _check(engine, checker, [tq], [tt], mode, "locations", -1, "rerun: long %s query" % mode)
