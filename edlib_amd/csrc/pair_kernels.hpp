@@ -120,7 +120,8 @@ hipError_t launch_build_peq_pairs(const PairDesc* descs, int numUnits, const uin
 
 // ---- lane rings of 32-row words (ring32_kernels.hip): NW pairs of a batch too small to fill the chip (lone waves: bound
 // by the latency of their own instruction stream), with the column store as 8-byte entries (the two planes of StoreEntry on
-// 32 rows) at (storeOff + (column + word) * G + word % G) of the u64 view of PairScanArgs::store, and a lane-parallel walk.
+// 32 rows) in lines of eight steps per ring lane ([group of 8 steps][ring lane][step & 7] behind storeOff, in the u64 view
+// of PairScanArgs::store; step = column + word), and a lane-parallel walk.
 // G in {4, 8, 16}; the band of desc.kinit must fit the ring (kinit <= ring32_max_k(G)) or all words sit on it (any kinit).
 // Forward units only (qstep = tstep = 1, no bandT / colOff); needs PairScanArgs::tsym; a launch's store stays below 4 GB.
 constexpr int ring32_max_k(int G) { return 32 * (G - 2); }

@@ -26,9 +26,12 @@
 //   * target symbols come from a pre-mapped symbol pool (target_symbols_kernel) through a 256-slot LDS ring per unit
 //     that is refilled 64 columns at a time: the loads are issued at one refill and committed to LDS at the NEXT one, so
 //     no step ever waits for global memory;
-//   * STORE: the two planes of a block-step (pair_kernels.hpp StoreEntry, on 32 rows: 8 bytes) go out through a buffer
-//     resource whose out-of-range offsets drop the stores of lanes outside their word's life (no exec juggling, and
-//     only the band is written: ~5 of 8 lanes at K = 128);
+//   * STORE: the two planes of a block-step (pair_kernels.hpp StoreEntry, on 32 rows: 8 bytes) stay in registers for eight
+//     steps and go out as the lane's own 64-byte line of the group ([group of 8 steps][ring lane][step]), through a buffer
+//     resource whose out-of-range offsets drop the lines of lanes that were outside their word's life for the whole group
+//     (no exec juggling, only the band is written: ~5 of 8 lanes at K = 128) -- and the walk, which follows ONE word
+//     through consecutive columns, finds eight of its entries per line (round 5's first layout, [step][lane], had it
+//     fetch a 64-byte line per column for 8 bytes of it: 0.67 GB of reads for config 5);
 //   * the walk (traceback32_kernel) takes 32 cells of the current DIAGONAL per trip: lane i looks at cell (r - i, c - i),
 //     a ballot over "an indel move is possible here" finds the end of the run of diagonal moves, the lanes before it
 //     write their MATCH / MISMATCH ops side by side, and the cell that stopped the run is resolved with the reference's
@@ -51,7 +54,11 @@ __host__ __device__ static inline int num_words(int m) { return (m + 31) >> 5; }
 #define R32_AND_OR(a, b, c)   ((u32)__builtin_amdgcn_bitop3_b32((a), (b), (c), 0xea))   /* (a & b) | c   */
 #define R32_ANDN_OR(a, b, c)  ((u32)__builtin_amdgcn_bitop3_b32((a), (b), (c), 0x0e))   /* ~a & (b | c)  */
 
-long long ring32_store_entries(int G, int qlen, int tlen) { return ((long long)tlen + num_words(qlen) + 1) * G; }
+// Column store of one unit: 8-byte entries in groups of 8 steps, [group][ring lane][step & 7]: a ring lane's eight entries of a
+// group are one 64-byte line -- written by that lane alone (a lane outside its word's life for the whole group writes
+// nothing), and what the walk reads when it follows a word through consecutive columns.
+__host__ __device__ static inline long long ring32_entry(int G, long long t, int ringLane) { return (((t >> 3) * G + ringLane) << 3) + (t & 7); }
+long long ring32_store_entries(int G, int qlen, int tlen) { return ((((long long)tlen + num_words(qlen) + 1) >> 3) + 2) * G * 8; }
 
 // LDS words (u32) of one unit's Peq on this kernel: [symbol][rowStride] + a skew of G words, so that the rings of a wave
 // (whose lanes hold the same word indices at the same time) start in different banks
@@ -153,7 +160,7 @@ template <typename T> __device__ __forceinline__ T wave_max(T v) {
 
 // NW inside Ukkonen's band of threshold K = desc.kinit (exact iff the result is <= K; any K when all words sit on the
 // ring).  Forward units only (tstep = +1; the target is read through a.tsym).  STORE: the two planes of every word-step
-// inside the band at entry (storeOff + t * G + ring lane) of the u64 view of a.store, t = column + word.
+// inside the band at entry storeOff + ring32_entry(G, t, ring lane) of the u64 view of a.store, t = column + word.
 template <int G, bool STORE>
 __global__ void __launch_bounds__(64)
 scan_pairs_ring32_kernel(const PairScanArgs a, const int rowStride, const int peqStride)
@@ -250,7 +257,9 @@ scan_pairs_ring32_kernel(const PairScanArgs a, const int rowStride, const int pe
     // column store: 8 bytes per word-step through a buffer resource; a lane outside its word's life stores out of range
     // (the caller keeps the store of a launch below 4 GB - 16: a 32-bit byte offset per lane; 0xffffffff is out of range)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(a.store), 0, (int)0xfffffff0u, 0x00020000);
-    u32 soff = STORE ? (u32)(8ull * ((u64)dp->storeOff + (u64)rl)) : 0u, dead = ~0u;
+    u32 soff = STORE ? (u32)(8ull * ((u64)dp->storeOff + 8ull * (u64)rl)) : 0u, dead = ~0u;
+    u32 gdead = ~0u;                                                  // all ones while the lane has been outside its word's life for the whole group
+    u32 px[8], py[8];                                                 // the planes of the group's eight steps
 
     // The rare part of a step: some lane's word has just finished (its last update was step t - 1) or starts now.
     auto events = [&](const int t, const u32 A, const u32 Bm, u32& eqCur, u32& offCur) {
@@ -287,7 +296,7 @@ scan_pairs_ring32_kernel(const PairScanArgs a, const int rowStride, const int pe
 
     // One step.  eqCur / offCur: Peq word of this step's column and row offset of the next column (fetched by the previous
     // step); eqNxt / offNxt are fetched here for the next step -- the caller swaps the two register sets every step.
-    auto step = [&](const int t, u32& eqCur, u32& eqNxt, u32& offCur, u32& offNxt) {
+    auto step = [&](const int t, u32& eqCur, u32& eqNxt, u32& offCur, u32& offNxt, u32& outX, u32& outY) {
         const u32 A = ring32_rot<G>(PhOut, firstLane), Bm = ring32_rot<G>(MhOut, firstLane);
         if (__builtin_amdgcn_ballot_w64(ev == 0) != 0ull) events(t, A, Bm, eqCur, offCur);
         --ev;
@@ -313,15 +322,27 @@ scan_pairs_ring32_kernel(const PairScanArgs a, const int rowStride, const int pe
         accM = __builtin_amdgcn_alignbit(accM, MhOut, 31);
         if constexpr (STORE) {
             // the planes of pair_kernels.hpp StoreEntry on 32 rows: x = Pv | Ph, y = ~Pv & (Ph | Xh)
-            const u32 px = Pv | ph, py = R32_ANDN_OR(Pv, ph, xh);
-            typedef u32 u32x2 __attribute__((ext_vector_type(2)));
-            u32x2 v; v.x = px; v.y = py;
-            __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, (int)(soff | dead), 0, 0);
-            soff += 8u * (u32)G;
+            outX = Pv | ph; outY = R32_ANDN_OR(Pv, ph, xh);
+            gdead &= dead;
+        }
+    };
+    // the lane's line of the group that has just ended: eight entries = 64 bytes, four 16-byte stores (the line of a lane
+    // that was dead for the whole group has an out-of-range offset: dropped)
+    auto flush = [&]() {
+        if constexpr (STORE) {
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            const int voff = (int)(soff | gdead);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                u32x4 v; v.x = px[2 * k]; v.y = py[2 * k]; v.z = px[2 * k + 1]; v.w = py[2 * k + 1];
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 16 * k, 0);
+            }
+            soff += 64u * (u32)G;
+            gdead = ~0u;
         }
     };
 
-    for (int t = 0; t <= nstepsU; t += 2) {
+    for (int t = 0; t <= nstepsU; t += 8) {
         if ((t & 31) == 0) {
             fold();                                                   // (the accumulators hold 32 steps)
             if ((t & 63) == 0 && t > 0) {
@@ -332,8 +353,15 @@ scan_pairs_ring32_kernel(const PairScanArgs a, const int rowStride, const int pe
                 if (active && written < jmax + 66 + 64) { commit(); issue(); }
             }
         }
-        step(t, eqA, eqB, offA, offB);
-        step(t + 1, eqB, eqA, offB, offA);
+        step(t, eqA, eqB, offA, offB, px[0], py[0]);
+        step(t + 1, eqB, eqA, offB, offA, px[1], py[1]);
+        step(t + 2, eqA, eqB, offA, offB, px[2], py[2]);
+        step(t + 3, eqB, eqA, offB, offA, px[3], py[3]);
+        step(t + 4, eqA, eqB, offA, offB, px[4], py[4]);
+        step(t + 5, eqB, eqA, offB, offA, px[5], py[5]);
+        step(t + 6, eqA, eqB, offA, offB, px[6], py[6]);
+        step(t + 7, eqB, eqA, offB, offA, px[7], py[7]);
+        flush();
     }
 }
 
@@ -399,7 +427,7 @@ traceback32_kernel(const TracebackArgs a, const int G)
         const int ri = r - sub, ci = c - sub;
         const bool valid = !done && ri >= 0 && ci >= 0;
         u64 e = 0;
-        if (valid) { const int wi = ri >> 5; e = S[(long long)(ci + wi) * G + (wi & (G - 1))]; }
+        if (valid) { const int wi = ri >> 5; e = S[ring32_entry(G, (long long)ci + wi, wi & (G - 1))]; }
         const u32 xw = (u32)e, yw = (u32)(e >> 32);
         const u32 bit = (u32)ri & 31u;
         const bool xb = (xw >> bit) & 1u, yb = (yw >> bit) & 1u;

@@ -2,7 +2,8 @@
 """Batches of SHORT independent pairs (the verification step of a seed-and-extend mapper): n reads of 150 bases, each
 against its own window -- HW against a 400-base window around its origin, NW against its 150-base mutated mate, and
 100 x 100 NW; distances, start locations, paths.  Resident run time (`run_ms`: everything up to the results sitting in
-HBM), the collection behind it (`results_ms`: download + per-unit records + flat arrays, paid once per results call),
+HBM), the collection behind it (`results_ms`: edlibAmdBatchResultsView -- the caller-facing arrays laid out by device
+kernels, one block to pinned host memory; `results_copy_ms`: the same as owned numpy copies), both per 1,000 pairs too,
 GCUPS, and a strided sample checked against the oracle."""
 import sys, os, json, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -21,7 +22,9 @@ out = []
 def run(name, q, t, mode, task="distance"):
     b = edlib_amd.PairBatch(q, t, mode=mode, task=task)
     b.run(); st = b.run()
-    t0 = time.perf_counter(); got = b.results_flat(); results_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter(); got = b.results_flat(copy=False); results_ms = (time.perf_counter() - t0) * 1e3
+    b.run()
+    t0 = time.perf_counter(); got = b.results_flat(); copy_ms = (time.perf_counter() - t0) * 1e3
     b.close()
     nq, mq = q.shape; nt, mt = t.shape
     sel = np.arange(0, nq, max(1, nq // 256), dtype=np.int32)
@@ -35,8 +38,10 @@ def run(name, q, t, mode, task="distance"):
         ao, ro = got["alnOff"], ref["alnOff"]
         ok = all(np.array_equal(got["alignment"][ao[i]:ao[i + 1]], ref["alignment"][ro[j]:ro[j + 1]]) for j, i in enumerate(sel))
     out.append({"case": name, "pairs": nq, "run_ms": round(st["run_ms"], 2), "results_ms": round(results_ms, 2),
+                "results_copy_ms": round(copy_ms, 2), "results_over_run": round(results_ms / st["run_ms"], 2),
                 "gcups": round(st["cells"] / st["run_ms"] / 1e6, 1),
-                "us_per_1k_pairs": round(st["run_ms"] * 1e3 / (nq / 1000.0), 1), "sample_ok": ok})
+                "us_per_1k_pairs": round(st["run_ms"] * 1e3 / (nq / 1000.0), 1),
+                "us_per_1k_pairs_results": round(results_ms * 1e3 / (nq / 1000.0), 1), "sample_ok": ok})
 
 
 start = np.clip(np.asarray(pos, dtype=np.int64) - 125, 0, len(T) - 400)
