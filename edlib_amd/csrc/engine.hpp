@@ -304,7 +304,7 @@ private:
     bool flatRing32_ = false; int flatG32_ = 8, flatMaxWords_ = 0;
     DevBuf<uint8_t> d_tsym_;
     // the caller-facing arrays of the last run: made on the device for a flat batch (buildFlatView), from the records otherwise
-    DevBuf<uint8_t> d_view_; PinBuf h_view_; bool viewReady_ = false;
+    DevBuf<uint8_t> d_view_; PinBuf h_view_, h_viewVar_; bool viewReady_ = false;     // host: per-unit fields + offsets / locations + op bytes
     EdlibAmdResultsView view_{};
     const uint8_t* viewAlnDev_ = nullptr; const long long* viewAlnOffDev_ = nullptr;     // the dense op bytes on the device (CIGARs)
     std::vector<int> viewInts_; std::vector<long long> viewOffs_; std::vector<uint8_t> viewOps_;   // host-made view of a general batch

@@ -432,9 +432,10 @@ int Batch::buildFlatView()
     const size_t oLocOff = take((n + 1) * 8), oAlnOff = take((n + 1) * 8), oBlockLoc = take(nblocks * 8), oBlockAln = take(nblocks * 8);
     const size_t oTotals = take(16);
     const size_t headBytes = at;
+    // (device: room for every location / op byte the batch could have; host: the fixed part now, the rest once the totals are known)
     const size_t oEnds = take((size_t)capLoc * 4), oStarts = wantStarts ? take((size_t)capLoc * 4) : 0, oAln = take((size_t)capAln + 16);
     EDLIB_AMD_HIP(d_view_.ensure(at));
-    if (h_view_.n < at) EDLIB_AMD_HIP(h_view_.alloc(at));
+    if (h_view_.n < headBytes) EDLIB_AMD_HIP(h_view_.alloc(headBytes));
     uint8_t* const dv = d_view_.p; uint8_t* const hv = h_view_.p;
     FlatResultArgs a{};
     a.descs = d_flatDescs_.p; a.n = n_; a.mode = scanMode; a.k = cfg_.k; a.wantPath = wantPath ? 1 : 0; a.posCap = kFlatPosCap;
@@ -459,9 +460,15 @@ int Batch::buildFlatView()
     const long long* totals = reinterpret_cast<const long long*>(hv + oTotals);
     const long long nloc = totals[0], naln = totals[1];
     if (nloc < 0 || nloc > capLoc || naln < 0 || naln > capAln) { set_error("flat results: totals out of range"); return 1; }
-    if (nloc) EDLIB_AMD_HIP(hipMemcpyAsync(hv + oEnds, dv + oEnds, (size_t)nloc * 4, hipMemcpyDeviceToHost, stream_));
-    if (nloc && wantStarts) EDLIB_AMD_HIP(hipMemcpyAsync(hv + oStarts, dv + oStarts, (size_t)nloc * 4, hipMemcpyDeviceToHost, stream_));
-    if (naln) EDLIB_AMD_HIP(hipMemcpyAsync(hv + oAln, dv + oAln, (size_t)naln, hipMemcpyDeviceToHost, stream_));
+    // the variable part in a pinned block of its own, sized by what there is (a block for everything a batch COULD have --
+    // 146 MB of op slots for 262,144 x 150 bp HW paths that come to 39 MB -- cost its pinning on the first collection)
+    const size_t vEnds = 0, vStarts = ((size_t)nloc * 4 + 63) & ~(size_t)63, vAln = vStarts + (wantStarts ? vStarts : 0);
+    const size_t varBytes = vAln + (size_t)naln + 64;
+    if (h_viewVar_.n < varBytes) EDLIB_AMD_HIP(h_viewVar_.alloc(varBytes + varBytes / 8));
+    uint8_t* const hvar = h_viewVar_.p;
+    if (nloc) EDLIB_AMD_HIP(hipMemcpyAsync(hvar + vEnds, dv + oEnds, (size_t)nloc * 4, hipMemcpyDeviceToHost, stream_));
+    if (nloc && wantStarts) EDLIB_AMD_HIP(hipMemcpyAsync(hvar + vStarts, dv + oStarts, (size_t)nloc * 4, hipMemcpyDeviceToHost, stream_));
+    if (naln) EDLIB_AMD_HIP(hipMemcpyAsync(hvar + vAln, dv + oAln, (size_t)naln, hipMemcpyDeviceToHost, stream_));
     if (alphaPending_ && !alphaOnDevice) { EDLIB_AMD_HIP(hipStreamSynchronize(side_)); }
     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
     alphaPending_ = false;
@@ -470,9 +477,9 @@ int Batch::buildFlatView()
     view_.status = reinterpret_cast<const int*>(hv + oStatus); view_.editDistance = reinterpret_cast<const int*>(hv + oEd);
     view_.numLocations = reinterpret_cast<const int*>(hv + oNloc); view_.alphabetLength = reinterpret_cast<const int*>(hv + oAlpha);
     view_.locOffsets = reinterpret_cast<const long long*>(hv + oLocOff); view_.alnOffsets = reinterpret_cast<const long long*>(hv + oAlnOff);
-    view_.endLocations = reinterpret_cast<const int*>(hv + oEnds);
-    view_.startLocations = wantStarts ? reinterpret_cast<const int*>(hv + oStarts) : nullptr;
-    view_.alignment = wantPath ? hv + oAln : nullptr;
+    view_.endLocations = reinterpret_cast<const int*>(hvar + vEnds);
+    view_.startLocations = wantStarts ? reinterpret_cast<const int*>(hvar + vStarts) : nullptr;
+    view_.alignment = wantPath ? hvar + vAln : nullptr;
     viewAlnDev_ = dv + oAln; viewAlnOffDev_ = reinterpret_cast<const long long*>(dv + oAlnOff);
     // ---- what the device does not know
     int* alpha = reinterpret_cast<int*>(hv + oAlpha);
@@ -488,7 +495,7 @@ int Batch::buildFlatView()
     }
     // start locations beyond the 16 a unit's flat list keeps (a unit of the exact second pass, HW): their reverse scans run now
     if (flatStarts_ && !flatOvfUnit_.empty()) {
-        int* starts = reinterpret_cast<int*>(hv + oStarts);
+        int* starts = reinterpret_cast<int*>(hvar + vStarts);
         std::vector<UnitSpec> late; std::vector<long long> where;
         for (int u : flatOvfUnit_) {
             const int ed = view_.editDistance[u], m = qlen(u);

@@ -21,7 +21,9 @@ out = []
 
 def run(name, q, t, mode, task="distance"):
     b = edlib_amd.PairBatch(q, t, mode=mode, task=task)
-    b.run(); st = b.run()
+    b.run()
+    t0 = time.perf_counter(); b.results_flat(copy=False); first_ms = (time.perf_counter() - t0) * 1e3   # (pays the pinned blocks of the session)
+    st = b.run()
     t0 = time.perf_counter(); got = b.results_flat(copy=False); results_ms = (time.perf_counter() - t0) * 1e3
     b.run()
     t0 = time.perf_counter(); got = b.results_flat(); copy_ms = (time.perf_counter() - t0) * 1e3
@@ -38,7 +40,8 @@ def run(name, q, t, mode, task="distance"):
         ao, ro = got["alnOff"], ref["alnOff"]
         ok = all(np.array_equal(got["alignment"][ao[i]:ao[i + 1]], ref["alignment"][ro[j]:ro[j + 1]]) for j, i in enumerate(sel))
     out.append({"case": name, "pairs": nq, "run_ms": round(st["run_ms"], 2), "results_ms": round(results_ms, 2),
-                "results_copy_ms": round(copy_ms, 2), "results_over_run": round(results_ms / st["run_ms"], 2),
+                "results_copy_ms": round(copy_ms, 2), "results_first_call_ms": round(first_ms, 2),
+                "results_over_run": round(results_ms / st["run_ms"], 2),
                 "gcups": round(st["cells"] / st["run_ms"] / 1e6, 1),
                 "us_per_1k_pairs": round(st["run_ms"] * 1e3 / (nq / 1000.0), 1),
                 "us_per_1k_pairs_results": round(results_ms * 1e3 / (nq / 1000.0), 1), "sample_ok": ok})
