@@ -379,6 +379,47 @@ alphabet_count_kernel(const uint8_t* __restrict__ qpool, const long long* __rest
     if (threadIdx.x == 0) out[blockIdx.x] = n;
 }
 
+// The same count for batches of SHORT sequences: a wave per unit, four units per workgroup (a workgroup per unit has
+// three idle waves and a launch of 262,144 workgroups for as many 150-base pairs: ~1 ms on the side stream, which the
+// collection of a flat batch then waited for).  Each wave owns 256 bytes of the table.
+__global__ void __launch_bounds__(256)
+alphabet_count_short_kernel(const uint8_t* __restrict__ qpool, const long long* __restrict__ qoff,
+                            const uint8_t* __restrict__ tpool, const long long* __restrict__ toff,
+                            int shared, const uint32_t* __restrict__ basePresence,
+                            const int* __restrict__ unitIdx, int n, int* __restrict__ out)
+{
+    __shared__ uint32_t s_seen[4][64];                               // per wave: 256 one-byte marks
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 4 + wv;
+    if (slot >= n) return;
+    uint8_t* const seen = reinterpret_cast<uint8_t*>(s_seen[wv]);
+    s_seen[wv][lane] = 0u;
+    const int u = unitIdx[slot];
+    auto scan = [&](const uint8_t* pool, long long lo, long long hi) {
+        for (long long c = (lo >> 4) + lane; (c << 4) < hi; c += 64) {
+            const uint4 v = *reinterpret_cast<const uint4*>(pool + (c << 4));
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+            const long long at = c << 4;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (at + k >= lo && at + k < hi) seen[(d[k >> 2] >> (8 * (k & 3))) & 0xffu] = 1;
+        }
+    };
+    scan(qpool, qoff[u], qoff[u + 1]);
+    if (!shared) scan(tpool, toff[u], toff[u + 1]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t w = s_seen[wv][lane];                                   // four marks
+    if (shared) {
+        const uint32_t bits = (basePresence[lane >> 3] >> (4 * (lane & 7))) & 0xfu;
+        w |= (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21);
+    }
+    int cnt = ((w & 0xffu) != 0) + ((w & 0xff00u) != 0) + ((w & 0xff0000u) != 0) + ((w & 0xff000000u) != 0);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (lane == 0) out[slot] = cnt;
+}
+
 // overflow census of the reads path: how many slots need the exact second pass
 __global__ void __launch_bounds__(256)
 count_flags_kernel(const int* __restrict__ flags, int n, int* __restrict__ counter)
@@ -526,6 +567,7 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
         long long total = 0;
         for (int u : alphaUnits_) total += qlen(u) + (shared_ ? 0 : tlen(u));
         alphaOnHost_ = h_in_.p && d_qpool_.p && !d_qpool_.owned && total <= 65536;
+        alphaBytes_ = total;
     }
 
     // reads-per-lane groups: one per query word count, slots padded to whole waves
@@ -1476,6 +1518,11 @@ int Batch::alphabetLengthsBegin()
     // the inputs went up on stream_ (init): the side stream starts behind whatever stream_ holds now
     EDLIB_AMD_HIP(hipEventRecord(evA_.e, stream_));
     EDLIB_AMD_HIP(hipStreamWaitEvent(side_, evA_.e, 0));
+    if (alphaBytes_ <= 4096LL * (long long)n)                        // short sequences: a wave per unit
+        hipLaunchKernelGGL(alphabet_count_short_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, side_,
+                           d_qpool_.p, d_qoff_.p, d_tpool_.p, d_toff_.p, shared_ ? 1 : 0, d_presence_.p,
+                           d_alphaIdx_.p, (int)n, d_alphaOut_.p);
+    else
     hipLaunchKernelGGL(alphabet_count_kernel, dim3((unsigned)n), dim3(256), 0, side_,
                        d_qpool_.p, d_qoff_.p, d_tpool_.p, d_toff_.p, shared_ ? 1 : 0, d_presence_.p,
                        d_alphaIdx_.p, d_alphaOut_.p);

@@ -242,7 +242,7 @@ private:
     // alphabetLength of the empty / pair units: launched on a side stream before phase 1, collected after it
     int alphabetLengthsBegin();
     int alphabetLengthsEnd(std::vector<UnitResult>& res);
-    std::vector<int> alphaUnits_; bool alphaOnHost_ = false, alphaPending_ = false;
+    std::vector<int> alphaUnits_; bool alphaOnHost_ = false, alphaPending_ = false; long long alphaBytes_ = 0;
     hipStream_t side_ = nullptr;
     DevBuf<int> d_alphaIdx_, d_alphaOut_; PinBuf alphaPin_;
     // linear-space paths (reference obtainAlignmentHirschberg, edlib.cpp:1231-1396)
