@@ -72,10 +72,7 @@ int size_class(size_t bytes, size_t* rounded) {
 static thread_local bool tl_quarantine = false;
 void pool_quarantine(bool on) { tl_quarantine = on; }
 
-static bool pool_enabled() {
-    static const bool on = !(getenv("EDLIB_AMD_NOPOOL") && getenv("EDLIB_AMD_NOPOOL")[0] == '1');
-    return on && !tl_quarantine;
-}
+static bool pool_enabled() { return !tl_quarantine; }
 
 void pool_trim() {
     Pool& P = pool();
@@ -538,17 +535,12 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
     const int modeIn = (int)cfg.mode;
     const bool readsOk = shared_ && tlen(0) > 0 && (tab_.sigmaT <= 4 || (tab_.sigmaT <= 16 && modeIn == EDLIB_MODE_HW));
     syms_ = tab_.sigmaT <= 4 ? 4 : (tab_.sigmaT <= 8 ? 8 : 16);
-    {
-        const char* env = getenv("EDLIB_AMD_BAND");
-        banded_ = (mode == EDLIB_MODE_HW) && (!(env && env[0] == '0') || syms_ > 4);   // more than 4 symbols: banded kernel only
-    }
-    // reads of 257..1024 bases (..512 above four target symbols): banded / full-height HW kernels only (EDLIB_AMD_LONGREADS=0: pair path)
-    static const bool longReads = !(getenv("EDLIB_AMD_LONGREADS") && getenv("EDLIB_AMD_LONGREADS")[0] == '0');
+    banded_ = mode == EDLIB_MODE_HW;
     // HW queries longer than kernel A's 256 rows against the shared target: piece filter + window verification
     // (long_reads.hip); EDLIB_AMD_FILTER=0 restores the groups of 12 / 16 / 24 / 32 words (up to 1024 bases) and kernel W
     static const bool filterOn = !(getenv("EDLIB_AMD_FILTER") && getenv("EDLIB_AMD_FILTER")[0] == '0');
     const bool filter = filterOn && readsOk && banded_ && modeIn == EDLIB_MODE_HW;
-    const int maxReadLen = 32 * ((banded_ && modeIn == EDLIB_MODE_HW && syms_ <= 8 && longReads && !filter)
+    const int maxReadLen = 32 * ((banded_ && modeIn == EDLIB_MODE_HW && syms_ <= 8 && !filter)
                                      ? (syms_ == 4 ? kMaxLongReadWords4 : kMaxLongReadWords) : kMaxReadWords);
     std::vector<std::vector<int>> byWords(kMaxLongReadWords4 + 1);
     for (int u = 0; u < n; ++u) {
@@ -606,7 +598,7 @@ int Batch::makeGroup(const std::vector<int>& units, int w, std::unique_ptr<ReadG
     if (mode == EDLIB_MODE_HW) {
         // enough waves to fill 256 CUs x 4 SIMDs x 8 slots many times over, segments >= 4096 columns
         // ~16 waves per resident slot: the launch ends on a thin tail (65,536 -> 131,072 waves: +1 % at 1M reads)
-        static const long long wantWaves = getenv("EDLIB_AMD_WAVES") ? atoll(getenv("EDLIB_AMD_WAVES")) : 131072;
+        const long long wantWaves = 131072;
         g->warm = 2 * 32 * w - 1;                        // 2m-1 columns
         long long S = (wantWaves + nrblk - 1) / nrblk;
         // gridDim.y limit; segments of at least 4096 columns and four warm-ups (the groups of 24 / 32 words warm up
@@ -738,14 +730,14 @@ int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, i
                 g.nwords, mode, nlanes, numSegments, segLen, warm, cap, kcap, (const void*)d_slotmap, (const void*)posOff);
     }
     scanTimerStart();
-    // full-height HW scans (pass 2 over unrelated reads): 0 = scan_reads_kernel (register-resident rows, 4 symbols only:
-    // 288 ms per 1M-read step), 1 = scan_reads_full_kernel (LDS rows picked by M0, any symbol count: 314 ms),
-    // 2 = the banded kernel at full height (325 ms).  Default: 0 for four symbols, 1 above.
-    static const int pass2Kernel = getenv("EDLIB_AMD_PASS2") ? atoi(getenv("EDLIB_AMD_PASS2")) : 0;
+    // full-height HW scans (pass 2 over unrelated reads): scan_reads_kernel for four symbols (register-resident rows: 288 ms
+    // per 1M-read step; the full-height kernel with LDS rows picked by M0 took 314 ms there, the banded kernel at full
+    // height 325 ms: measured in round 2, the variants are gone), scan_reads_full_kernel above four symbols and for the
+    // long word groups
     const bool longGroup = g.nwords > kMaxReadWords;                  // no plain kernel for 12 / 16 words
     // columns a lane walks: the segments' own columns (a launch may cover a prefix of the target only) and their warm-ups
     const long long colsScanned = std::min<long long>(a.targetLength, (long long)numSegments * segLen) + (long long)(numSegments - 1) * warm;
-    const bool fullHeight = banded_ && mode == EDLIB_MODE_HW && unbanded && (chained || ((pass2Kernel == 1 || syms_ > 4 || longGroup) && pass2Kernel != 2));
+    const bool fullHeight = banded_ && mode == EDLIB_MODE_HW && unbanded && (chained || syms_ > 4 || longGroup);
     if (fullHeight) {
         EDLIB_AMD_HIP(launch_scan_reads_full(g.nwords, syms_, a, stream_));
         stats.word_steps += (long long)((nlanes + 63) / 64 * 64) * g.nwords * colsScanned;
@@ -866,8 +858,7 @@ int Batch::runGroupScans(ReadGroup& g, bool fullOnly)
         // read that reaches it a band of about 1 + (t - 6) / 8 words per column; it pays when what it resolves
         // would otherwise meet a taller band.  All subsets of {12, 16, 24, 32, 48, 64} are priced; reads at
         // Illumina-like error rates (leftovers = unrelated sequence) keep the two levels they always had.
-        static const bool ladderOn = !(getenv("EDLIB_AMD_LADDER") && getenv("EDLIB_AMD_LADDER")[0] == '0');
-        if (twoPass && ladderOn && (int)open.size() * 10 > real && open.size() >= 32) {
+        if (twoPass && (int)open.size() * 10 > real && open.size() >= 32) {
             const int kTop = std::min(64, 32 * g.nwords - 1);
             std::vector<int> obest;
             if (probe_scan(open, kTop, obest)) return 1;
@@ -958,7 +949,7 @@ int Batch::runGroupScans(ReadGroup& g, bool fullOnly)
                 EDLIB_AMD_HIP(hipMemcpyAsync(&ws, d_ws.p, sizeof ws, hipMemcpyDeviceToHost, stream_));
                 EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
                 const double cols = (double)np2 * ((double)T + (double)(S3 - 1) * warm3);
-                plain = (double)ws >= 0.85 * g.nwords * cols && !getenv("EDLIB_AMD_PASS2_BANDED");
+                plain = (double)ws >= 0.85 * g.nwords * cols;
                 stats.word_steps += (long long)ws;
             }
             // The leftovers are scattered over the batch: through the slot map every lane of a wave would pull its
@@ -979,10 +970,9 @@ int Batch::runGroupScans(ReadGroup& g, bool fullOnly)
             // write traffic per 1M-read step in round 2).  The first columns of the target give every lane a score that
             // some column does reach; all segments start from that one (results do not depend on it: the best over
             // the whole target is at most that score, and equal scores are still recorded).
-            static const bool seedOn = !(getenv("EDLIB_AMD_SEED") && getenv("EDLIB_AMD_SEED")[0] == '0');
             const int seedCols = 4096;                               // (a lone wave per SIMD: 0.27 ms)
             DevBuf<int> d_b0, d_c0, d_p0;                            // (live until the synchronisation below)
-            if (seedOn && mode == EDLIB_MODE_HW && last && no >= 4096 && S2 > 1 && T >= 16 * seedCols) {
+            if (mode == EDLIB_MODE_HW && last && no >= 4096 && S2 > 1 && T >= 16 * seedCols) {
                 EDLIB_AMD_HIP(d_b0.alloc(no)); EDLIB_AMD_HIP(d_c0.alloc(no)); EDLIB_AMD_HIP(d_p0.alloc(no * 8));
                 if (scanGroup(g, mode, nullptr, (int)no, kcapL, d_kinit2.p, 1, seedCols, 0,
                               d_b0.p, d_c0.p, d_p0.p, 8, nullptr, nullptr, plain, nullptr, d_peq2.p, d_qlen2.p)) return 1;
@@ -1582,12 +1572,11 @@ int Batch::hirschbergLevel(const std::vector<PathPiece>& big, std::vector<int>& 
     static const int rings[kNumRings + 1] = {4, 8, 16, 21, 32, 64, 0};
     // (packing only pays with enough pieces to fill the chip: a handful of long pieces runs faster one per wave)
     const bool packed = np >= 256;
-    const bool wideOffEarly = getenv("EDLIB_AMD_WIDE") && getenv("EDLIB_AMD_WIDE")[0] == '0';
     auto ring_of = [&](const PathPiece& pc) {
         const bool off = getenv("EDLIB_AMD_NWBAND") && getenv("EDLIB_AMD_NWBAND")[0] == '0';
         if (off) return kNumRings;
         // (a few long pieces are bound by dependent steps: 0.074 us on the wide kernel's waves against 0.12 on a ring's)
-        if (!packed) return (pc.m > 64 * 64 && pc.score <= kMaxBandK && (pc.T < 4096 || wideOffEarly)) ? kNumRings - 1 : kNumRings;
+        if (!packed) return (pc.m > 64 * 64 && pc.score <= kMaxBandK && pc.T < 4096) ? kNumRings - 1 : kNumRings;
         for (int g = 0; g < kNumRings; ++g) if (pc.score <= ring_max_k(rings[g])) return g;
         return (pc.m + 63) / 64 <= 64 ? kNumRings - 1 : kNumRings;
     };
@@ -1598,8 +1587,8 @@ int Batch::hirschbergLevel(const std::vector<PathPiece>& big, std::vector<int>& 
     for (int g = 0; g <= kNumRings; ++g) for (size_t p = 0; p < np; ++p) if (groupOf[p] == g) order.push_back(p);
     std::vector<PairDesc> descs(2 * np);
     std::vector<int> best(np);
-    // what no ring holds: the band on many waves (wide_kernels.hip); EDLIB_AMD_WIDE=0: the unbanded strips of round 3
-    const bool wideOff = getenv("EDLIB_AMD_WIDE") && getenv("EDLIB_AMD_WIDE")[0] == '0';
+    // what no ring holds: the band on many waves (wide_kernels.hip)
+    const bool wideOff = false;
     long long peqWords = 0, auxInts = 0, colBlocks = 0;
     for (size_t q = 0; q < np; ++q) {
         const PathPiece& pc = big[order[q]];
@@ -1904,14 +1893,13 @@ int Batch::solvePaths(const std::vector<PathPiece>& jobs, std::vector<OpsOut>& o
 int Batch::solveSemiGlobal(int mode, bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out)
 {
     const size_t n = units.size();
-    const bool off = getenv("EDLIB_AMD_HWSEG") && getenv("EDLIB_AMD_HWSEG")[0] == '0';
     if (mode == EDLIB_MODE_SHW && n > 0 && !(getenv("EDLIB_AMD_SHWBAND") && getenv("EDLIB_AMD_SHWBAND")[0] == '0')) {
         // (queries of up to four blocks sit whole on the smallest ring whatever their threshold: nothing to band)
         bool any = false;
         for (size_t i = 0; i < n && !any; ++i) any = units[i].qlen > 256;
         if (any) return solveShwBanded(wantPositions, units, out);
     }
-    if (mode != EDLIB_MODE_HW || n == 0 || n >= 4096 || off) return solveSemiGlobalUnits(mode, wantPositions, units, out);
+    if (mode != EDLIB_MODE_HW || n == 0 || n >= 4096) return solveSemiGlobalUnits(mode, wantPositions, units, out);
     const long long smax = std::max<long long>(1, 8192 / (long long)n);
     std::vector<UnitSpec> sub; std::vector<int> firstSeg(n + 1, 0); std::vector<int> base;   // base: first recorded column of a segment
     bool any = false;
@@ -2022,7 +2010,6 @@ int Batch::solveSemiGlobalUnits(int mode, bool wantPositions, const std::vector<
     // rest on the strips
     // more than 64 blocks: the strips as a pipeline over many waves (wide_kernels.hip) instead of one wave walking them
     // one after the other
-    const bool wideOff = getenv("EDLIB_AMD_WIDE") && getenv("EDLIB_AMD_WIDE")[0] == '0';
     static const int rings[6] = {4, 16, 16, 16, 0, kWide}, ringH[6] = {1, 1, 2, 4, 1, 1};
     const int NG = 6;
     std::vector<int> grp(n, 4);
@@ -2030,7 +2017,7 @@ int Batch::solveSemiGlobalUnits(int mode, bool wantPositions, const std::vector<
     for (size_t i = 0; i < n; ++i) {
         const int nb = (units[i].qlen + 63) / 64;
         if (!ringsOff) grp[i] = nb <= 4 ? 0 : (nb <= 16 ? 1 : (nb <= 32 ? 2 : (nb <= 64 ? 3 : 4)));
-        if (nb > 64 && !wideOff) grp[i] = 5;
+        if (nb > 64) grp[i] = 5;
         // a banded SHW unit (UnitSpec::band) needs the ring that holds its band, not its query
         if (mode == EDLIB_MODE_SHW && units[i].band && !ringsOff) {
             // (the SHW band [-K, K] is 2 K + 1 rows wide, twice the NW band of the same threshold: ring_max_k / 2)
@@ -2086,11 +2073,8 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
     // 16 x 2 = 2048 rows for a band that needs ~1300 is 52 % more block updates than the 21-lane ring's 1344, which the
     // cheaper step (105 against 119 SIMD cycles per block) does not pay back: config 4 24.7 ms of scans against 20.7.
     // They serve the semi-global units of 17..64 blocks instead (solveSemiGlobalUnits), where the alternative is a strip
-    // that uses 17 of 64 lanes.  EDLIB_AMD_NWRINGS=tall selects them for experiments.
-    static const bool tall = getenv("EDLIB_AMD_NWRINGS") && !strcmp(getenv("EDLIB_AMD_NWRINGS"), "tall");
-    static const int ringOfA[kNumRings] = {4, 8, 16, 21, 32, 64}, ringHA[kNumRings] = {1, 1, 1, 1, 1, 1};
-    static const int ringOfB[kNumRings] = {4, 8, 16, 16, 16, 64}, ringHB[kNumRings] = {1, 1, 1, 2, 4, 1};
-    const int* ringOf = tall ? ringOfB : ringOfA; const int* ringH = tall ? ringHB : ringHA;
+    // that uses 17 of 64 lanes.
+    static const int ringOf[kNumRings] = {4, 8, 16, 21, 32, 64}, ringH[kNumRings] = {1, 1, 1, 1, 1, 1};
     auto cap_of = [&](int l) { return ring_max_k(ringOf[l], ringH[l]); };
     auto blocks_of = [&](int l) { return ringOf[l] * ringH[l]; };
     const int nl = kNumRings;                                           // ring levels; level nl = unbanded strips
@@ -2131,8 +2115,7 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
     // A handful of LONG units (the reference's 1 Mb Chromosome pairs, test_data/perf_tests.sh:180-191): a level costs its
     // ~T dependent steps whether it succeeds or not (0.1 s per Mb), so each unit gets its own estimate from its first 4 kb
     // (PREFIX mode on a 16-lane ring of 4-block lanes: ~1 ms) instead of climbing.
-    const bool wideOff = getenv("EDLIB_AMD_WIDE") && getenv("EDLIB_AMD_WIDE")[0] == '0';
-    const bool wideLevel = !wideOff && paths == nullptr;                // what follows the rings: the wide band, else the strips
+    const bool wideLevel = paths == nullptr;                            // what follows the rings: the wide band (with the column store: the strips)
     // A handful of units (edlibAlign() on a long pair is one) are bound by DEPENDENT STEPS, not by work: a ring scan is
     // ~T steps of 0.12 us on one wave whether it succeeds or not, the wide kernel's two half scans are T / 2 steps of
     // 0.074 us on as many waves as the band is tall.  So when the strips of all units' whole matrices fit the resident
@@ -2185,9 +2168,9 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
         const int nbI = blocks(i);
         for (int l = 0; l < nl; ++l)
             if (nbI <= blocks_of(l) || mean <= meanCap[l] || l >= levelOfKcap) return l;
-        // above every ring: the band on many waves.  (Without it -- EDLIB_AMD_WIDE=0 -- the last ring is still tried while
-        // the estimate is within twice its limit: the unbanded strips cost nstrips times as much.)
-        if (wideOff) return (mean <= meanCap[nl] || kcap <= 2.0 * ring_max_k(64)) ? nl - 1 : nl;
+        // above every ring: the band on many waves.  (With the column store -- fused PATH levels -- what follows the rings is
+        // the unbanded strips, nstrips times the work: the last ring is still tried while the estimate is within twice its limit.)
+        if (!wideLevel) return (mean <= meanCap[nl] || kcap <= 2.0 * ring_max_k(64)) ? nl - 1 : nl;
         return nl;
     };
     std::vector<int>& lvl = lvlScratch_;
@@ -2256,7 +2239,7 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
             }
         // long units: two half scans that meet in the middle (solveWideSplit: half the dependent steps); a unit of one
         // target column has no two halves
-        const int splitMin = getenv("EDLIB_AMD_WIDE_SPLIT") ? atoi(getenv("EDLIB_AMD_WIDE_SPLIT")) : (direct.empty() ? 16384 : 4096);
+        const int splitMin = direct.empty() ? 16384 : 4096;
         while (!rest.empty()) {
             std::vector<UnitSpec>& sel = selScratch_;
             sel.clear();
@@ -2412,10 +2395,8 @@ int Batch::runImpl()
             if (runGroupScans(*g, true) || runGroupExact(*g) || collectGroup(*g, res)) return 1;
         }
         if (!tall.empty()) {                    // taller: strips of fullMax rows on the same kernel, chained through HBM
-            static const bool tallOn = !(getenv("EDLIB_AMD_TALL") && getenv("EDLIB_AMD_TALL")[0] == '0');
             std::vector<int> back;
-            if (!tallOn) back = tall;
-            else if (solveTallFull(tall, res, back)) return 1;
+            if (solveTallFull(tall, res, back)) return 1;
             pairNow_.insert(pairNow_.end(), back.begin(), back.end());
         }
         lap("run: handed back (full height)");
@@ -2450,8 +2431,7 @@ int Batch::runImpl()
             // (distance, then the storing scan with k = distance, :1196-1199); here a unit's first successful level
             // stores its columns and is traced back right away -- any threshold >= the distance gives the same walk
             // (every neighbour that could be "one less than here" is <= the distance, hence exact inside the band)
-            static const bool fuseOn = !(getenv("EDLIB_AMD_FUSEPATH") && getenv("EDLIB_AMD_FUSEPATH")[0] == '0');
-            bool fuse = fuseOn && cfg_.task == EDLIB_TASK_PATH && mode == EDLIB_MODE_NW;
+            bool fuse = cfg_.task == EDLIB_TASK_PATH && mode == EDLIB_MODE_NW;
             for (size_t i = 0; fuse && i < units.size(); ++i) fuse = !needs_hirschberg(units[i].qlen, units[i].tlen);
             fusedOps_.clear();
             lap("run: pair specs");

@@ -333,8 +333,8 @@ void finalize_global(UnitResult& r, int kcfg, int mode, int T, int score);
 int roundup(int x, int q);
 void plan_segments(int nlanes, int T, int mode, int warmFull, long long wantWaves, int& S, int& segLen, int& warm);
 // waves of the 24- / 32-word full-height lane kernels (24 / 32 KB of LDS rows each) the chip runs without two of them sharing
-// a SIMD: one per SIMD of 256 CUs (EDLIB_AMD_TALL_WAVES overrides; read per call: tools/tall_matrix.sh sweeps it)
-inline long long tall_round_waves() { const char* e = getenv("EDLIB_AMD_TALL_WAVES"); return e ? std::max(64LL, atoll(e)) : 1024; }
+// a SIMD: one per SIMD of 256 CUs (swept in round 4: DESIGN.md 3c)
+inline long long tall_round_waves() { return 1024; }
 void finalize_semiglobal(UnitResult& r, int kcfg, int m, int best, const int* pos, long long npos);
 
 int device_count();

@@ -141,13 +141,10 @@ PairDesc Batch::flatDesc(int u) const
 
 int Batch::initFlatPairs()
 {
-    static const bool on = !(getenv("EDLIB_AMD_FLATPAIRS") && getenv("EDLIB_AMD_FLATPAIRS")[0] == '0');
     flatPairs_ = false;
-    static const bool locOn = !(getenv("EDLIB_AMD_FLATLOC") && getenv("EDLIB_AMD_FLATLOC")[0] == '0');
     flatStarts_ = flatPaths_ = flatNwStore_ = flatRing32_ = false;
     flatOvfUnit_.clear(); flatOvfOff_.assign(1, 0);
-    if (!on || !emptyUnits_.empty() || !groups_.empty() || !longUnits_.empty()) return 0;
-    if (cfg_.task != EDLIB_TASK_DISTANCE && !locOn) return 0;
+    if (!emptyUnits_.empty() || !groups_.empty() || !longUnits_.empty()) return 0;
     if ((int)pairUnits_.size() != n_ || n_ < 1024) return 0;       // (a handful of units: the zero-copy path of solveChunk)
     const int mode = (int)cfg_.mode;
     if (mode != EDLIB_MODE_NW && mode != EDLIB_MODE_SHW && mode != EDLIB_MODE_HW) return 0;

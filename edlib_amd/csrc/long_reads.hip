@@ -163,7 +163,7 @@ int Batch::solveLongReads(std::vector<UnitResult>& res, std::vector<int>& fallba
     if (!n) return 0;
     stats.path |= 4;
     const int T = tlen(0);
-    static const int kpMax = getenv("EDLIB_AMD_FILTER_KP") ? std::max(1, atoi(getenv("EDLIB_AMD_FILTER_KP"))) : 56;   // (24 / 40 / 56 measured: 494 / 446 / 427 ms per 2,048 ONT-like 10 kb reads)
+    const int kpMax = 56;   // (24 / 40 / 56 measured: 494 / 446 / 427 ms per 2,048 ONT-like 10 kb reads)
     static const bool dbg = getenv("EDLIB_AMD_DEBUG") != nullptr;
     auto kmax_of = [&](int m) { return (cfg_.k < 0 || cfg_.k > m) ? m : cfg_.k; };     // HW clamps k to m (edlib.cpp:566-568)
 
@@ -333,13 +333,12 @@ int Batch::solveTallFull(const std::vector<int>& units, std::vector<UnitResult>&
         // as many segments as it takes to fill the chip (a wave of this kernel holds 32 KB of LDS rows: ~1280 resident
         // waves), none shorter than ONE warm-up.  (Rounds 2-3 asked for four: 559 unrelated reads of 6,000 bases then are 9 x 104
         // waves, fewer than the chip has SIMDs, and 410 of 8,192 bases fell below the floor underneath and went to kernel W.
-        // Measured per 16,384-read-equivalents batch, tools/tall_matrix.sh: 6,000 bases 860 -> 745 ms, 8,192: 959 -> 803,
+        // Measured per 16,384-read-equivalents batch, the round-4 sweep: 6,000 bases 860 -> 745 ms, 8,192: 959 -> 803,
         // 10,000: 969 -> 933; a wave that recomputes as many columns as it owns still beats an idle SIMD.)
-        const char* wm = getenv("EDLIB_AMD_TALL_WARMS");              // (shortest segment in warm-ups; read per call)
-        const long long warms = wm ? std::max(1LL, atoll(wm)) : 1;
+        const long long warms = 1;                                    // (shortest segment in warm-ups)
         const long long maxS = std::max<long long>(1, std::min<long long>(std::min(65535, std::max(1, T / 4096)), T / (warms * warm)));
         // ONE round of waves, at most one per SIMD (tall_round_waves): measured per 16,384-read-equivalents batch with
-        // tools/tall_matrix.sh, 6,000-base reads (9 read blocks) at 768 / 896 / 1024 / 1152 / 1792 / 2043 waves: 672 / 628 /
+        // the round-4 sweep, 6,000-base reads (9 read blocks) at 768 / 896 / 1024 / 1152 / 1792 / 2043 waves: 672 / 628 /
         // 593 / 822 / 679 / 645 ms -- the kernel is bound by VALU issue, a SIMD with two of its waves takes twice as long and
         // the launch waits for it, and every extra segment is another warm-up of 2m - 1 columns.  Rounds 2-3 aimed at 2048
         // waves and four warm-ups per segment: 860 ms there (and 158 x 13 = 2054 waves for 4,096-base reads: 566 ms against

@@ -464,8 +464,7 @@ int align_one_fused(const char* q, int m, const char* t, int T, EdlibAlignConfig
     if (mode < 0 || mode > 2 || task < 0 || task > 2) return 2;
     const int nb = (m + 63) / 64;
     // NW without a path: two half scans on two waves (one_pair_nw_kernel), any size this file takes
-    static const bool nwFast = !(getenv("EDLIB_AMD_ONEPAIR_NW") && getenv("EDLIB_AMD_ONEPAIR_NW")[0] == '0');
-    const bool nwKernel = nwFast && mode == 0 && task != 2 && T >= 2;
+    const bool nwKernel = mode == 0 && task != 2 && T >= 2;
     // One wave walks T + nb dependent steps of ~0.2 us here; beyond ~400 steps the batch-of-one path (ring kernel: ~0.12 us
     // per step behind ~45 us of launches and copies) is the faster one for distances.  PATH is faster here whenever its
     // store fits (1 k x 1 k: the general path takes 900 us).

@@ -979,10 +979,8 @@ hipError_t launch_traceback(const TracebackArgs& a, hipStream_t stream)
     if (a.numUnits == 0) return hipSuccess;
     // lanes per wave: a wave steps at the pace of its slowest lane (up-moves, block-row changes), and a batch of a few
     // thousand units leaves most of the 1024 SIMDs idle at 64 units per wave, so small batches spread out
-    static const int forced = [] { const char* e = getenv("EDLIB_AMD_TB_LANES"); return e ? atoi(e) : 0; }();
     int lanes = 64;
     while (lanes > 16 && (a.numUnits + lanes - 1) / lanes < 2048) lanes >>= 1;
-    if (forced >= 1 && forced <= 64) lanes = forced;
     hipLaunchKernelGGL(traceback_kernel, dim3((a.numUnits + lanes - 1) / lanes), dim3(64), 0, stream, a, lanes);
     return hipGetLastError();
 }

@@ -212,7 +212,7 @@ def test_switches_do_not_change_results(engine):
         return out
 
     base = everything()
-    for var, val in (("EDLIB_AMD_NWBAND", "0"), ("EDLIB_AMD_NOPROBE", "1"), ("EDLIB_AMD_PEQFULL", "0"), ("EDLIB_AMD_BAND", "0")):
+    for var, val in (("EDLIB_AMD_NWBAND", "0"), ("EDLIB_AMD_NOPROBE", "1"), ("EDLIB_AMD_PEQFULL", "0")):
         os.environ[var] = val
         try:
             got = everything()

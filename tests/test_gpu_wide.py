@@ -81,7 +81,7 @@ def test_k_ladder_from_a_small_start(engine, checker, slots):
             q, t = _mut(rng, n, rate / 2, rate / 4, rate / 4)
             qs.append(q); ts.append(t)
     qs.append(synth.random_dna(11, 9000).tobytes()); ts.append(synth.random_dna(12, 14000).tobytes())
-    with _env(EDLIB_AMD_NWBAND="0", EDLIB_AMD_WIDE_K0="64", EDLIB_AMD_WIDE_SLOTS=slots, EDLIB_AMD_ONEPAIR="0"):
+    with _env(EDLIB_AMD_NWBAND="0", EDLIB_AMD_WIDE_K0="64", EDLIB_AMD_WIDE_SLOTS=slots):
         _check(engine, checker, qs, ts, "NW", "distance", -1, "ladder slots=%s" % slots)
         _check(engine, checker, qs[:10], ts[:10], "NW", "distance", 40, "ladder fixed k")
 
