@@ -37,6 +37,7 @@ void pinned_free(void* p, size_t granted);
 // flight; until the next entry point clears the flag this thread's frees go straight to hipFree / hipHostFree
 // (which wait for the device) instead of into the cache, so no other batch can be handed a block that is still in use.
 void pool_quarantine(bool on);
+bool pool_enabled();                              // false while this thread is quarantined
 // Releases every cached device / pinned block and idle stream (edlibAmdTrim()).
 void pool_trim();
 hipError_t pool_stream(hipStream_t* s);

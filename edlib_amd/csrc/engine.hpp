@@ -7,6 +7,7 @@
 #include "pair_kernels.hpp"
 #include "reads_kernels.hpp"
 
+#include <chrono>
 #include <deque>
 #include <memory>
 #include <vector>
@@ -323,7 +324,20 @@ int align_one(const char* q, int qn, const char* t, int tn, EdlibAlignConfig cfg
 // one small pair in one kernel launch (one_pair.hip): 0 = answered, 1 = error, 2 = not handled here (take align_one)
 int align_one_fused(const char* q, int qn, const char* t, int tn, EdlibAlignConfig cfg, EdlibAlignResult* out);
 
+// EDLIB_AMD_DEBUG: host wall time between named points of a run (stderr)
+struct Lap {
+    bool on; std::chrono::steady_clock::time_point t;
+    Lap() : on(getenv("EDLIB_AMD_DEBUG") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void operator()(const char* what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[edlib_amd] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
 // helpers shared by the translation units of the host side
+const int kMaxDevices = 16;                       // devices the process-wide caches and gates are kept for
 const int kPosCap = 16;                           // end positions kept beside a pair unit's results (longer lists: exact second pass)
 int peq_row_stride(long long nb);                 // row length of the LDS-resident Peq of the ring kernels
 bool needs_hirschberg(int m, int T);              // the reference's 1 MiB rule (edlib.cpp:1188-1190)
