@@ -225,7 +225,7 @@ private:
     // NW distance of long units as two half scans that meet in the middle (forward over the left half of the target,
     // reverse over the right half, both inside the band of UnitSpec::kinit): out[4 u ..] = {min, split row, left, right};
     // exact iff min <= kinit
-    int solveWideSplit(const std::vector<UnitSpec>& units, std::vector<int>& out);
+    int solveWideSplit(const std::vector<UnitSpec>& units, std::vector<int>& out, int ring = 0);     // ring > 0: the halves on lane rings
     // what the distance phase of this run already knows about a piece's first split (solveWideSplit): the path phase
     // does not scan the two halves again
     struct KnownSplit { long long qoff; int m; long long toff; int T; int score; int row, left, right; };

@@ -425,14 +425,18 @@ int Batch::buildFlatView()
     // ---- layout of the block (the same offsets on the device and in pinned host memory)
     size_t at = 0;
     auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 63) & ~(size_t)63; return o; };
-    const size_t oStatus = take(n * 4), oEd = take(n * 4), oNloc = take(n * 4), oAlpha = take(n * 4), oAlnLen = take(n * 4);
-    const size_t oLocOff = take((n + 1) * 8), oAlnOff = take((n + 1) * 8), oBlockLoc = take(nblocks * 8), oBlockAln = take(nblocks * 8);
+    // (what the host wants first -- the D2H of this head is most of what a DISTANCE batch brings over -- then the device's
+    // scratch; status is all zeros for a flat batch and is filled in on the host)
     const size_t oTotals = take(16);
+    const size_t oEd = take(n * 4), oNloc = take(n * 4), oAlpha = take(n * 4);
+    const size_t oLocOff = take((n + 1) * 8), oAlnOff = take((n + 1) * 8);
     const size_t headBytes = at;
+    const size_t oStatus = take(n * 4), oAlnLen = take(n * 4), oBlockLoc = take(nblocks * 8), oBlockAln = take(nblocks * 8);
+    const size_t hostHead = headBytes + ((n * 4 + 63) & ~(size_t)63);     // host: the head + the status array
     // (device: room for every location / op byte the batch could have; host: the fixed part now, the rest once the totals are known)
     const size_t oEnds = take((size_t)capLoc * 4), oStarts = wantStarts ? take((size_t)capLoc * 4) : 0, oAln = take((size_t)capAln + 16);
     EDLIB_AMD_HIP(d_view_.ensure(at));
-    if (h_view_.n < headBytes) EDLIB_AMD_HIP(h_view_.alloc(headBytes));
+    if (h_view_.n < hostHead) EDLIB_AMD_HIP(h_view_.alloc(hostHead));
     uint8_t* const dv = d_view_.p; uint8_t* const hv = h_view_.p;
     FlatResultArgs a{};
     a.descs = d_flatDescs_.p; a.n = n_; a.mode = scanMode; a.k = cfg_.k; a.wantPath = wantPath ? 1 : 0; a.posCap = kFlatPosCap;
@@ -471,7 +475,8 @@ int Batch::buildFlatView()
     alphaPending_ = false;
     view_ = EdlibAmdResultsView{};
     view_.numUnits = n_;
-    view_.status = reinterpret_cast<const int*>(hv + oStatus); view_.editDistance = reinterpret_cast<const int*>(hv + oEd);
+    memset(hv + headBytes, 0, n * 4);
+    view_.status = reinterpret_cast<const int*>(hv + headBytes); view_.editDistance = reinterpret_cast<const int*>(hv + oEd);
     view_.numLocations = reinterpret_cast<const int*>(hv + oNloc); view_.alphabetLength = reinterpret_cast<const int*>(hv + oAlpha);
     view_.locOffsets = reinterpret_cast<const long long*>(hv + oLocOff); view_.alnOffsets = reinterpret_cast<const long long*>(hv + oAlnOff);
     view_.endLocations = reinterpret_cast<const int*>(hvar + vEnds);

@@ -709,6 +709,19 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
         lap("nw level: select");
         SolveOut& so = soLevel_;
         const bool store = paths != nullptr && (l == nl || ringH[l] == 1);
+        // A level that only reruns what the one before left open is a handful of waves: its launch takes the T + blocks
+        // DEPENDENT steps of one wave however few units there are (config 4: 7 % of the batch, 2.6 ms of a 23 ms step).  The
+        // two halves of a target are independent (edlib.cpp:1246-1260): forward over the left half, reverse over the right
+        // half, min over the rows of L[i] + R[i+1] -- half the steps, while twice the waves still fit the chip at once.
+        bool halves = !store && l < nl && ringH[l] == 1 && sel.size() < n && 2 * ((sel.size() + 64 / ringOf[l] - 1) / (64 / ringOf[l])) <= 8192;
+        for (size_t q = 0; halves && q < sel.size(); ++q)
+            halves = sel[q].tlen >= 2048 && sel[q].qstep == 1 && sel[q].tstep == 1 && sel[q].kinit <= cap_of(l) && blocks(who[q]) > blocks_of(l);
+        if (halves) {
+            std::vector<int> sp;
+            if (solveWideSplit(sel, sp, ringOf[l])) return 1;
+            so.score.resize(sel.size());
+            for (size_t q = 0; q < sel.size(); ++q) so.score[q] = sp[4 * q];
+        } else
         if (solve(EDLIB_MODE_NW, false, store, sel, so, l < nl ? ringOf[l] : 0, l < nl ? ringH[l] : 1)) return 1;
         lap("nw level: solve");
         if (store) opsKeep_.insert(opsKeep_.end(), so.opsBufs.begin(), so.opsBufs.end());

@@ -143,7 +143,10 @@ int Batch::hirschbergLevel(const std::vector<PathPiece>& big, std::vector<int>& 
 // half), both inside the band of the whole problem and dumped at their last column, then min over the query rows of
 // L[i] + R[i+1].  Half the dependent steps; exact iff the minimum is within the threshold (cells outside the band are
 // upper bounds).
-int Batch::solveWideSplit(const std::vector<UnitSpec>& units, std::vector<int>& out)
+// ring > 0: the two halves of every unit on lane rings of that many lanes instead (band of UnitSpec::kinit <= ring_max_k(ring)):
+// what a HANDFUL of ring units -- the rerun of the units a level left open -- takes, whose launch is bound by the
+// T + blocks dependent steps of its waves, not by work.
+int Batch::solveWideSplit(const std::vector<UnitSpec>& units, std::vector<int>& out, int ring)
 {
     const size_t np = units.size();
     out.assign(4 * np, 0);
@@ -167,11 +170,11 @@ int Batch::solveWideSplit(const std::vector<UnitSpec>& units, std::vector<int>& 
             d.peqOff = peqWords; peqWords += nb * tab_.sigmaT;
             d.auxOff = 0;
             d.colOff = colBlocks; colBlocks += nb;
-            stats.word_steps += wide_word_steps(0, d.qlen, d.tlen, d.bandT, d.kinit);
+            if (ring <= 0) stats.word_steps += wide_word_steps(0, d.qlen, d.tlen, d.bandT, d.kinit);
         }
     }
     WidePlan wplan;
-    if (planWide(0, descs.data(), descs.size(), wplan)) return 1;
+    if (ring <= 0 && planWide(0, descs.data(), descs.size(), wplan)) return 1;
     const size_t n = descs.size();
     DevBuf<unsigned long long> colP, colM, packed; DevBuf<int> colS, d_out;
     EDLIB_AMD_HIP(colP.alloc((size_t)colBlocks)); EDLIB_AMD_HIP(colM.alloc((size_t)colBlocks)); EDLIB_AMD_HIP(colS.alloc((size_t)colBlocks));
@@ -193,7 +196,14 @@ int Batch::solveWideSplit(const std::vector<UnitSpec>& units, std::vector<int>& 
     a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p;
     a.colP = colP.p; a.colM = colM.p; a.colS = colS.p;
     scanTimerStart();
-    if (launchWide(0, a, descs.data(), n, wplan)) return 1;
+    if (ring > 0) {
+        long long nbMax = 0;
+        for (const UnitSpec& u : units) nbMax = std::max<long long>(nbMax, (u.qlen + 63) / 64);
+        a.peqRowStride = peq_row_stride(nbMax);
+        a.peqFullStride = (int)std::min<long long>((long long)a.peqRowStride * tab_.sigmaT, 1 << 20);
+        a.wordSteps = ringStepsCounter();
+        EDLIB_AMD_HIP(launch_scan_pairs_ring(ring, 0, false, a, stream_));
+    } else if (launchWide(0, a, descs.data(), n, wplan)) return 1;
     scanTimerStop();
     SplitArgs sa{};
     sa.descs = d_descs_.p; sa.numPieces = (int)np; sa.best = nullptr;
@@ -201,7 +211,7 @@ int Batch::solveWideSplit(const std::vector<UnitSpec>& units, std::vector<int>& 
     EDLIB_AMD_HIP(launch_split_min(sa, packed.p, maxRows, stream_));
     EDLIB_AMD_HIP(hipMemcpyAsync(out.data(), d_out.p, out.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-    {
+    if (ring <= 0) {
         const int w = checkWide();
         if (w == 2) return solveWideSplit(units, out);
         if (w) return 1;
