@@ -32,7 +32,8 @@ struct UnitSpec {
     long long toff; int tlen; int tstep;
     int kinit;
     int skip = 0;      // HW target segments: leading warm-up columns whose scores are not recorded
-    int band = 0;      // SHW: scan only the diagonals [-kinit, kinit] (a cell within kinit of the origin's diagonal has |i - j| <= kinit)
+    int band = 0;      // SHW: scan only the diagonals [-kinit, kinit] (a cell within kinit of the origin's diagonal has |i - j| <= kinit);
+                       // HW: only [-kinit, (tlen - qlen) + 2 kinit] (an alignment within kinit starts in [0, tlen - qlen + kinit])
 };
 
 struct SolveOut {
@@ -240,6 +241,8 @@ private:
     int solveSemiGlobalUnits(int mode, bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out);
     // SHW inside Ukkonen's band (edlib.cpp:562, 602-630): threshold levels like the NW distances, target cut at m + K
     int solveShwBanded(bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out);
+    // HW inside the static band of a threshold: diagonals [-K, (T - m) + 2 K] (queries in windows not much longer than themselves)
+    int solveHwBanded(bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out);
     // alphabetLength of the empty / pair units: launched on a side stream before phase 1, collected after it
     int alphabetLengthsBegin();
     int alphabetLengthsEnd(std::vector<UnitResult>& res);
@@ -343,6 +346,7 @@ int peq_row_stride(long long nb);                 // row length of the LDS-resid
 bool needs_hirschberg(int m, int T);              // the reference's 1 MiB rule (edlib.cpp:1188-1190)
 void blank_record(UnitResult& r);
 void finalize_global(UnitResult& r, int kcfg, int mode, int T, int score);
+long long hw_band_rows(const UnitSpec& u, long long K);     // rows per column of the HW band of threshold K
 // helpers shared by engine.hip and long_reads.hip
 int roundup(int x, int q);
 void plan_segments(int nlanes, int T, int mode, int warmFull, long long wantWaves, int& S, int& segLen, int& warm);

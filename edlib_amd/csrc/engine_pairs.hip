@@ -91,7 +91,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         if (wantPath) storeEntries += ring > 0 ? ring_store_entries(ring, s.qlen, s.tlen) : pair_store_entries(s.qlen, s.tlen);
         d.posCap = wantPositions ? kPosCap : 0;
         d.posOff = (long long)i * kPosCap;
-        d.colOff = -1; d.bandT = (s.band && mode == EDLIB_MODE_SHW) ? -1 : 0; d.ring = ring > 0 ? ring : 0;
+        d.colOff = -1; d.bandT = (s.band && (mode == EDLIB_MODE_SHW || mode == EDLIB_MODE_HW)) ? -1 : 0; d.ring = ring > 0 ? ring : 0;
         // op slot of the unit, filled from the back.  An alignment has (m + T + inserts + deletes) / 2 ops, and a ring scan
         // is only walked when its distance is within kinit: (m + T + kinit) / 2 bounds the length (config 5: 1064 bytes
         // instead of 2000 per pair to bring back over PCIe)
@@ -398,6 +398,12 @@ int Batch::solveSemiGlobal(int mode, bool wantPositions, const std::vector<UnitS
         for (size_t i = 0; i < n && !any; ++i) any = units[i].qlen > 256;
         if (any) return solveShwBanded(wantPositions, units, out);
     }
+    if (mode == EDLIB_MODE_HW && n > 0 && !(getenv("EDLIB_AMD_HWBAND") && getenv("EDLIB_AMD_HWBAND")[0] == '0')) {
+        // a query in a window not much longer than itself, with a threshold well below its length: the band of solveHwBanded
+        bool any = false;
+        for (size_t i = 0; i < n && !any; ++i) any = hw_band_rows(units[i], std::min(units[i].kinit, 64)) + 64 <= 64LL * ((units[i].qlen + 63) / 64 - 1);
+        if (any) return solveHwBanded(wantPositions, units, out);
+    }
     if (mode != EDLIB_MODE_HW || n == 0 || n >= 4096) return solveSemiGlobalUnits(mode, wantPositions, units, out);
     const long long smax = std::max<long long>(1, 8192 / (long long)n);
     std::vector<UnitSpec> sub; std::vector<int> firstSeg(n + 1, 0); std::vector<int> base;   // base: first recorded column of a segment
@@ -500,6 +506,66 @@ int Batch::solveShwBanded(bool wantPositions, const std::vector<UnitSpec>& units
     return 0;
 }
 
+// HW with a threshold, as a STATIC band (the reference narrows HW with its first..lastBlock bookkeeping, edlib.cpp:562,
+// 602-630, block 0 kept alive): an alignment of the whole query with cost <= K starts at a column j0 in [0, T - m + K] and
+// stays within K diagonals of j0, so only the diagonals [-K, (T - m) + 2 K] are needed -- (T - m) + 3 K + 1 rows per column
+// instead of m.  That pays for a query in a window not much longer than itself (the verification step of a mapper: 1 kb in
+// 1.2 kb at k = 20 is 261 rows: an 8-lane ring, eight units per wave, instead of 16 lanes and four).  A unit with a real
+// threshold is scanned inside it once; an open unit (k = -1: threshold m) climbs K = 64, 256, 1024 ... like the reference
+// doubles k (:197-217), exact as soon as some column scores <= K; a level whose band is no narrower than the query is
+// the plain scan, which ends the climb.  Units with long targets keep the plain path (target segments, the piece filter).
+long long hw_band_rows(const UnitSpec& u, long long K) { return std::max(0, u.tlen - u.qlen) + 3 * K + 1; }
+
+int Batch::solveHwBanded(bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out)
+{
+    const size_t n = units.size();
+    out.score.assign(n, -1); out.count.assign(n, 0); out.last.assign(n, -1);
+    out.posStart.assign(n + 1, 0); out.posFlat.clear();
+    out.opsPtr.assign(n, nullptr); out.opsLen.assign(n, 0); out.opsBufs.clear();
+    std::vector<long long> kcur(n);
+    std::vector<std::vector<int>> posOf(wantPositions ? n : 0);
+    std::vector<size_t> rest;
+    // a level K pays while its band is at least a block narrower than the query
+    auto narrow = [&](const UnitSpec& u, long long K) { return hw_band_rows(u, K) + 64 <= 64LL * ((u.qlen + 63) / 64 - 1); };
+    for (size_t i = 0; i < n; ++i) {
+        const UnitSpec& u = units[i];
+        kcur[i] = u.kinit < u.qlen ? u.kinit : 64;                    // the caller's threshold, or the first level of an open unit
+        rest.push_back(i);
+    }
+    while (!rest.empty()) {
+        std::vector<UnitSpec> sel; sel.reserve(rest.size());
+        for (size_t i : rest) {
+            UnitSpec u = units[i];
+            const long long K = std::min<long long>(kcur[i], u.kinit);
+            // (T < m - K: no alignment of cost <= K exists; the band would never reach row m - 1 -- the plain scan answers)
+            const bool banded = K < u.kinit || u.kinit < u.qlen ? (narrow(u, K) && (long long)u.tlen >= (long long)u.qlen - K) : false;
+            u.kinit = banded ? (int)K : units[i].kinit;
+            u.band = banded ? 1 : 0;
+            sel.push_back(u);
+        }
+        SolveOut so;
+        if (solveSemiGlobalUnits(EDLIB_MODE_HW, wantPositions, sel, so)) return 1;
+        std::vector<size_t> again;
+        for (size_t q = 0; q < sel.size(); ++q) {
+            const size_t i = rest[q];
+            if (!sel[q].band || so.score[q] >= 0 || sel[q].kinit >= units[i].kinit) {   // plain / exact / the caller's own threshold found nothing
+                out.score[i] = so.score[q]; out.count[i] = so.count[q]; out.last[i] = so.last[q];
+                if (wantPositions) posOf[i].assign(so.posFlat.begin() + so.posStart[q], so.posFlat.begin() + so.posStart[q + 1]);
+                continue;
+            }
+            kcur[i] = 4LL * sel[q].kinit;
+            again.push_back(i);
+        }
+        rest.swap(again);
+    }
+    if (wantPositions)
+        for (size_t i = 0; i < n; ++i) {
+            out.posFlat.insert(out.posFlat.end(), posOf[i].begin(), posOf[i].end());
+            out.posStart[i + 1] = (long long)out.posFlat.size();
+        }
+    return 0;
+}
+
 int Batch::solveSemiGlobalUnits(int mode, bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out)
 {
     const size_t n = units.size();
@@ -509,22 +575,24 @@ int Batch::solveSemiGlobalUnits(int mode, bool wantPositions, const std::vector<
     // rest on the strips
     // more than 64 blocks: the strips as a pipeline over many waves (wide_kernels.hip) instead of one wave walking them
     // one after the other
-    static const int rings[6] = {4, 16, 16, 16, 0, kWide}, ringH[6] = {1, 1, 2, 4, 1, 1};
-    const int NG = 6;
-    std::vector<int> grp(n, 4);
-    size_t cnt[NG] = {0, 0, 0, 0, 0, 0};
+    static const int rings[7] = {4, 8, 16, 16, 16, 0, kWide}, ringH[7] = {1, 1, 1, 2, 4, 1, 1};
+    const int NG = 7;
+    std::vector<int> grp(n, 5);
+    size_t cnt[NG] = {0, 0, 0, 0, 0, 0, 0};
     for (size_t i = 0; i < n; ++i) {
         const int nb = (units[i].qlen + 63) / 64;
-        if (!ringsOff) grp[i] = nb <= 4 ? 0 : (nb <= 16 ? 1 : (nb <= 32 ? 2 : (nb <= 64 ? 3 : 4)));
-        if (nb > 64) grp[i] = 5;
-        // a banded SHW unit (UnitSpec::band) needs the ring that holds its band, not its query
-        if (mode == EDLIB_MODE_SHW && units[i].band && !ringsOff) {
-            // (the SHW band [-K, K] is 2 K + 1 rows wide, twice the NW band of the same threshold: ring_max_k / 2)
-            const long long K2 = 2LL * units[i].kinit;
+        if (!ringsOff) grp[i] = nb <= 4 ? 0 : (nb <= 8 ? 1 : (nb <= 16 ? 2 : (nb <= 32 ? 3 : (nb <= 64 ? 4 : 5))));
+        if (nb > 64) grp[i] = 6;
+        // a banded SHW / HW unit (UnitSpec::band) needs the ring that holds its band, not its query
+        if ((mode == EDLIB_MODE_SHW || mode == EDLIB_MODE_HW) && units[i].band && !ringsOff) {
+            // (the SHW band [-K, K] is 2 K + 1 rows wide, twice the NW band of the same threshold: ring_max_k / 2; the HW band
+            // [-K, (T - m) + 2 K] is (T - m) + 3 K + 1 rows wide)
+            const long long K2 = mode == EDLIB_MODE_SHW ? 2LL * units[i].kinit : hw_band_rows(units[i], units[i].kinit) - 1;
             if (nb > 4 && K2 <= ring_max_k(4)) grp[i] = 0;
-            else if (nb > 16 && K2 <= ring_max_k(16)) grp[i] = 1;
-            else if (nb > 32 && K2 <= ring_max_k(16, 2)) grp[i] = 2;
-            else if (nb > 64 && K2 <= ring_max_k(16, 4)) grp[i] = 3;
+            else if (nb > 8 && K2 <= ring_max_k(8)) grp[i] = 1;
+            else if (nb > 16 && K2 <= ring_max_k(16)) grp[i] = 2;
+            else if (nb > 32 && K2 <= ring_max_k(16, 2)) grp[i] = 3;
+            else if (nb > 64 && K2 <= ring_max_k(16, 4)) grp[i] = 4;
         }
         ++cnt[grp[i]];
     }

@@ -409,14 +409,19 @@ scan_pairs_ring_kernel(const PairScanArgs a)
     // is the diagonals [-K, K] whatever the lengths are (the reference's SHW band, edlib.cpp:562, 602-630, for a fixed k);
     // the host cuts the target at column m + K and answers "none" itself when T < m - K
     const bool shwBand = MODE == 1 && bandT < 0;
-    const int D = shwBand ? 0 : (bandT > 0 ? bandT : T) - m, absD = D < 0 ? -D : D;     // the band is that of the whole problem
+    // MODE 2 with bandT < 0: HW inside the band of threshold K -- an alignment of the whole query with cost <= K starts at a
+    // column j0 in [0, T - m + K] and stays within K diagonals of j0: the diagonals [-K, (T - m) + 2 K].  What the
+    // reference's first..lastBlock bookkeeping (edlib.cpp:562, 602-630) saves on a query in a window not much longer than
+    // itself, as a static band: the smallest ring that holds (T - m) + 3 K rows instead of the whole query.
+    const bool hwBand = MODE == 2 && bandT < 0;
+    const int D = (shwBand || hwBand) ? 0 : (bandT > 0 ? bandT : T) - m, absD = D < 0 ? -D : D;     // the band is that of the whole problem
     // last-column dump of Hirschberg halves: the packed rings look their slot up when they get there
     const bool dumpCol = a.colP != nullptr && (G != 64 || colOffU >= 0);
     const bool active = have && (MODE != 0 || K >= absD);
     if (have && !active && rl == 0) { a.outScore[unit] = 0x3fffffff; a.outCount[unit] = 0; a.outLast[unit] = -1; }
     if (__builtin_amdgcn_ballot_w64(active) == 0ull) return;
-    const int p = MODE != 0 ? (shwBand ? K : (1 << 28)) : (K - absD) >> 1;            // semi-global: the whole matrix unless banded
-    const int dmin = (D < 0 ? D : 0) - p, dmax = (D > 0 ? D : 0) + p;
+    const int p = MODE != 0 ? ((shwBand || hwBand) ? K : (1 << 28)) : (K - absD) >> 1;            // semi-global: the whole matrix unless banded
+    const int dmin = (D < 0 ? D : 0) - p, dmax = hwBand ? (T > m ? T - m : 0) + 2 * K : (D > 0 ? D : 0) + p;
     int best = K, cnt = 0, lastCol = -1;                              // MODE != 0: columns scoring <= best qualify
     const u32 sh = (u32)(m - 1) & 63u;                                // row m-1 inside its 64-row block ...
     const int hb = (nb - 1) % H;                                      // ... which is this block of the last ring-lane block
@@ -643,11 +648,11 @@ count_ring_steps_kernel(const PairDesc* __restrict__ descs, const int n, const i
         const PairDesc d = descs[unit];
         const int m = d.qlen, T = d.tlen, K = d.kinit, RH = 64 * H;
         const int nsb = (num_blocks(m) + H - 1) / H;
-        const bool shwBand = mode == 1 && d.bandT < 0;
-        const int D = shwBand ? 0 : (d.bandT > 0 ? d.bandT : T) - m, absD = D < 0 ? -D : D;
+        const bool shwBand = mode == 1 && d.bandT < 0, hwBand = mode == 2 && d.bandT < 0;
+        const int D = (shwBand || hwBand) ? 0 : (d.bandT > 0 ? d.bandT : T) - m, absD = D < 0 ? -D : D;
         if (mode != 0 || K >= absD) {
-            const int p = mode != 0 ? (shwBand ? K : (1 << 28)) : (K - absD) >> 1;
-            const int dmin = (D < 0 ? D : 0) - p, dmax = (D > 0 ? D : 0) + p;
+            const int p = mode != 0 ? ((shwBand || hwBand) ? K : (1 << 28)) : (K - absD) >> 1;
+            const int dmin = (D < 0 ? D : 0) - p, dmax = hwBand ? (T > m ? T - m : 0) + 2 * K : (D > 0 ? D : 0) + p;
             for (int b = 0; b < nsb; ++b) {
                 int f = RH * b + dmin, l = RH * b + RH - 1 + dmax;
                 f = f < 0 ? 0 : f; l = l > T - 1 ? T - 1 : l;
@@ -706,7 +711,7 @@ hipError_t launch_scan_pairs_ring(int G, int mode, bool store, const PairScanArg
         }
         return hipErrorInvalidValue;
     }
-    if (mode != 0 && (store || (G != 4 && G != 16))) return hipErrorInvalidValue;   // semi-global rings: 4 or 16 lanes, distance only
+    if (mode != 0 && (store || (G != 4 && G != 8 && G != 16))) return hipErrorInvalidValue;   // semi-global rings: 4, 8 or 16 lanes, distance only
     switch (G * 8 + mode * 2 + (store ? 1 : 0)) {
         case 32: return launch_scan_pairs_ring_t<4, 0, false>(a, stream);
         case 33: return launch_scan_pairs_ring_t<4, 0, true>(a, stream);
@@ -714,6 +719,8 @@ hipError_t launch_scan_pairs_ring(int G, int mode, bool store, const PairScanArg
         case 36: return launch_scan_pairs_ring_t<4, 2, false>(a, stream);
         case 64: return launch_scan_pairs_ring_t<8, 0, false>(a, stream);
         case 65: return launch_scan_pairs_ring_t<8, 0, true>(a, stream);
+        case 66: return launch_scan_pairs_ring_t<8, 1, false>(a, stream);
+        case 68: return launch_scan_pairs_ring_t<8, 2, false>(a, stream);
         case 128: return launch_scan_pairs_ring_t<16, 0, false>(a, stream);
         case 129: return launch_scan_pairs_ring_t<16, 0, true>(a, stream);
         case 130: return launch_scan_pairs_ring_t<16, 1, false>(a, stream);

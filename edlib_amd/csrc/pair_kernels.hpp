@@ -91,8 +91,9 @@ hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStr
 constexpr int ring_max_k(int G, int H = 1) { return 64 * H * (G - 2); }      // H: 64-row blocks per ring lane (1, 2 or 4)
 constexpr int kNumRings = 6;           // ring sizes 4, 8, 16, 21, 32, 64 (units per wave: 16, 8, 4, 3, 2, 1)
 constexpr int kMaxBandK = ring_max_k(64);
-// mode 1 (SHW) / 2 (HW): packed rings only (ringLanes 4 or 16), every unit must have numBlocks <= ringLanes;
-// no band, kinit is the end-location threshold, outputs as launch_scan_pairs.
+// mode 1 (SHW) / 2 (HW): packed rings only (ringLanes 4, 8 or 16); every unit has numBlocks <= ringLanes (no band, kinit is
+// the end-location threshold) or desc.bandT < 0: the static band of threshold kinit -- SHW the diagonals [-K, K], HW
+// [-K, (tlen - qlen) + 2 K] -- which must fit the ring like an NW band of that many rows; outputs as launch_scan_pairs.
 // blocksPerLane H = 2 / 4 (16-lane rings, no store): a ring lane holds H vertically adjacent blocks ("superblock"); the band
 // limit is ring_max_k(16, H), modes 1 / 2 take units of up to 16 H blocks.
 hipError_t launch_scan_pairs_ring(int ringLanes, int mode, bool store, const PairScanArgs& a, hipStream_t stream,

@@ -60,6 +60,7 @@ struct WideGeom { long long dmin, dmax; };
 __host__ __device__ static inline WideGeom wide_geom(int mode, int m, int T, int bandT, int K)
 {
     if (mode == 1 && bandT < 0) return WideGeom{-(long long)K, (long long)K};     // SHW inside the band of threshold K: |i - j| <= K
+    if (mode == 2 && bandT < 0) return WideGeom{-(long long)K, (long long)(T > m ? T - m : 0) + 2LL * K};   // HW: starts in [0, T - m + K], K diagonals either side
     if (mode != 0) return WideGeom{-kWideInf, kWideInf};
     const long long D = (long long)(bandT > 0 ? bandT : T) - m, absD = D < 0 ? -D : D;
     const long long p = ((long long)K - absD) >> 1;

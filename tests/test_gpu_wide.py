@@ -262,3 +262,55 @@ def test_wide_rerun_with_one_slot_after_a_launch_that_is_not_resident(engine, ch
         tt = synth.random_dna(32, 20000).tobytes()
         for mode in ("SHW", "HW"):
             _check(engine, checker, [tq], [tt], mode, "locations", -1, "rerun: long %s query" % mode)
+
+
+def test_hw_inside_the_band_of_a_threshold(engine, checker):
+    """HW pair units whose window is not much longer than the query, inside the static band [-K, (T - m) + 2 K]
+    (Batch::solveHwBanded): fixed k below / at / above the distance, open units (levels 64, 256, ...), queries from
+    5 blocks (an 8-lane ring holds them whole) to beyond 64 blocks (the wide kernel inside the band), equal hits at
+    both ends of the window, targets shorter than m - k, unrelated pairs; the same answers with EDLIB_AMD_HWBAND=0;
+    and the band is what runs: fewer word-steps than the whole matrix."""
+    rng = random.Random(9007 + SEED_SHIFT)
+    qs, ts = [], []
+    for m in (320, 500, 1000, 1100, 2500, 5000, 9000):
+        for rate, slack in ((0.01, 0.1), (0.04, 0.2), (0.15, 0.05)):
+            lead = rng.randrange(0, int(m * slack) + 1)
+            t = synth.random_dna(rng.randrange(1 << 30), m + int(m * slack))
+            q, _ = synth.mutate(t[lead:lead + m], rng.randrange(1 << 30), rate / 2, rate / 4, rate / 4)
+            qs.append(q.tobytes()); ts.append(t.tobytes())
+    # the window holds the query twice (overlapping copies end at both sides), an unrelated pair, a target shorter than the query
+    rep = synth.random_dna(77, 900).tobytes()
+    qs.append(rep); ts.append(rep + rep[-150:] + rep[:60])
+    qs.append(synth.random_dna(31, 3000).tobytes()); ts.append(synth.random_dna(32, 3300).tobytes())
+    qs.append(synth.random_dna(33, 2000).tobytes()); ts.append(synth.random_dna(34, 1500).tobytes())
+    for task in ("distance", "locations", "path"):
+        _check(engine, checker, qs, ts, "HW", task, -1, "hw band, open")
+    ds = [checker.align(q, t, "HW", "distance", -1)["editDistance"] for q, t in zip(qs, ts)]
+    for k in (0, 5, 20, 60, 130, 500):
+        _check(engine, checker, qs, ts, "HW", "locations", k, "hw band, fixed k")
+    for i in (0, 4, 8, 13, 17, 20):                      # one unit at a time right around its own distance
+        for k in (ds[i] - 1, ds[i], ds[i] + 1):
+            if k >= 0:
+                _check(engine, checker, qs[i:i + 1], ts[i:i + 1], "HW", "locations", k, "hw band at its distance")
+    with _env(EDLIB_AMD_HWBAND="0"):
+        _check(engine, checker, qs, ts, "HW", "locations", 20, "band off")
+    # 1 kb queries in 1.2 kb windows at k = 20: 261 rows per column on 8-lane rings instead of 16 blocks
+    q1, t1 = [], []
+    for i in range(600):
+        t = synth.random_dna(rng.randrange(1 << 30), 1200)
+        lead = rng.randrange(0, 200)
+        q, _ = synth.mutate(t[lead:lead + 1000], rng.randrange(1 << 30), 0.005, 0.002, 0.002)
+        q1.append(q.tobytes()); t1.append(t.tobytes())
+    steps = {}
+    for band in ("1", "0"):
+        with _env(EDLIB_AMD_HWBAND=band):
+            b = engine.PairBatch(q1, t1, mode="HW", task="distance", k=20)
+            try:
+                steps[band] = b.run()["word_steps"]
+                got = b.results()
+            finally:
+                b.close()
+        for i in range(0, 600, 37):
+            want = checker.align(q1[i], t1[i], "HW", "distance", 20)
+            assert got[i]["editDistance"] == want["editDistance"] and got[i]["endLocations"] == want["endLocations"], (band, i)
+    assert steps["1"] * 3 < steps["0"] * 2, steps         # (at least a third fewer executed word-steps; the geometry says ~2.9x)

@@ -171,3 +171,29 @@ def test_shw_inside_the_band_of_a_threshold(oracle, L):
                 assert score == -1 or (want["editDistance"] == m), (it, m, T, K, d, score)
                 continue
             assert score == want["editDistance"] and positions == ends, (it, m, T, K, d, score, positions, ends)
+
+
+@pytest.mark.parametrize("L", [1, 2, 64])
+def test_hw_inside_the_band_of_a_threshold(oracle, L):
+    """HW with threshold K only needs the diagonals [-K, (T - m) + 2 K] (an alignment within K starts at a column in
+    [0, T - m + K] and stays within K diagonals of it): same answer as the oracle with k = K (score, every end
+    position), "none" when nothing is within K"""
+    rng = random.Random(177 + L)
+    for it in range(60):
+        m = rng.randrange(1, 500)
+        slack = rng.randrange(0, 120)
+        t = _rand(rng, m + slack)
+        lead = rng.randrange(0, slack + 1)
+        q = _mutate(rng, t[lead:lead + m], rng.choice([0.02, 0.1, 0.3])) if rng.random() < 0.8 else _rand(rng, m)
+        m, T = len(q), len(t)
+        d = oracle.align(q, t, "HW", "distance", -1)["editDistance"]
+        for K in sorted({max(1, d // 2), max(1, d - 1), max(1, d), d + 1, d + 25}):
+            if K >= m or T < m - K:
+                continue
+            want = oracle.align(q, t, "HW", "distance", K)
+            score, count, last, positions, _ = wide_scan(q, t, 2, K, L=L, bandT=-1)
+            ends = [e for e in (want["endLocations"] or []) if e >= 0]
+            if want["editDistance"] < 0 or not ends:
+                assert score == -1 or (want["editDistance"] == m), (it, m, T, K, d, score)
+                continue
+            assert score == want["editDistance"] and positions == ends, (it, m, T, K, d, score, positions, ends)

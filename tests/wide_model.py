@@ -22,6 +22,8 @@ def popc(x):
 def geom(mode, m, T, bandT, K):
     if mode == 1 and bandT < 0:                          # SHW inside the band of threshold K: |i - j| <= K
         return -K, K
+    if mode == 2 and bandT < 0:                          # HW inside the band of threshold K: starts in [0, T - m + K], K diagonals either side
+        return -K, max(0, T - m) + 2 * K
     if mode != 0:
         return -(1 << 40), 1 << 40
     D = (bandT if bandT > 0 else T) - m
