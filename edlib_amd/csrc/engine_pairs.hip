@@ -223,10 +223,15 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
             if (count[i] > kPosCap) { ovf.push_back((int)i); ovfOff.push_back(ovfOff.back() + count[i]); }
         if (!ovf.empty()) {
             std::vector<PairDesc> d2(ovf.size());
+            // (ring units are rescanned on the strips, every row of every column: a unit of more than 64 blocks -- a banded
+            // unit on a ring of 2- / 4-block lanes -- needs the strips' hand-off buffer, which its first scan did not)
+            long long aux2 = 0;
             for (size_t j = 0; j < ovf.size(); ++j) {
                 d2[j] = descs[ovf[j]];
                 d2[j].kinit = score[ovf[j]]; d2[j].posCap = count[ovf[j]]; d2[j].posOff = ovfOff[j];
+                if (ring != kWide) { d2[j].auxOff = aux2; if ((d2[j].qlen + 63) / 64 > 64) aux2 += d2[j].tlen; }
             }
+            if (ring != kWide) EDLIB_AMD_HIP(d_aux_.ensure((size_t)aux2));
             DevBuf<PairDesc> dd; DevBuf<int> pool2, s2, c2, l2;
             EDLIB_AMD_HIP(dd.alloc(d2.size())); EDLIB_AMD_HIP(pool2.alloc((size_t)ovfOff.back()));
             EDLIB_AMD_HIP(s2.alloc(d2.size())); EDLIB_AMD_HIP(c2.alloc(d2.size())); EDLIB_AMD_HIP(l2.alloc(d2.size()));
@@ -234,6 +239,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
             if (ring == kWide && planWide(mode, d2.data(), d2.size(), wp2)) return 1;
             EDLIB_AMD_HIP(hipMemcpyAsync(dd.p, d2.data(), d2.size() * sizeof(PairDesc), hipMemcpyHostToDevice, stream_));
             PairScanArgs a2 = a;
+            a2.aux = d_aux_.p;
             a2.descs = dd.p; a2.numUnits = (int)d2.size(); a2.posPool = pool2.p;
             a2.outScore = s2.p; a2.outCount = c2.p; a2.outLast = l2.p;
             scanTimerStart();

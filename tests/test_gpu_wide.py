@@ -314,3 +314,16 @@ def test_hw_inside_the_band_of_a_threshold(engine, checker):
             want = checker.align(q1[i], t1[i], "HW", "distance", 20)
             assert got[i]["editDistance"] == want["editDistance"] and got[i]["endLocations"] == want["endLocations"], (band, i)
     assert steps["1"] * 3 < steps["0"] * 2, steps         # (at least a third fewer executed word-steps; the geometry says ~2.9x)
+
+
+def test_banded_units_with_overflowing_end_location_lists(engine, checker):
+    """a banded semi-global unit of more than 64 blocks on a ring of 4-block lanes, in a periodic target: more end locations
+    than the 16 a unit's list keeps -- its exact second pass runs on the strips and needs their hand-off buffer (a device
+    fault in the soak of round 5 until it got one)"""
+    unit = synth.random_dna(41, 331).tobytes()
+    t = (unit * 40)[:9000]
+    for m in (4500, 6000):
+        q = (unit * 40)[100:100 + m]
+        for mode in ("HW", "SHW"):
+            for k in (-1, 5):
+                _check(engine, checker, [q, q[:3000]], [t, t], mode, "locations", k, "periodic target m=%d" % m)

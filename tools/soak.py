@@ -21,6 +21,14 @@ LENS = [1, 5, 31, 32, 33, 64, 65, 100, 150, 160, 161, 255, 256, 257, 258, 300, 3
 os.environ.setdefault("EDLIB_AMD_TALL_MIN_WAVES", "1")        # small batches also take the chained strips
 
 
+TRACE = os.environ.get("SOAK_TRACE") == "1"
+
+
+def trace(*a):
+    if TRACE:
+        print("[soak]", *a, file=sys.stderr, flush=True)
+
+
 def mutate(w, m, rate):
     n = int(rate * m)
     for _ in range(n):
@@ -75,6 +83,7 @@ def shared_case():
     if mode != "HW" and tn > 9000: target = target[:9000]
     task = str(rng.choice(["distance", "distance", "locations", "path"]))
     k = int(rng.choice([-1, -1, -1, 0, 4, 8, 9, 30, 100, 700]))
+    trace("shared mode=%s task=%s k=%d tn=%d nq=%d lens=%s" % (mode, task, k, len(target), len(lens), sorted(set(lens))[:8]))
     b = edlib_amd.SharedBatch(reads, target, mode=mode, task=task, k=k)
     try:
         b.run(); got = b.results_flat()
@@ -106,6 +115,7 @@ def pair_case():
     mode = str(rng.choice(["NW", "NW", "HW", "SHW"]))
     task = str(rng.choice(["distance", "locations", "path"]))
     k = int(rng.choice([-1, -1, 0, 5, 50, 1000]))
+    trace("pairs mode=%s task=%s k=%d nq=%d base=%d sigma=%d" % (mode, task, k, nq, base, sig))
     b = edlib_amd.PairBatch(qs, ts, mode=mode, task=task, k=k)
     try:
         b.run(); got = b.results_flat()
@@ -140,6 +150,7 @@ def long_pair_case():
     task = str(rng.choice(["distance", "distance", "locations", "path"]))
     if task == "path" and chk.name != "reference": task = "locations"      # (the restatement has no Hirschberg regime)
     k = int(rng.choice([-1, -1, -1, 30, 400, 5000]))
+    trace("long pairs mode=%s task=%s k=%d" % (mode, task, k), [(len(q), len(t)) for q, t in zip(qs, ts)])
     got = edlib_amd.align_pairs(qs, ts, mode=mode, task=task, k=k, raw=True)
     bad = None
     for q, t, g in zip(qs, ts, got):
@@ -159,6 +170,7 @@ def single_case():
         t = ACGT[rng.integers(0, 4, T)]
         q = mutate(t[:m + 64].copy(), m, float(rng.choice([0.0, 0.03, 0.2]))) if rng.random() < 0.7 and T >= m else ACGT[rng.integers(0, 4, m)]
         mode = str(rng.choice(["NW", "HW", "SHW"])); task = str(rng.choice(["distance", "locations", "path"])); k = int(rng.choice([-1, -1, 3, 60]))
+        trace("single mode=%s task=%s k=%d m=%d T=%d" % (mode, task, k, m, T))
         g = edlib_amd.align_raw(q.tobytes(), t.tobytes(), mode, task, k); w = chk.align(q.tobytes(), t.tobytes(), mode, task, k)
         if w["status"] != 2 and any(g[f] != w[f] for f in ("status", "editDistance", "endLocations", "startLocations", "numLocations", "alignment", "alphabetLength")):
             bad = "single mode=%s task=%s k=%d m=%d T=%d" % (mode, task, k, m, T)
