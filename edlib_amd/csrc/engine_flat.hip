@@ -154,7 +154,7 @@ int Batch::initFlatPairs()
     // (long targets: the general path cuts HW targets into segments when the batch alone does not fill the chip)
     if (maxBlocks > 16 || maxT > 65536) return 0;
     flatMaxBlocks_ = maxBlocks;
-    flatRing_ = maxBlocks <= 4 ? 4 : 16;
+    flatRing_ = maxBlocks <= 4 ? 4 : (maxBlocks <= 8 ? 8 : 16);      // (the smallest ring that holds every query whole)
     // window of a unit's alignment: the whole target (NW), at most 2 m + 1 columns (SHW: the scan stops there; HW: m + distance)
     auto window = [&](int u) { return scanMode == EDLIB_MODE_NW ? tlen(u) : (int)std::min<long long>(tlen(u), 2LL * qlen(u) + 1); };
     if (cfg_.task == EDLIB_TASK_PATH) {

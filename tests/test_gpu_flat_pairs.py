@@ -49,7 +49,7 @@ def _check(engine, qs, ts, mode, k=-1):
 
 
 @pytest.mark.parametrize("mode", ["NW", "SHW", "HW"])
-@pytest.mark.parametrize("maxq", [256, 1024])
+@pytest.mark.parametrize("maxq", [256, 512, 1024])          # 4-, 8- and 16-lane rings
 def test_flat_pairs_every_mode(engine, mode, maxq):
     qs, ts = _pairs(3000, 11 + maxq, maxq)
     _check(engine, qs, ts, mode)

@@ -57,7 +57,7 @@ for stage in "$@"; do
       for c in ${TRACE_CFGS:-2 4 5}; do trace bench_c$c --config $c --no-cpu-baseline --no-e2e --no-secondary; done ;;
     traffic)
       for c in ${TRAFFIC_CFGS:-2 4 5}; do
-        pmc fetch_c$c "FETCH_SIZE" --config $c --steps 1 --warmup 0
+        pmc fetch_c$c "${FETCH_COUNTER:-FETCH_SIZE}" --config $c --steps 1 --warmup 0
         pmc write_c$c "WRITE_SIZE" --config $c --steps 1 --warmup 0
       done
       python tools/make_traffic_json.py $OUT $R "$(cat $ROOT/.visit_commit 2>/dev/null)" | tee $OUT/${R}_traffic_summary.json ;;
