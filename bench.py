@@ -56,7 +56,7 @@ CONFIGS = {
     4: dict(units=100_000, name="100k x 10kb NW pairs, distance", mode="NW", task="distance",
             kernel="scan_pairs_ring_kernel<21,0,false,1> (+ <32,0,false,1> for the units above K = 1216)", dtype="u64 (2 x u32)"),
     5: dict(units=10_000, name="10k x 1kb NW pairs, path + CIGAR", mode="NW", task="path",
-            kernel="scan_pairs_ring_kernel<4,0,*,1> + traceback_kernel", dtype="u64 (2 x u32)"),
+            kernel="scan_pairs_ring32_kernel<8,true> + traceback32_kernel<32> (+ the collection: flat_write_kernel, cigar_kernel)", dtype="u32"),
 }
 TARGET_LEN, READ_LEN = 5_000_000, 150
 

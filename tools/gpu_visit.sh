@@ -8,7 +8,7 @@
 #   bench4|bench5  one config on its own (--config N)
 #   parity       whole-batch config-2 results for tools/full_parity_c2.py compare (gpurun_out/c2gpu.npz)
 #   trace        rocprofv3 --kernel-trace --stats of bench.py for configs 2, 4, 5 (TRACE_CFGS)
-#   traffic      rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) for configs 2, 4, 5 at full size
+#   traffic      rocprofv3 --pmc TCC_EA0_RDREQ_sum (= FETCH_SIZE's source; FETCH_COUNTER overrides) / WRITE_SIZE passes (separate runs) for configs 2, 4, 5 at full size
 #   sq           SQ instruction / cycle counters for config 2 (262,144 reads) and config 4 (20,000 units)
 #   cliff        tools/bench_read_length_cliff.py (CLIFF_ARGS)
 #   latency      build/latency for the engine and the reference
@@ -57,7 +57,7 @@ for stage in "$@"; do
       for c in ${TRACE_CFGS:-2 4 5}; do trace bench_c$c --config $c --no-cpu-baseline --no-e2e --no-secondary; done ;;
     traffic)
       for c in ${TRAFFIC_CFGS:-2 4 5}; do
-        pmc fetch_c$c "${FETCH_COUNTER:-FETCH_SIZE}" --config $c --steps 1 --warmup 0
+        pmc fetch_c$c "${FETCH_COUNTER:-TCC_EA0_RDREQ_sum}" --config $c --steps 1 --warmup 0
         pmc write_c$c "WRITE_SIZE" --config $c --steps 1 --warmup 0
       done
       python tools/make_traffic_json.py $OUT $R "$(cat $ROOT/.visit_commit 2>/dev/null)" | tee $OUT/${R}_traffic_summary.json ;;

@@ -3,7 +3,11 @@
 which bench.py copies into `roofline.traffic` TOGETHER WITH the commit the counters were taken at (a measurement of
 that commit, not of the timed run).  bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE on gfx950 reports
 half the bytes of a wide coalesced read (MI355X_MICROARCH.md §HBM; confirmed here on pack_target_2bit_kernel:
-2458 KB reported for its 5,000,000-byte read).  One bench step per pass (--steps 1 --warmup 0)."""
+2458 KB reported for its 5,000,000-byte read).  One bench step per pass (--steps 1 --warmup 0).
+Round 5: the FETCH_SIZE pass (three TCC slots) did not come back within its limit on this pool once the ring32 kernels
+were in the step (twice, 90 s and 240 s; the WRITE_SIZE pass and every test are unaffected), so the fetch pass takes the
+counter FETCH_SIZE is derived from, TCC_EA0_RDREQ_sum (one slot): FETCH_SIZE [KB] = RDREQ x 64 / 1024 (the guide's formula),
+i.e. the same number by another route; a file whose Counter_Name is TCC_EA0_RDREQ_sum is converted here."""
 import csv
 import json
 import os
@@ -20,7 +24,7 @@ try:
     out = json.load(open(dst))
 except Exception:
     out = {"configs": {}}
-out["method"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --config N --steps 1 --warmup 0 "
+out["method"] = ("rocprofv3 --pmc FETCH_SIZE (round 5: TCC_EA0_RDREQ_sum x 64 B, the counter it derives from) / --pmc WRITE_SIZE in separate passes over `bench.py --config N --steps 1 --warmup 0 "
                  "--no-cpu-baseline --no-e2e --no-secondary` (tools/gpu_visit.sh traffic); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024")
 for cfg, units in (("2", 1000000), ("4", 100000), ("5", 10000)):
     items, ok = {}, True
@@ -34,7 +38,10 @@ for cfg, units in (("2", 1000000), ("4", 100000), ("5", 10000)):
                 continue
             k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("edlib_amd::", "")
             items.setdefault(k, {"fetch_kb": 0.0, "write_kb": 0.0, "dispatches": 0})
-            items[k][ctr] += float(r["Sum"])
+            v = float(r["Sum"])
+            if r.get("Counter_Name", "").startswith("TCC_EA0_RDREQ"):
+                v = v * 64.0 / 1024.0                        # requests -> the KB FETCH_SIZE would report
+            items[k][ctr] += v
             items[k]["dispatches"] = int(r["Dispatches"])
     if not ok or not items:
         continue
