@@ -14,9 +14,9 @@
 //     target bytes and Peq words fetched from LDS one step ahead;
 //   * HW start locations (:228-272): one reverse SHW scan per end location inside the same launch (the reversed query's
 //     Peq is rebuilt in LDS);
-//   * PATH (:276-289, 942-1141): the storing scan keeps (P, M, block score) of every block-step in LDS when the matrix of
-//     the alignment window fits (ceil(m / 64) x T' x 20 bytes), lane 0 walks back with the reference's candidate order
-//     up > left > diagonal, the ops leave through the mailbox.
+//   * PATH (:276-289, 942-1141): the storing scan keeps the two planes of every block-step in LDS when the matrix of the
+//     alignment window fits (ceil(m / 64) x T' x 16 bytes); the wave walks back 64 cells of the current diagonal per trip
+//     (the reference's candidate order up > left > diagonal), the ops leave through the mailbox.
 //
 // What does not fit (more than 64 end locations, a store beyond the LDS budget, additional equalities, unknown modes)
 // answers "not handled" and the call takes the general path; results are the same function of the DP matrix either way
@@ -222,27 +222,56 @@ one_pair_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out)
                     ScanOut r;
                     scan_small<true>(s_peq, nb, s_t, s0, 1, len, m, 0, m + len, s_pos, s_store, r);
                 }
-                // reference obtainAlignmentTraceback (edlib.cpp:942-1141): lane 0 walks from (m-1, len-1) to the origin on the
-                // stored planes (up = x & ~y, left = x & y, diagonal = ~x with MATCH iff y); ops are written back to front
+                // reference obtainAlignmentTraceback (edlib.cpp:942-1141) on the stored planes (up = x & ~y, left = x & y, diagonal = ~x
+                // with MATCH iff y), the whole wave at once (round 5; lane 0 alone took 0.25 us per column: half of a 1 k x 1 k
+                // call): lane i looks at cell (r - i, c - i) of the current diagonal; the run of diagonal moves ends at the first
+                // cell whose x bit says an indel move is possible (or outside the matrix) -- one ballot --, the lanes before it
+                // write their MATCH / MISMATCH ops side by side, the cell that stopped the run takes up-moves while the "up"
+                // plane says so (one count-leading-ones inside its block), else one left move (the reference's preference up >
+                // left > diagonal, :1020, 1054, 1085); row -1 / column -1 leave the tail (:1040-1046, 1070-1078).  Ops are written
+                // back to front.  (ring32_kernels.hip: traceback32_kernel is the same walk over HBM, 32 lanes per unit.)
                 int wpos = m + len;
-                if (lane == 0) {
+                {
                     int r = m - 1, c = len - 1;
-                    for (;;) {
-                        const uint4 e = *reinterpret_cast<const uint4*>(s_store + (size_t)(c * nb + (r >> 6)) * 4);
-                        const u64 x = ((u64)e.y << 32) | e.x, y = ((u64)e.w << 32) | e.z;
-                        const int bit = r & 63;
-                        if (((x & ~y) >> bit) & 1ull) {               // up: INSERT
-                            s_ops[--wpos] = 1;
-                            if (r == 0) { for (int i = 0; i < c + 1; ++i) s_ops[--wpos] = 2; break; }
-                            --r;
-                        } else if (((x & y) >> bit) & 1ull) {         // left: DELETE
-                            s_ops[--wpos] = 2; --c;
-                            if (c == -1) { for (int i = 0; i < r + 1; ++i) s_ops[--wpos] = 1; break; }
-                        } else {                                      // diagonal: MATCH / MISMATCH
-                            s_ops[--wpos] = ((y >> bit) & 1ull) ? 0 : 3; --c;
-                            if (c == -1) { for (int i = 0; i < r; ++i) s_ops[--wpos] = 1; break; }
-                            if (r == 0) { for (int i = 0; i < c + 1; ++i) s_ops[--wpos] = 2; break; }
-                            --r;
+                    bool done = false;
+                    while (!done) {                                   // (r, c, wpos, done are wave-uniform)
+                        const int ri = r - lane, ci = c - lane;
+                        const bool valid = ri >= 0 && ci >= 0;
+                        u64 x = 0, y = 0;
+                        if (valid) {
+                            const uint4 e = *reinterpret_cast<const uint4*>(s_store + (size_t)(ci * nb + (ri >> 6)) * 4);
+                            x = ((u64)e.y << 32) | e.x; y = ((u64)e.w << 32) | e.z;
+                        }
+                        const u32 bit = (u32)ri & 63u;
+                        const bool xb = (x >> bit) & 1ull, yb = (y >> bit) & 1ull;
+                        const u64 stops = __builtin_amdgcn_ballot_w64(!valid || xb);
+                        const int j = stops ? __builtin_ctzll(stops) : 64;        // diagonal moves before the first stop
+                        if (lane < j) s_ops[wpos - 1 - lane] = yb ? (uint8_t)0 : (uint8_t)3;
+                        const int src = j < 64 ? j : 0;
+                        const u32 X0 = (u32)__shfl((int)(u32)x, src, 64), X1 = (u32)__shfl((int)(u32)(x >> 32), src, 64);
+                        const u32 Y0 = (u32)__shfl((int)(u32)y, src, 64), Y1 = (u32)__shfl((int)(u32)(y >> 32), src, 64);
+                        r -= j; c -= j; wpos -= j;
+                        if (j < 64) {
+                            if (r >= 0 && c >= 0) {                   // the cell that stopped the run: x is set there
+                                const u64 X = ((u64)X1 << 32) | X0, Y = ((u64)Y1 << 32) | Y0;
+                                const u32 bb = (u32)r & 63u;
+                                const u64 nx = ~((X & ~Y) << (63u - bb));        // row r at bit 63; the zeros shifted in end the run
+                                const int ups = nx ? __builtin_clzll(nx) : 64;   // leading ones: <= bb + 1
+                                if (ups > 0) {                        // INSERTs
+                                    if (lane < ups) s_ops[wpos - 1 - lane] = 1;
+                                    r -= ups; wpos -= ups;
+                                } else {                              // DELETE (x set, not up: Ph)
+                                    if (lane == 0) s_ops[wpos - 1] = 2;
+                                    c -= 1; wpos -= 1;
+                                }
+                            }
+                            if (r < 0 || c < 0) {                     // the matrix boundary: the rest is one run
+                                const int cnt = (r < 0 && c < 0) ? 0 : (c < 0 ? r + 1 : c + 1);
+                                const uint8_t op = c < 0 ? (uint8_t)1 : (uint8_t)2;      // INSERT / DELETE
+                                for (int i = lane; i < cnt; i += 64) s_ops[wpos - 1 - i] = op;
+                                wpos -= cnt;
+                                done = true;
+                            }
                         }
                     }
                 }
