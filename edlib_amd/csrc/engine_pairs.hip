@@ -78,6 +78,22 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     PairDesc* descs = reinterpret_cast<PairDesc*>(descsPin.p);
     std::vector<long long> opsOff(wantPath ? n + 1 : 1, 0);           // [n] = total op bytes (0 without PATH)
     long long peqWords = 0, auxInts = 0, storeEntries = 0, nbMax = 0;
+    // A storing scan on 4-lane rings over a chunk that cannot fill the chip (edlibAlign() with TASK_PATH on a 1 kb pair is
+    // one unit) is bound by the latency of its waves' instruction streams: it takes the rings of 32-row words and their
+    // walk instead (ring32_kernels.hip, DESIGN.md 4d: 0.18 against 0.48 us per step, a walk of ~T / 32 trips).  Every unit
+    // of a 4-lane launch fits an 8-lane ring of words: at most 4 blocks = 8 words, or a band of K <= 128 <= ring32_max_k(8).
+    bool use32 = wantPath && ring == 4 && mode == EDLIB_MODE_NW && n <= 20000 && d_tpool_.n <= ((size_t)64 << 20);
+    int maxWords32 = 1;
+    if (use32) {
+        long long store32 = 0;
+        for (size_t i = 0; i < n && use32; ++i) {
+            const UnitSpec& u = units[ua + i];
+            use32 = u.qstep == 1 && u.tstep == 1 && ((u.qlen + 31) / 32 <= 8 || u.kinit <= ring32_max_k(8));
+            store32 += 8LL * ring32_store_entries(8, u.qlen, u.tlen);
+            maxWords32 = std::max(maxWords32, (u.qlen + 31) / 32);
+        }
+        use32 = use32 && store32 < 0xF0000000LL && ring32_lds_bytes(8, tab_.sigmaT, maxWords32) <= 48 * 1024;
+    }
     for (size_t i = 0; i < n; ++i) {
         const UnitSpec& s = units[ua + i];
         PairDesc& d = descs[i];
@@ -88,7 +104,8 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         d.peqOff = peqWords; peqWords += nb * tab_.sigmaT;
         d.auxOff = auxInts; if (nb > 64 && !ring) auxInts += s.tlen;
         d.storeOff = storeEntries;
-        if (wantPath) storeEntries += ring > 0 ? ring_store_entries(ring, s.qlen, s.tlen) : pair_store_entries(s.qlen, s.tlen);
+        if (wantPath) storeEntries += use32 ? ring32_store_entries(8, s.qlen, s.tlen)                 // (8-byte entries)
+                                           : (ring > 0 ? ring_store_entries(ring, s.qlen, s.tlen) : pair_store_entries(s.qlen, s.tlen));
         d.posCap = wantPositions ? kPosCap : 0;
         d.posOff = (long long)i * kPosCap;
         d.colOff = -1; d.bandT = (s.band && (mode == EDLIB_MODE_SHW || mode == EDLIB_MODE_HW)) ? -1 : 0; d.ring = ring > 0 ? ring : 0;
@@ -145,7 +162,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     }
     d_outScore_.alias(d_out3_.p, n); d_outCount_.alias(d_out3_.p + n, n); d_outLast_.alias(d_out3_.p + 2 * n, n);
     if (wantPath) {
-        EDLIB_AMD_HIP(d_store_.ensure((size_t)storeEntries));
+        EDLIB_AMD_HIP(d_store_.ensure(use32 ? (size_t)(storeEntries + 1) / 2 : (size_t)storeEntries));
         if (!zeroCopy) {
             EDLIB_AMD_HIP(d_ops_.ensure((size_t)opsOff[n])); EDLIB_AMD_HIP(d_opsOff_.ensure(n + 1));
             EDLIB_AMD_HIP(d_opsLen_.ensure(n));
@@ -167,8 +184,15 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p; a.posPool = d_posPool_.p;
     a.colP = nullptr; a.colM = nullptr; a.colS = nullptr;
     a.wordSteps = ring > 0 ? ringStepsCounter() : nullptr;
+    if (use32) {                                       // the targets as symbol ids (the refills of the ring32 scan read them)
+        EDLIB_AMD_HIP(d_tsym_.ensure(d_tpool_.n));
+        EDLIB_AMD_HIP(launch_target_symbols(d_tpool_.p, d_tlut_.p, (long long)d_tpool_.n, d_tsym_.p, stream_));
+        a.tsym = d_tsym_.p; a.wordSteps = nullptr;
+        stats.word_steps += ring32_word_steps(8, descs, (int)n);
+    }
     scanTimerStart();
     if (ring == kWide) { if (launchWide(mode, a, descs, n, wplan)) return 1; }
+    else if (use32) EDLIB_AMD_HIP(launch_scan_pairs_ring32(8, true, a, maxWords32, stream_));
     else if (ring) EDLIB_AMD_HIP(launch_scan_pairs_ring(ring, mode, wantPath, a, stream_, ringH));
     else EDLIB_AMD_HIP(launch_scan_pairs(mode, wantPath, a, stream_));
     scanTimerStop();
@@ -177,7 +201,8 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         tb.descs = d_descs_.p; tb.numUnits = (int)n; tb.score = d_outScore_.p;
         tb.store = d_store_.p;
         tb.ops = d_ops_.p; tb.opsOff = d_opsOff_.p; tb.opsLen = d_opsLen_.p;
-        EDLIB_AMD_HIP(launch_traceback(tb, stream_));
+        if (use32) EDLIB_AMD_HIP(launch_traceback32(tb, 8, stream_));
+        else EDLIB_AMD_HIP(launch_traceback(tb, stream_));
     }
     if (lap.on) { EDLIB_AMD_HIP(hipStreamSynchronize(stream_)); lap("chunk: kernels"); }
     // downloads land in pinned staging (a pageable std::vector took 5 ms for the 17 MB of end positions of 262,144

@@ -165,6 +165,7 @@ int Batch::solveLongReads(std::vector<UnitResult>& res, std::vector<int>& fallba
     const int T = tlen(0);
     const int kpMax = 56;   // (24 / 40 / 56 measured: 494 / 446 / 427 ms per 2,048 ONT-like 10 kb reads)
     static const bool dbg = getenv("EDLIB_AMD_DEBUG") != nullptr;
+    Lap lap;
     auto kmax_of = [&](int m) { return (cfg_.k < 0 || cfg_.k > m) ? m : cfg_.k; };     // HW clamps k to m (edlib.cpp:566-568)
 
     // ---- first level: divergence of a sample (the HW distance of the first 256 rows of up to 128 strided queries,
@@ -186,6 +187,7 @@ int Batch::solveLongReads(std::vector<UnitResult>& res, std::vector<int>& fallba
         std::sort(r.begin(), r.end());
         rate = r[ns / 2];
     }
+    lap("long: probe");
     std::vector<int> level(n);                     // current threshold of every query; -1 resolved, -2 handed back
     for (size_t i = 0; i < n; ++i) {
         const int m = qlen(longUnits_[i]);
@@ -222,6 +224,7 @@ int Batch::solveLongReads(std::vector<UnitResult>& res, std::vector<int>& fallba
             }
             if (chunk.empty()) continue;
             if (scanPieces(pieces, true, &cand, &ovf, nullptr)) return 1;
+            lap("long: filter scan");
             // ---- windows of end columns per query
             std::vector<std::vector<std::pair<int, int>>> win(n > 0 ? chunk.size() : 0);
             std::vector<int> slotOf(n, -1);                       // index into longUnits_ -> index into chunk
@@ -261,8 +264,10 @@ int Batch::solveLongReads(std::vector<UnitResult>& res, std::vector<int>& fallba
                     vunits.push_back(v); vwho.push_back(c); vbase.push_back(start);
                 }
             }
+            lap("long: windows");
             SolveOut so;
             if (!vunits.empty() && solveSemiGlobalUnits(EDLIB_MODE_HW, true, vunits, so)) return 1;
+            lap("long: verification");
             // ---- the smallest score over a query's windows, its columns in ascending order (windows are disjoint and sorted)
             std::vector<int> bestOf(chunk.size(), -1);
             for (size_t v = 0; v < vunits.size(); ++v)
@@ -290,6 +295,7 @@ int Batch::solveLongReads(std::vector<UnitResult>& res, std::vector<int>& fallba
                     next.push_back(i);
                 }
             }
+            lap("long: finalize");
             if (dbg) fprintf(stderr, "[edlib_amd] long reads round %d: %zu queries, %zu pieces, %zu candidates, %zu windows\n",
                              round, chunk.size(), pieces.size(), cand.size(), vunits.size());
         }
