@@ -214,6 +214,8 @@ private:
     // ---- one unit on many waves (wide_kernels.hip): `ring` = kWide in solve() / solveChunk().  NW: the band of threshold
     // UnitSpec::kinit, any width (exact iff score <= kinit); SHW / HW: the pipelined strips.  Distances / positions only.
     static const int kWide = -1;
+    static const int kRing32 = -2;                // solve(): storing NW scans on 16-lane rings of 32-row words (the caller checked ring32_fits)
+    bool ring32_fits(const std::vector<UnitSpec>& units, size_t a, size_t b, int G) const;
     DevBuf<unsigned long long> d_wide_; DevBuf<unsigned> d_wabort_; PinBuf h_wabort_;
     int wideCap_ = -1;                           // resident waves of the wide kernel on this device
     struct WidePlan { int slots = 1; size_t perLaunch = 1; };

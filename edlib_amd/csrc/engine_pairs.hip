@@ -38,6 +38,24 @@ unsigned long long* Batch::ringStepsCounter()
     return d_ringSteps_.p;
 }
 
+// Can the storing scans of units [a, b) run on G-lane rings of 32-row words (ring32_kernels.hip)?  Forward units whose band
+// fits the ring (or whose words all sit on it), a chunk that cannot fill the chip (the kernels are built for lone waves), a
+// target pool small enough to be mapped to symbol ids per call, a store the kernel's 32-bit offsets reach, a Peq table per
+// unit that fits a wave's LDS.
+bool Batch::ring32_fits(const std::vector<UnitSpec>& units, size_t a, size_t b, int G) const
+{
+    if (b - a > 20000 || d_tpool_.n > ((size_t)64 << 20)) return false;
+    long long store = 0; int maxWords = 1;
+    for (size_t i = a; i < b; ++i) {
+        const UnitSpec& u = units[i];
+        const int nw = (u.qlen + 31) / 32;
+        if (u.qstep != 1 || u.tstep != 1 || !(nw <= G || u.kinit <= ring32_max_k(G))) return false;
+        store += 8LL * ring32_store_entries(G, u.qlen, u.tlen);
+        maxWords = std::max(maxWords, nw);
+    }
+    return store < 0xF0000000LL && ring32_lds_bytes(G, tab_.sigmaT, maxWords) <= 48 * 1024;
+}
+
 int Batch::solve(int mode, bool wantPositions, bool wantPath, const std::vector<UnitSpec>& units, SolveOut& out,
                  int ring, int ringH)
 {
@@ -57,8 +75,9 @@ int Batch::solve(int mode, bool wantPositions, bool wantPath, const std::vector<
         while (b < n) {
             const long long nb = (units[b].qlen + 63) / 64;
             const long long pb = nb * tab_.sigmaT * 8;
-            const long long sb = !wantPath ? 0 : (long long)sizeof(StoreEntry) * (ring > 0 ? ring_store_entries(ring, units[b].qlen, units[b].tlen)
-                                                            : pair_store_entries(units[b].qlen, units[b].tlen));
+            const long long sb = !wantPath ? 0 : (ring == kRing32 ? 8LL * ring32_store_entries(16, units[b].qlen, units[b].tlen)
+                                                 : (long long)sizeof(StoreEntry) * (ring > 0 ? ring_store_entries(ring, units[b].qlen, units[b].tlen)
+                                                            : pair_store_entries(units[b].qlen, units[b].tlen)));
             if (b > a && (peqBytes + pb > peqBudget || storeBytes + sb > storeBudget)) break;
             peqBytes += pb; storeBytes += sb; ++b;
         }
@@ -82,18 +101,13 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     // one unit) is bound by the latency of its waves' instruction streams: it takes the rings of 32-row words and their
     // walk instead (ring32_kernels.hip, DESIGN.md 4d: 0.18 against 0.48 us per step, a walk of ~T / 32 trips).  Every unit
     // of a 4-lane launch fits an 8-lane ring of words: at most 4 blocks = 8 words, or a band of K <= 128 <= ring32_max_k(8).
-    bool use32 = wantPath && ring == 4 && mode == EDLIB_MODE_NW && n <= 20000 && d_tpool_.n <= ((size_t)64 << 20);
+    // (ring == kRing32: the caller asks for 16-lane rings of words -- bands up to K = 448 -- and has checked ring32_fits())
+    const int g32 = ring == kRing32 ? 16 : 8;
+    bool use32 = wantPath && (ring == 4 || ring == kRing32) && mode == EDLIB_MODE_NW && ring32_fits(units, ua, ub, g32);
     int maxWords32 = 1;
-    if (use32) {
-        long long store32 = 0;
-        for (size_t i = 0; i < n && use32; ++i) {
-            const UnitSpec& u = units[ua + i];
-            use32 = u.qstep == 1 && u.tstep == 1 && ((u.qlen + 31) / 32 <= 8 || u.kinit <= ring32_max_k(8));
-            store32 += 8LL * ring32_store_entries(8, u.qlen, u.tlen);
-            maxWords32 = std::max(maxWords32, (u.qlen + 31) / 32);
-        }
-        use32 = use32 && store32 < 0xF0000000LL && ring32_lds_bytes(8, tab_.sigmaT, maxWords32) <= 48 * 1024;
-    }
+    for (size_t i = 0; use32 && i < n; ++i) maxWords32 = std::max(maxWords32, (units[ua + i].qlen + 31) / 32);
+    if (ring == kRing32 && !use32) { set_error("ring32 level on units that do not fit it"); return 1; }
+    if (ring == kRing32) ring = 16;                    // (descriptor bookkeeping below: any ring size > 0)
     for (size_t i = 0; i < n; ++i) {
         const UnitSpec& s = units[ua + i];
         PairDesc& d = descs[i];
@@ -104,7 +118,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         d.peqOff = peqWords; peqWords += nb * tab_.sigmaT;
         d.auxOff = auxInts; if (nb > 64 && !ring) auxInts += s.tlen;
         d.storeOff = storeEntries;
-        if (wantPath) storeEntries += use32 ? ring32_store_entries(8, s.qlen, s.tlen)                 // (8-byte entries)
+        if (wantPath) storeEntries += use32 ? ring32_store_entries(g32, s.qlen, s.tlen)               // (8-byte entries)
                                            : (ring > 0 ? ring_store_entries(ring, s.qlen, s.tlen) : pair_store_entries(s.qlen, s.tlen));
         d.posCap = wantPositions ? kPosCap : 0;
         d.posOff = (long long)i * kPosCap;
@@ -188,11 +202,11 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         EDLIB_AMD_HIP(d_tsym_.ensure(d_tpool_.n));
         EDLIB_AMD_HIP(launch_target_symbols(d_tpool_.p, d_tlut_.p, (long long)d_tpool_.n, d_tsym_.p, stream_));
         a.tsym = d_tsym_.p; a.wordSteps = nullptr;
-        stats.word_steps += ring32_word_steps(8, descs, (int)n);
+        stats.word_steps += ring32_word_steps(g32, descs, (int)n);
     }
     scanTimerStart();
     if (ring == kWide) { if (launchWide(mode, a, descs, n, wplan)) return 1; }
-    else if (use32) EDLIB_AMD_HIP(launch_scan_pairs_ring32(8, true, a, maxWords32, stream_));
+    else if (use32) EDLIB_AMD_HIP(launch_scan_pairs_ring32(g32, true, a, maxWords32, stream_));
     else if (ring) EDLIB_AMD_HIP(launch_scan_pairs_ring(ring, mode, wantPath, a, stream_, ringH));
     else EDLIB_AMD_HIP(launch_scan_pairs(mode, wantPath, a, stream_));
     scanTimerStop();
@@ -201,7 +215,7 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
         tb.descs = d_descs_.p; tb.numUnits = (int)n; tb.score = d_outScore_.p;
         tb.store = d_store_.p;
         tb.ops = d_ops_.p; tb.opsOff = d_opsOff_.p; tb.opsLen = d_opsLen_.p;
-        if (use32) EDLIB_AMD_HIP(launch_traceback32(tb, 8, stream_));
+        if (use32) EDLIB_AMD_HIP(launch_traceback32(tb, g32, stream_));
         else EDLIB_AMD_HIP(launch_traceback(tb, stream_));
     }
     if (lap.on) { EDLIB_AMD_HIP(hipStreamSynchronize(stream_)); lap("chunk: kernels"); }
@@ -792,6 +806,33 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
         }
     }
     Lap lap;
+    // A handful of PATH units (edlibAlign() with TASK_PATH on a 1 kb pair is one): the whole-wave ring they would start on
+    // takes 0.48 us per dependent step with its store, and the walk a cell at a time.  First the 16-lane rings of 32-row
+    // words (K = 448, or the whole matrix up to 16 words: DESIGN.md 4d): 0.16 us per step, a walk of ~T / 32 trips; a unit
+    // beyond that band goes on to the levels below.
+    if (paths != nullptr && fewUnits && !bandOff) {
+        std::vector<UnitSpec> sel; std::vector<size_t> who;
+        for (size_t i = 0; i < n; ++i) {
+            UnitSpec u = units[i];
+            const int nw = (u.qlen + 31) / 32;
+            u.kinit = std::min(kcap, nw <= 16 ? std::max(u.qlen, u.tlen) : ring32_max_k(16));
+            if (std::abs(u.qlen - u.tlen) > u.kinit || u.qlen < 128) continue;   // (no path within this band; tiny units: their 4-lane level takes ring32 anyway)
+            sel.push_back(u); who.push_back(i);
+        }
+        if (!sel.empty() && ring32_fits(sel, 0, sel.size(), 16)) {
+            SolveOut& so = soLevel_;
+            if (solve(EDLIB_MODE_NW, false, true, sel, so, kRing32)) return 1;
+            opsKeep_.insert(opsKeep_.end(), so.opsBufs.begin(), so.opsBufs.end());
+            for (size_t q = 0; q < sel.size(); ++q) {
+                const size_t i = who[q];
+                if (so.score[q] > sel[q].kinit) continue;                         // beyond the band: the levels below
+                score[i] = so.score[q];
+                (*paths)[i].p = so.opsPtr[q]; (*paths)[i].len = so.opsLen[q];
+                --atLevel[lvl[i]]; lvl[i] = -1;
+            }
+            lap("nw level: ring32");
+        }
+    }
     for (int l = 0; l <= nl; ++l) {
         if (atLevel[l] == 0) continue;
         if (l == nl && wideLevel) break;
