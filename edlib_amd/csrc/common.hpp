@@ -4,7 +4,6 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
-#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -117,10 +116,6 @@ struct Event {
     ~Event() { if (e) pool_event_release(e, device); }
     hipError_t create() { return e ? hipSuccess : pool_event(&e, &device); }
 };
-
-// fn(lo, hi) over [0, n) in contiguous ranges of at least `grain`, on the caller and a few persistent helper threads
-// (runtime.hip); inline when the loop is small or the helpers are busy with another batch's loop.  fn must not throw.
-void parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)>& fn);
 
 // Joins the threads of a fan-out on every exit path: a std::thread that is still joinable when its vector unwinds
 // (thread creation failed part-way: EAGAIN) would be std::terminate before guarded() sees the exception.

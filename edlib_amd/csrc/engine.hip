@@ -673,13 +673,11 @@ int Batch::runImpl()
             lap("run: pair specs");
             if (solveGlobalDistances(units, score, fuse ? &fusedOps_ : nullptr)) return 1;
             lap("run: global distances");
-            parallel_for(units.size(), 8192, [&](size_t lo, size_t hi) {      // (a record per unit: distinct entries of `res`)
-                for (size_t i = lo; i < hi; ++i) {
-                    UnitResult& r = res[pairUnits_[i]];
-                    if (deferReset) blank_record(r);
-                    finalize_global(r, cfg_.k, mode, units[i].tlen, score[i]);
-                }
-            });
+            for (size_t i = 0; i < units.size(); ++i) {
+                UnitResult& r = res[pairUnits_[i]];
+                if (deferReset) blank_record(r);
+                finalize_global(r, cfg_.k, mode, units[i].tlen, score[i]);
+            }
             if (fuse)
                 for (size_t i = 0; i < units.size(); ++i) {
                     UnitResult& r = res[pairUnits_[i]];

@@ -108,18 +108,21 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     for (size_t i = 0; use32 && i < n; ++i) maxWords32 = std::max(maxWords32, (units[ua + i].qlen + 31) / 32);
     if (ring == kRing32 && !use32) { set_error("ring32 level on units that do not fit it"); return 1; }
     if (ring == kRing32) ring = 16;                    // (descriptor bookkeeping below: any ring size > 0)
-    // the running sums first (Peq words, hand-off ints, store entries, op slots: each unit's offsets depend on the units before
-    // it), then the plain fields of the 88-byte descriptors in parallel (100,000 of them were 0.35 ms of a config-4 step)
     for (size_t i = 0; i < n; ++i) {
         const UnitSpec& s = units[ua + i];
         PairDesc& d = descs[i];
         const long long nb = (s.qlen + 63) / 64;
         nbMax = std::max(nbMax, nb);
+        d.qoff = s.qoff; d.toff = s.toff; d.qlen = s.qlen; d.tlen = s.tlen; d.qstep = s.qstep; d.tstep = s.tstep;
+        d.kinit = s.kinit; d.skip = s.skip;
         d.peqOff = peqWords; peqWords += nb * tab_.sigmaT;
         d.auxOff = auxInts; if (nb > 64 && !ring) auxInts += s.tlen;
         d.storeOff = storeEntries;
         if (wantPath) storeEntries += use32 ? ring32_store_entries(g32, s.qlen, s.tlen)               // (8-byte entries)
                                            : (ring > 0 ? ring_store_entries(ring, s.qlen, s.tlen) : pair_store_entries(s.qlen, s.tlen));
+        d.posCap = wantPositions ? kPosCap : 0;
+        d.posOff = (long long)i * kPosCap;
+        d.colOff = -1; d.bandT = (s.band && (mode == EDLIB_MODE_SHW || mode == EDLIB_MODE_HW)) ? -1 : 0; d.ring = ring > 0 ? ring : 0;
         // op slot of the unit, filled from the back.  An alignment has (m + T + inserts + deletes) / 2 ops, and a ring scan
         // is only walked when its distance is within kinit: (m + T + kinit) / 2 bounds the length (config 5: 1064 bytes
         // instead of 2000 per pair to bring back over PCIe)
@@ -127,24 +130,10 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
             const long long full = (long long)s.qlen + s.tlen;
             opsOff[i + 1] = opsOff[i] + (ring > 0 && s.kinit >= 0 && s.kinit < full ? (full + s.kinit) / 2 + 8 : full);
         }
+        // executed work: whole matrix, or one 64-block wave per column inside the band
         // executed work: the strips update every block of every column; the rings count the updates inside the band themselves
         if (!ring) stats.word_steps += 2 * nb * (long long)s.tlen;
-        else if (ring == kWide) stats.word_steps += wide_word_steps(mode, s.qlen, s.tlen, (s.band && mode != EDLIB_MODE_NW) ? -1 : 0, s.kinit);
-    }
-    {
-        const int ringField = ring > 0 ? ring : 0;
-        const bool semi = mode == EDLIB_MODE_SHW || mode == EDLIB_MODE_HW;
-        parallel_for(n, 8192, [&](size_t lo, size_t hi) {
-            for (size_t i = lo; i < hi; ++i) {
-                const UnitSpec& s = units[ua + i];
-                PairDesc& d = descs[i];
-                d.qoff = s.qoff; d.toff = s.toff; d.qlen = s.qlen; d.tlen = s.tlen; d.qstep = s.qstep; d.tstep = s.tstep;
-                d.kinit = s.kinit; d.skip = s.skip;
-                d.posCap = wantPositions ? kPosCap : 0;
-                d.posOff = (long long)i * kPosCap;
-                d.colOff = -1; d.bandT = (s.band && semi) ? -1 : 0; d.ring = ringField;
-            }
-        });
+        else if (ring == kWide) stats.word_steps += wide_word_steps(mode, s.qlen, s.tlen, d.bandT, s.kinit);
     }
     WidePlan wplan;
     if (ring == kWide && planWide(mode, descs, n, wplan)) return 1;
@@ -850,16 +839,6 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
         std::vector<UnitSpec>& sel = selScratch_; std::vector<size_t>& who = whoScratch_;
         sel.clear(); who.clear();
         sel.reserve(atLevel[l]); who.reserve(atLevel[l]);
-        if (atLevel[l] == n) {                             // the level takes every unit (a batch of like pairs): a straight map
-            sel.resize(n); who.resize(n);
-            parallel_for(n, 8192, [&](size_t lo, size_t hi) {
-                for (size_t i = lo; i < hi; ++i) {
-                    UnitSpec u = units[i];
-                    if (l < nl) u.kinit = std::min(kcap, blocks(i) <= blocks_of(l) ? std::max(u.qlen, u.tlen) : cap_of(l));
-                    sel[i] = u; who[i] = i;
-                }
-            });
-        } else
         for (size_t i = 0; i < n; ++i) {
             if (lvl[i] != l) continue;
             UnitSpec u = units[i];

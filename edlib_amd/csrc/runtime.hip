@@ -2,8 +2,6 @@
 // streams and events (a call of edlibAlign() is a batch of one: without the cache it pays ~30 hipMalloc / hipFree round
 // trips), the helper-thread budget, device selection.  Host code only.
 #include "engine.hpp"
-#include <functional>
-#include <system_error>
 #include <sched.h>
 #include <cstdarg>
 
@@ -215,70 +213,6 @@ int host_threads(int cap) {
         return n;
     }();
     return std::max(1, std::min(cap, avail));
-}
-
-// A few persistent helper threads for the per-unit host loops of a big batch (unit selection, descriptors, records): at
-// 100,000 units each of those loops is 0.1-0.4 ms during which the device idles, and std::thread creation per loop would
-// cost what it saves.  parallel_for(n, grain, fn) runs fn(lo, hi) over [0, n) in contiguous ranges: on the calling thread
-// alone when the loop is small or another parallel_for is in flight (the pool serves one loop at a time: batches on other
-// host threads fall back to running theirs inline), else on the caller + the pool.  fn must not throw.
-namespace {
-struct HostPool {
-    std::mutex m; std::condition_variable cvWork, cvDone;
-    std::vector<std::thread> workers;
-    const std::function<void(size_t, size_t)>* fn = nullptr;
-    size_t n = 0, chunk = 0, next = 0; int pending = 0; unsigned long long epoch = 0; bool busy = false, stop = false;
-    void worker() {
-        unsigned long long seen = 0;
-        std::unique_lock<std::mutex> l(m);
-        for (;;) {
-            cvWork.wait(l, [&] { return stop || epoch != seen; });
-            if (stop) return;
-            seen = epoch;
-            for (;;) {
-                const size_t lo = next; if (lo >= n) break;
-                const size_t hi = std::min(n, lo + chunk); next = hi;
-                l.unlock(); (*fn)(lo, hi); l.lock();
-            }
-            if (--pending == 0) cvDone.notify_one();
-        }
-    }
-};
-HostPool* host_pool() {
-    static HostPool* p = [] {
-        HostPool* hp = new HostPool;                               // leaked on purpose, like the block cache: no teardown-order hazards
-        const int nthreads = host_threads(4) - 1;
-        try { for (int i = 0; i < nthreads; ++i) { hp->workers.emplace_back([hp] { hp->worker(); }); hp->workers.back().detach(); } }
-        catch (const std::system_error&) {}
-        return hp;
-    }();
-    return p;
-}
-}  // namespace
-
-void parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)>& fn)
-{
-    if (n == 0) return;
-    HostPool* hp = n >= 2 * grain ? host_pool() : nullptr;
-    if (hp && !hp->workers.empty()) {
-        std::unique_lock<std::mutex> l(hp->m);
-        if (!hp->busy) {
-            hp->busy = true;
-            const size_t parts = std::min<size_t>(hp->workers.size() + 1, (n + grain - 1) / grain);
-            hp->fn = &fn; hp->n = n; hp->chunk = (n + parts - 1) / parts; hp->next = 0;
-            hp->pending = (int)hp->workers.size(); ++hp->epoch;
-            hp->cvWork.notify_all();
-            for (;;) {                                             // the caller takes ranges too
-                const size_t lo = hp->next; if (lo >= hp->n) break;
-                const size_t hi = std::min(hp->n, lo + hp->chunk); hp->next = hi;
-                l.unlock(); fn(lo, hi); l.lock();
-            }
-            hp->cvDone.wait(l, [&] { return hp->pending == 0; });
-            hp->fn = nullptr; hp->busy = false;
-            return;
-        }
-    }
-    fn(0, n);
 }
 
 int device_count() {
