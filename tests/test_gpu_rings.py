@@ -294,3 +294,25 @@ def test_round2_ring_sizes_8_and_21(engine, ref, oracle):
     for i in range(0, 300, 3):
         want = impl.align(qs[i], ts[i], "NW", "distance", -1)
         assert all(got[i][f] == want[f] for f in FIELDS), (i, got[i], want)
+
+
+def test_big_batch_of_like_pairs(engine, checker):
+    """20,000 NW pairs of 1,100 bases (beyond the flat path's 16 blocks; the NW distance levels over a batch whose unit
+    selection, descriptors and records are 20,000 long): a strided sample against the reference, every unit's shape fields,
+    and two runs agree (records are recycled across runs)"""
+    from edlib_amd import synth
+    import numpy as np
+    qs, ts = synth.mutated_pairs(20000, 1100, seed=77, sub=0.02, ins=0.01, dele=0.01)
+    b = engine.PairBatch(list(qs), list(ts), mode="NW", task="distance", k=-1)
+    try:
+        b.run()
+        first = b.results_flat()["editDistance"].copy()
+        b.run()
+        got = b.results_flat()
+    finally:
+        b.close()
+    assert np.array_equal(first, got["editDistance"]) and np.all(got["status"] == 0) and np.all(got["numLocations"] == 1)
+    assert np.all(got["ends"] == 1099)
+    for i in range(0, 20000, 67):
+        want = checker.align(qs[i].tobytes(), ts[i].tobytes(), "NW", "distance", -1)
+        assert got["editDistance"][i] == want["editDistance"] and got["alphabetLength"][i] == want["alphabetLength"], i
