@@ -989,27 +989,16 @@ int Batch::cigarView(int format, const char** chars, const long long** offsets)
     if (resultsView(&v)) return 1;
     CigarOut& c = cigar_[format == EDLIB_CIGAR_STANDARD ? 1 : 0];
     const size_t n = (size_t)n_;
+    cigarSticky_ = true;
     if (!c.ready) {
         DeviceGuard guard(device_);
         EDLIB_AMD_HIP(guard.status);
         if (viewAlnDev_ && v.alignment) {
-            const size_t nblocks = (n + 255) / 256;
-            EDLIB_AMD_HIP(d_cigWork_.ensure(3 * n + nblocks + 4));
-            long long* cigLen = d_cigWork_.p; long long* cigRel = cigLen + n; long long* blockTot = cigRel + n;
-            long long* totals = blockTot + nblocks; long long* cigOff = totals + 2;
-            const int standard = format == EDLIB_CIGAR_STANDARD ? 1 : 0;
-            EDLIB_AMD_HIP(launch_cigars(viewAlnDev_, viewAlnOffDev_, n_, standard, cigLen, cigRel, blockTot, totals, nullptr, cigOff, 0, stream_));
-            if (c.offs.n < (n + 1) * sizeof(long long)) EDLIB_AMD_HIP(c.offs.alloc((n + 1) * sizeof(long long)));
-            long long total = 0;
-            EDLIB_AMD_HIP(hipMemcpyAsync(c.offs.p, totals, sizeof(long long), hipMemcpyDeviceToHost, stream_));
+            const int f = format == EDLIB_CIGAR_STANDARD ? 1 : 0;
+            const size_t cap = 2 * (size_t)v.alnOffsets[n] + n + 64;
+            if (enqueueCigars(f, viewAlnDev_, viewAlnOffDev_, cap, stream_)) return 1;
             EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
-            total = *reinterpret_cast<const long long*>(c.offs.p);
-            if (total < (long long)n) { set_error("CIGAR: bad total"); return 1; }
-            EDLIB_AMD_HIP(d_cigChars_.ensure((size_t)total));
-            if (c.chars.n < (size_t)total) EDLIB_AMD_HIP(c.chars.alloc((size_t)total));
-            EDLIB_AMD_HIP(launch_cigars(viewAlnDev_, viewAlnOffDev_, n_, standard, cigLen, cigRel, blockTot, totals, d_cigChars_.p, cigOff, 1, stream_));
-            EDLIB_AMD_HIP(hipMemcpyAsync(c.chars.p, d_cigChars_.p, (size_t)total, hipMemcpyDeviceToHost, stream_));
-            EDLIB_AMD_HIP(hipMemcpyAsync(c.offs.p, cigOff, (n + 1) * sizeof(long long), hipMemcpyDeviceToHost, stream_));
+            if (fetchCigars(f, stream_)) return 1;
             EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
             c.p = reinterpret_cast<const char*>(c.chars.p); c.off = reinterpret_cast<const long long*>(c.offs.p);
         } else {

@@ -320,7 +320,11 @@ private:
     // CIGAR strings of the last run (edlibAlignmentToCigar, edlib.cpp:303-350, over the batch): [0] extended, [1] standard
     struct CigarOut { bool ready = false; PinBuf chars, offs; std::vector<char> hostChars; std::vector<long long> hostOffs; const char* p = nullptr; const long long* off = nullptr; };
     CigarOut cigar_[2];
-    DevBuf<long long> d_cigWork_; DevBuf<char> d_cigChars_;
+    DevBuf<long long> d_cigWork_; DevBuf<char> d_cigChars_, d_cigChars2_;
+    bool cigarSticky_ = false;                   // a caller of this batch has asked for CIGARs: later collections make them while the op bytes travel
+    Event evView_;
+    int enqueueCigars(int f, const uint8_t* aln, const long long* alnOff, size_t cap, hipStream_t st);
+    int fetchCigars(int f, hipStream_t st);
     int ensureCollected();                       // results of the last run that are still on the device -> results_
 };
 
