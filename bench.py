@@ -54,7 +54,7 @@ CONFIGS = {
     2: dict(units=1_000_000, name="1M x 150bp HW reads vs 5Mb target", mode="HW", task="distance",
             kernel="scan_reads_banded_kernel<5> (+ scan_reads_kernel<5,2> for pass 2)", dtype="u32"),
     4: dict(units=100_000, name="100k x 10kb NW pairs, distance", mode="NW", task="distance",
-            kernel="scan_pairs_ring_kernel<21,0,false,1> (+ <32,0,false,1> for the units above K = 1216)", dtype="u64 (2 x u32)"),
+            kernel="scan_pairs_ring_kernel<21,0,false,1> (+ <32,0,false,1> as two half scans for units above K = 1301)", dtype="u64 (2 x u32)"),
     5: dict(units=10_000, name="10k x 1kb NW pairs, path + CIGAR", mode="NW", task="path",
             kernel="scan_pairs_ring32_kernel<8,true> + traceback32_kernel<32> (+ the collection: flat_write_kernel, cigar_kernel)", dtype="u32"),
 }

@@ -203,6 +203,7 @@ alphabet_count_short_kernel(const uint8_t* __restrict__ qpool, const long long* 
 Batch::~Batch() {
     DeviceGuard guard(device_);
     if (side_) { (void)hipStreamSynchronize(side_); pool_stream_release(side_); }
+    if (aux_) { (void)hipStreamSynchronize(aux_); (void)hipStreamDestroy(aux_); }
     if (stream_) { (void)hipStreamSynchronize(stream_); pool_stream_release(stream_); }
     wideGateRelease();           // (behind the synchronisation: a failed run may still have had a wide launch in flight)
     for (auto& p : scanEvents_) { pool_event_release(p.first, device_); pool_event_release(p.second, device_); }
@@ -456,19 +457,21 @@ void finalize_global(UnitResult& r, int kcfg, int mode, int T, int score) {
 // alphabetLength of the units the reads path does not cover (reference transformSequences, edlib.cpp:1417-1462:
 // the number of distinct bytes of query and target).  It depends on the sequences only, not on any scan, so it runs
 // on a side stream next to phase 1 and is collected after it.
-int Batch::alphabetLengthsBegin()
+int Batch::alphabetLengthsBegin(bool markOnly, bool marked)
 {
-    alphaPending_ = false;
+    if (!marked) alphaPending_ = false;
     if (alphaUnits_.empty() || alphaOnHost_) return 0;
     const size_t n = alphaUnits_.size();
     if (!side_) EDLIB_AMD_HIP(pool_stream(&side_));
     EDLIB_AMD_HIP(evA_.create());
+    // the inputs went up on stream_ (init): the side stream starts behind whatever stream_ held at the start of the run
+    // (a big pair batch launches the count later, next to its main scan -- the mark is taken first all the same)
+    if (!marked) EDLIB_AMD_HIP(hipEventRecord(evA_.e, stream_));
+    if (markOnly) return 0;
     if (!d_alphaIdx_.p) {
         EDLIB_AMD_HIP(d_alphaIdx_.alloc(n)); EDLIB_AMD_HIP(d_alphaOut_.alloc(n)); EDLIB_AMD_HIP(alphaPin_.alloc(n * sizeof(int)));
         EDLIB_AMD_HIP(hipMemcpyAsync(d_alphaIdx_.p, alphaUnits_.data(), n * sizeof(int), hipMemcpyHostToDevice, side_));
     }
-    // the inputs went up on stream_ (init): the side stream starts behind whatever stream_ holds now
-    EDLIB_AMD_HIP(hipEventRecord(evA_.e, stream_));
     EDLIB_AMD_HIP(hipStreamWaitEvent(side_, evA_.e, 0));
     if (alphaBytes_ <= 4096LL * (long long)n)                        // short sequences: a wave per unit
         hipLaunchKernelGGL(alphabet_count_short_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, side_,
@@ -580,7 +583,11 @@ int Batch::runImpl()
         else if (mode == EDLIB_MODE_SHW || mode == EDLIB_MODE_HW) { r.editDistance = m; r.ends.assign(1, -1); r.hasEnds = true; }
         else r.status = EDLIB_STATUS_ERROR;
     }
-    if (alphabetLengthsBegin()) return 1;
+    // (a big NW distance batch of pairs: the count reads 2 GB next to the Peq build of the whole batch, which the main scan
+    // waits for -- it is launched behind that scan instead, which does not touch HBM much: runLevelAll)
+    alphaDeferred_ = !flatPairs_ && cfg_.mode == EDLIB_MODE_NW && cfg_.task == EDLIB_TASK_DISTANCE && pairUnits_.size() >= 8192 &&
+                     groups_.empty() && longUnits_.empty();
+    if (alphabetLengthsBegin(alphaDeferred_, false)) return 1;
     bool flatDone = false;
     if (flatPairs_) {                                   // ---- a flat pair batch: everything stays on the device
         bool over = false, fell = false;
@@ -659,6 +666,7 @@ int Batch::runImpl()
                                     (cfg_.k < 0 || cfg_.k > m) ? m : cfg_.k};
             }
             pairSpecsFor_ = pairUnits_;
+            ++pairSpecsVersion_;
         }
         SolveOut& so = soMain_;
         if (scanMode == EDLIB_MODE_NW) {
@@ -672,11 +680,22 @@ int Batch::runImpl()
             fusedOps_.clear();
             lap("run: pair specs");
             if (solveGlobalDistances(units, score, fuse ? &fusedOps_ : nullptr)) return 1;
+            if (alphaDeferred_) { alphaDeferred_ = false; if (alphabetLengthsBegin(false, true)) return 1; }     // (no level took every unit)
             lap("run: global distances");
+            // (alphabetLength of the same units, counted on the side stream meanwhile: set in this pass over the records
+            // instead of in one of its own -- alphabetLengthsEnd() then finds nothing pending)
+            if (alphaIsPairsVersion_ != pairSpecsVersion_) { alphaIsPairs_ = alphaUnits_ == pairUnits_; alphaIsPairsVersion_ = pairSpecsVersion_; }
+            const int* alphaOut = nullptr;
+            if (alphaPending_ && alphaIsPairs_ && !alphaOnHost_) {
+                EDLIB_AMD_HIP(hipStreamSynchronize(side_));
+                alphaPending_ = false;
+                alphaOut = reinterpret_cast<const int*>(alphaPin_.p);
+            }
             for (size_t i = 0; i < units.size(); ++i) {
                 UnitResult& r = res[pairUnits_[i]];
                 if (deferReset) blank_record(r);
                 finalize_global(r, cfg_.k, mode, units[i].tlen, score[i]);
+                if (alphaOut) r.alphabetLength = alphaOut[i];
             }
             if (fuse)
                 for (size_t i = 0; i < units.size(); ++i) {

@@ -246,7 +246,8 @@ private:
     // HW inside the static band of a threshold: diagonals [-K, (T - m) + 2 K] (queries in windows not much longer than themselves)
     int solveHwBanded(bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out);
     // alphabetLength of the empty / pair units: launched on a side stream before phase 1, collected after it
-    int alphabetLengthsBegin();
+    int alphabetLengthsBegin(bool markOnly = false, bool marked = false);     // markOnly: only note where stream_ stands; marked: launch behind that note
+    bool alphaDeferred_ = false;
     int alphabetLengthsEnd(std::vector<UnitResult>& res);
     std::vector<int> alphaUnits_; bool alphaOnHost_ = false, alphaPending_ = false; long long alphaBytes_ = 0;
     hipStream_t side_ = nullptr;
@@ -277,6 +278,21 @@ private:
     std::vector<int> pairSpecsFor_;              // the pair units pairSpecs_ was built for
     std::vector<UnitSpec> pairSpecs_, selScratch_; std::vector<size_t> whoScratch_; std::vector<int> lvlScratch_, scoreMain_;
     SolveOut soMain_, soLevel_;
+    // a ladder level that takes every unit of a big pair batch (engine_pairs.hip): compact specs resident per batch,
+    // descriptors written by a kernel, the Peq of all units built on a third stream while the divergence probe runs
+    int pairSpecsVersion_ = 0, levelSpecsVersion_ = -1, shapeVersion_ = -1, alphaIsPairsVersion_ = -1;
+    bool alphaIsPairs_ = false;
+    struct PairShape { size_t minBlocks = 0, maxBlocks = 0; int minLenLo = 0, minLenHi = 0, maxDiff = 0; } shape_;   // of pairSpecs_
+    long long levelPeqWords_ = 0;
+    bool levelAllReady_ = false;
+    PinBuf h_levelSpecs_, h_levelScore_;
+    DevBuf<LevelSpec> d_levelSpecs_;
+    DevBuf<PairDesc> d_descsAll_;
+    DevBuf<unsigned long long> d_peqAll_;
+    hipStream_t aux_ = nullptr;
+    Event evLevelIn_, evLevelPeq_;
+    int prepareLevelAll(const std::vector<UnitSpec>& units);
+    int runLevelAll(const std::vector<UnitSpec>& units, int ring, int ringH, int ringBlocks, int cap, int kcap, int nbMax);
     std::vector<OpsOut> fusedOps_;
     // ---- flat pair path (TASK_DISTANCE, every unit a pair of at most 16 blocks): descriptors built once and resident, a
     // run is Peq build + ONE ring scan + an overflow census, results stay in HBM until results() (like the reads path)

@@ -129,7 +129,7 @@ PairDesc Batch::flatDesc(int u) const
     if (flatNwStore_) {
         const int kcap = cfg_.k >= 0 ? cfg_.k : 0x3fffffff;
         // (words of 32 rows on 8-lane rings, ring32_kernels.hip: a query of up to 8 words sits whole on its ring; above, the
-        // first band level K = 128 -- the threshold the 4-lane rings of 64-row blocks hold, and well inside ring32_max_k(8) = 192)
+        // first band level K = 128 -- well inside what the 4-lane rings of 64-row blocks hold, and inside ring32_max_k(8) = 192)
         if (flatRing32_) x.kinit = std::min(kcap, (m + 31) / 32 <= flatG32_ ? std::max(m, T) : 128);
         else x.kinit = std::min(kcap, (m + 63) / 64 <= flatRing_ ? std::max(m, T) : ring_max_k(flatRing_));
     }

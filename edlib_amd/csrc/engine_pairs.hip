@@ -664,14 +664,94 @@ int Batch::solveSemiGlobalUnits(int mode, bool wantPositions, const std::vector<
     return 0;
 }
 
+// ------------------------------------------------------ a level that takes every unit
+
+// A big batch whose units all start on one ring (config 4: 100,000 x 10 kb pairs on 21-lane rings) spent 1.6 ms of a 22 ms
+// step around its scan: 0.3 ms selecting the level's units (all of them), 0.33 ms writing 100,000 descriptors, 0.35 ms
+// sending them up, 0.75 ms building Peq -- behind a divergence probe that leaves the chip idle (16 waves, 0.5 ms).  So:
+// the units' offsets and lengths stay on the device between runs (LevelSpec: input layout, like the offset arrays of
+// init()); BEFORE the probe a third stream writes plain descriptors from them and builds the Peq of every unit, and a level
+// that then takes every unit has its descriptors rewritten by a kernel (threshold, ring) and scans at once.  Units the
+// level leaves open go on to the next one the usual way.  Returns 0 with levelAllReady_ set when the Peq is on its way.
+int Batch::prepareLevelAll(const std::vector<UnitSpec>& units)
+{
+    levelAllReady_ = false;
+    const size_t n = units.size();
+    if (levelSpecsVersion_ != pairSpecsVersion_) {
+        EDLIB_AMD_HIP(h_levelSpecs_.alloc(n * sizeof(LevelSpec)));
+        LevelSpec* ls = reinterpret_cast<LevelSpec*>(h_levelSpecs_.p);
+        long long words = 0;
+        bool plain = true;
+        for (size_t i = 0; i < n; ++i) {
+            const UnitSpec& u = units[i];
+            plain = plain && u.qstep == 1 && u.tstep == 1 && u.skip == 0 && u.band == 0;
+            ls[i] = LevelSpec{u.qoff, u.toff, words, u.qlen, u.tlen};
+            words += (long long)((u.qlen + 63) / 64) * tab_.sigmaT;
+        }
+        levelPeqWords_ = plain ? words : -1;
+        levelSpecsVersion_ = pairSpecsVersion_;
+        if (!plain) return 0;
+        EDLIB_AMD_HIP(d_levelSpecs_.ensure(n));
+        EDLIB_AMD_HIP(hipMemcpyAsync(d_levelSpecs_.p, ls, n * sizeof(LevelSpec), hipMemcpyHostToDevice, stream_));
+    }
+    if (levelPeqWords_ < 0 || levelPeqWords_ * 8 > (4LL << 30)) return 0;
+    EDLIB_AMD_HIP(d_descsAll_.ensure(n));
+    EDLIB_AMD_HIP(d_peqAll_.ensure((size_t)levelPeqWords_));
+    if (!aux_) {                                                    // (lowest priority: the probe's 16 waves are dispatched first)
+        int least = 0, greatest = 0;
+        EDLIB_AMD_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        EDLIB_AMD_HIP(hipStreamCreateWithPriority(&aux_, hipStreamNonBlocking, least));
+    }
+    EDLIB_AMD_HIP(evLevelIn_.create()); EDLIB_AMD_HIP(evLevelPeq_.create());
+    EDLIB_AMD_HIP(uploadEq8());
+    EDLIB_AMD_HIP(hipEventRecord(evLevelIn_.e, stream_));           // the inputs, the specs and the equality table went up on stream_
+    EDLIB_AMD_HIP(hipStreamWaitEvent(aux_, evLevelIn_.e, 0));
+    EDLIB_AMD_HIP(launch_fill_level_descs(d_levelSpecs_.p, (int)n, 0, 0, 0, 0, d_descsAll_.p, aux_));
+    EDLIB_AMD_HIP(launch_build_peq_pairs(d_descsAll_.p, (int)n, d_qpool_.p, d_eq8_.p, d_idToByte_.p, tab_.sigmaT, d_peqAll_.p, aux_));
+    EDLIB_AMD_HIP(hipEventRecord(evLevelPeq_.e, aux_));
+    levelAllReady_ = true;
+    return 0;
+}
+
+// the scan of a level that takes every unit: scores into h_levelScore_ (pinned, units.size() ints)
+int Batch::runLevelAll(const std::vector<UnitSpec>& units, int ring, int ringH, int ringBlocks, int cap, int kcap, int nbMax)
+{
+    const size_t n = units.size();
+    Lap lap;
+    stats.path |= 2;
+    if (!d_out3_.owned) d_out3_.release();
+    if (!d_posPool_.owned) d_posPool_.release();
+    EDLIB_AMD_HIP(d_out3_.ensure(3 * n));
+    EDLIB_AMD_HIP(d_posPool_.ensure(1));
+    if (h_levelScore_.n < n * sizeof(int)) EDLIB_AMD_HIP(h_levelScore_.alloc(n * sizeof(int)));
+    d_outScore_.alias(d_out3_.p, n); d_outCount_.alias(d_out3_.p + n, n); d_outLast_.alias(d_out3_.p + 2 * n, n);
+    EDLIB_AMD_HIP(hipStreamWaitEvent(stream_, evLevelPeq_.e, 0));   // (the descriptors below replace the ones the Peq build read)
+    EDLIB_AMD_HIP(launch_fill_level_descs(d_levelSpecs_.p, (int)n, kcap, ringBlocks, cap, ring, d_descsAll_.p, stream_));
+    PairScanArgs a{};
+    a.descs = d_descsAll_.p; a.numUnits = (int)n; a.qpool = d_qpool_.p; a.tpool = d_tpool_.p;
+    a.tlut = d_tlut_.p; a.sigmaT = tab_.sigmaT; a.peq = d_peqAll_.p; a.aux = d_aux_.p;
+    a.peqRowStride = peq_row_stride(nbMax);
+    a.peqFullStride = (int)std::min<long long>((long long)a.peqRowStride * tab_.sigmaT, 1 << 20);
+    a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p; a.posPool = d_posPool_.p;
+    a.wordSteps = ringStepsCounter();
+    scanTimerStart();
+    EDLIB_AMD_HIP(launch_scan_pairs_ring(ring, EDLIB_MODE_NW, false, a, stream_, ringH));
+    scanTimerStop();
+    if (alphaDeferred_) { alphaDeferred_ = false; if (alphabetLengthsBegin(false, true)) return 1; }     // alphabetLength: next to this scan
+    EDLIB_AMD_HIP(hipMemcpyAsync(h_levelScore_.p, d_outScore_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+    lap("nw level (every unit): kernels + D2H");
+    return 0;
+}
+
 // ------------------------------------------------------ NW distance levels
 
 // The reference finds the NW distance by doubling k from 64 until the banded scan succeeds
 // (edlib.cpp:197-217); any threshold >= the distance gives the same answer, so the levels here are the
-// ring sizes of scan_pairs_ring_kernel: K = 128 on 4-lane rings (16 units per wave), 384 on 8, 896 on 16, 1216 on 21
-// (three units per wave), 1920 on half waves, 3968 on whole waves, then the unbanded strips.  A unit whose blocks
+// ring sizes of scan_pairs_ring_kernel: K = 196 on 4-lane rings (16 units per wave), 456 on 8, 976 on 16, 1301 on 21
+// (three units per wave), 2016 on half waves, 4031 on whole waves (ring_max_k), then the unbanded strips.  A unit whose blocks
 // all fit a ring is exact on it for any distance (threshold max(m, T)).  A failed level is pure waste when the whole
-// batch is divergent, so larger batches first measure the divergence of 64 strided units on their 1 kb prefixes
+// batch is divergent, so larger batches first measure the divergence of 64 strided units on their 512-base prefixes
 // (one small launch) and every unit starts at the level that holds its extrapolated distance.  The estimate only picks the starting level; results never depend on it.
 int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<int>& score, std::vector<OpsOut>* paths)
 {
@@ -695,14 +775,33 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
     auto blocks = [&](size_t i) { return (units[i].qlen + 63) / 64; };
 
     double rate = 0.0;                                                  // edits per base, median of the sample
-    size_t maxBlocks = 0;
-    for (size_t i = 0; i < n; ++i) maxBlocks = std::max<size_t>(maxBlocks, (size_t)blocks(i));
+    // the shape of the batch (its extremes): a property of the inputs like the specs themselves, kept with them
+    PairShape shapeNow;
+    PairShape& shape = &units == &pairSpecs_ ? shape_ : shapeNow;
+    if (&units != &pairSpecs_ || shapeVersion_ != pairSpecsVersion_) {
+        shape = PairShape{};
+        shape.minBlocks = (size_t)1 << 40; shape.minLenLo = 0x7fffffff;
+        for (size_t i = 0; i < n; ++i) {
+            const size_t nbI = (size_t)blocks(i);
+            const int lo = std::min(units[i].qlen, units[i].tlen);
+            shape.minBlocks = std::min(shape.minBlocks, nbI); shape.maxBlocks = std::max(shape.maxBlocks, nbI);
+            shape.minLenLo = std::min(shape.minLenLo, lo); shape.minLenHi = std::max(shape.minLenHi, lo);
+            shape.maxDiff = std::max(shape.maxDiff, std::abs(units[i].qlen - units[i].tlen));
+        }
+        if (&units == &pairSpecs_) shapeVersion_ = pairSpecsVersion_;
+    }
+    const size_t maxBlocks = shape.maxBlocks;
     // (units of at most 16 blocks climb cheap levels -- the 16-lane ring holds them whole -- and skip the probe)
+    levelAllReady_ = false;
     if (n >= 256 && maxBlocks > 16 && !bandOff && !getenv("EDLIB_AMD_NOPROBE")) {
-        // 64 strided units, the first 1 kb of the query against the first 1 kb + 128 of the target in PREFIX mode
+        // (a big batch: the Peq of every unit is built next to the probe -- prepareLevelAll)
+        if (paths == nullptr && n >= 8192 && &units == &pairSpecs_ && prepareLevelAll(units)) return 1;
+        // 64 strided units, the first 512 bases of the query against the first 512 + 128 of the target in PREFIX mode
         // (the best end column is free: a global alignment of two equally cut prefixes would add the indel drift at
-        // the cut to the count, about one edit in a hundred bases at ONT-like rates)
-        const int np = 64, cut = 1024;
+        // the cut to the count, about one edit in a hundred bases at ONT-like rates).  16 waves of ~650 dependent steps:
+        // the median of 64 counts of ~60 edits is good to 2 %, and the estimate only picks the first level (1 kb prefixes,
+        // rounds 2-4, took twice as long for 1.4 %).
+        const int np = 64, cut = 512;
         std::vector<UnitSpec> probe(np);
         for (int i = 0; i < np; ++i) {
             UnitSpec u = units[(size_t)((long long)i * n / np)];
@@ -721,7 +820,7 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
     // of a unit of length L at rate r scatters like a sum of L Bernoulli trials (sigma = sqrt(r L)).  A ring of G
     // lanes costs G / 64 of a wave per unit, so trying the smaller ring first pays as long as fewer than a quarter
     // to a half of the units fail on it and move up: the estimate is the mean plus half a sigma (10 kb pairs at
-    // 11.4 % sit under the 21-lane ring's 1216 -- three units per wave instead of two -- and the 7 % above it rerun).
+    // 11.4 % sit under the 21-lane ring's 1301 -- three units per wave instead of two).
     // (est = mean + sqrt(mean) / 2 + 8 <= cap is a bound on the mean: solved once per level, so that a unit costs a
     // multiply-add and a few compares -- the square root per unit was 2 ms of host time per 100,000 units)
     // A handful of LONG units (the reference's 1 Mb Chromosome pairs, test_data/perf_tests.sh:180-191): a level costs its
@@ -765,9 +864,14 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
             for (size_t q = 0; q < probe.size(); ++q) unitRate[who[q]] = (double)std::max(so.score[q], 0) / cut;
         }
     }
+    // (the length difference of a pair is part of its edits -- 10 kb at 4 % insertions and 4 % deletions differ by 28 bases
+    // sigma -- and already inside the rate; only what exceeds three sigma of such a drift counts as a tail to add: rounds 2-4
+    // added all of it, which sent the 7 % of config 4's pairs with the largest drift past the ring that holds them)
     auto mean_of = [&](size_t i) {
         const UnitSpec& u = units[i];
-        return (unitRate.empty() ? rate : unitRate[i]) * std::min(u.qlen, u.tlen) + std::abs(u.qlen - u.tlen);
+        const double base = (unitRate.empty() ? rate : unitRate[i]) * std::min(u.qlen, u.tlen);
+        const double diff = std::abs(u.qlen - u.tlen);
+        return diff * diff <= 9.0 * base ? base : base + diff - 3.0 * std::sqrt(base);        // (no square root in the usual case)
     };
     double meanCap[kNumRings + 1];
     auto mean_cap = [](double cap) { if (cap < 8) return -1.0; const double r = (-0.5 + std::sqrt(0.25 + 4.0 * (cap - 8.0))) / 2.0; return r * r; };
@@ -789,9 +893,27 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
     lvl.resize(n);
     // A few units do not fill the chip at any ring size: a level then costs its ~T dependent steps on one wave
     // whether it succeeds or not (a 10 kb pair: 1.7 ms per level), so units with more blocks than a ring holds
-    // go straight to whole-wave rings (K = 3968) instead of climbing.
+    // go straight to whole-wave rings (K = 4031) instead of climbing.
     const bool fewUnits = n <= 512 && rate == 0.0;
     std::vector<size_t> atLevel(nl + 2, 0);
+    // A batch whose shortest and longest unit start on the same ring level (config 4: 100,000 pairs of 10 kb +- 1 %): the
+    // level of a unit is monotone in its estimate, and no unit is small enough to sit whole on a smaller ring -- one
+    // evaluation at each extreme instead of 100,000 (0.4 ms).
+    int uniformLevel = -1;
+    if (!bandOff && !fewUnits && rate > 0.0 && unitRate.empty() && direct.empty()) {
+        auto by_mean = [&](double mean) {
+            for (int l = 0; l < nl; ++l) if (mean <= meanCap[l] || l >= levelOfKcap) return l;
+            return nl;
+        };
+        const double lo = rate * shape.minLenLo, base = rate * shape.minLenHi;
+        const double hi = (double)shape.maxDiff * shape.maxDiff <= 9.0 * lo ? base : base + shape.maxDiff;
+        const int L = by_mean(lo);
+        if (L < nl && by_mean(hi) == L && (L == 0 || shape.minBlocks > (size_t)blocks_of(L - 1))) uniformLevel = L;
+    }
+    if (uniformLevel >= 0) {
+        std::fill(lvl.begin(), lvl.end(), uniformLevel);
+        atLevel[uniformLevel] = n;
+    } else
     {
         int lastQ = -1, lastT = -1, lastL = 0;                           // batches of equal shapes: one evaluation
         for (size_t i = 0; i < n; ++i) {
@@ -833,9 +955,25 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
             lap("nw level: ring32");
         }
     }
+    if (levelAllReady_) EDLIB_AMD_HIP(hipStreamWaitEvent(stream_, evLevelPeq_.e, 0));      // whatever follows: the side work is over before stream_'s next synchronisation
     for (int l = 0; l <= nl; ++l) {
         if (atLevel[l] == 0) continue;
         if (l == nl && wideLevel) break;
+        if (levelAllReady_ && l < nl && atLevel[l] == n) {                // ---- the level takes every unit
+            if (runLevelAll(units, ringOf[l], ringH[l], blocks_of(l), cap_of(l), kcap, (int)maxBlocks)) return 1;
+            const int* got = reinterpret_cast<const int*>(h_levelScore_.p);
+            atLevel[l] = 0;
+            const int capL = std::min(kcap, cap_of(l));
+            const bool banded = shape.minBlocks > (size_t)blocks_of(l);           // every unit inside the ring's band limit: one threshold
+            for (size_t i = 0; i < n; ++i) {
+                const int kin = banded ? capL : std::min(kcap, blocks(i) <= blocks_of(l) ? std::max(units[i].qlen, units[i].tlen) : cap_of(l));
+                if (got[i] <= kin) score[i] = got[i];                             // exact
+                else if (kin >= kcap) score[i] = kInf;                             // > k: final
+                else { lvl[i] = l + 1; ++atLevel[l + 1]; }                         // next level
+            }
+            lap("nw level (every unit): scores");
+            continue;
+        }
         std::vector<UnitSpec>& sel = selScratch_; std::vector<size_t>& who = whoScratch_;
         sel.clear(); who.clear();
         sel.reserve(atLevel[l]); who.reserve(atLevel[l]);

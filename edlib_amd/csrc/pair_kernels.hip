@@ -144,6 +144,32 @@ hipError_t launch_build_peq_pairs(const PairDesc* descs, int numUnits, const uin
     return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(256)
+fill_level_descs_kernel(const LevelSpec* __restrict__ specs, int numUnits, int kcap, int ringBlocks, int cap, int ring,
+                        PairDesc* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= numUnits) return;
+    const LevelSpec v = specs[i];
+    PairDesc d;
+    d.qoff = v.qoff; d.toff = v.toff; d.peqOff = v.peqOff; d.storeOff = 0; d.auxOff = 0;
+    d.qlen = v.qlen; d.tlen = v.tlen; d.qstep = 1; d.tstep = 1;
+    const int whole = v.qlen > v.tlen ? v.qlen : v.tlen;
+    const int k = num_blocks(v.qlen) <= ringBlocks ? whole : cap;
+    d.kinit = k < kcap ? k : kcap;
+    d.posCap = 0; d.posOff = 0; d.colOff = -1; d.bandT = 0; d.skip = 0; d.ring = ring;
+    out[i] = d;
+}
+
+hipError_t launch_fill_level_descs(const LevelSpec* specs, int numUnits, int kcap, int ringBlocks, int cap, int ring,
+                                   PairDesc* out, hipStream_t stream)
+{
+    if (numUnits == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_level_descs_kernel, dim3((numUnits + 255) / 256), dim3(256), 0, stream,
+                       specs, numUnits, kcap, ringBlocks, cap, ring, out);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------- the scan
 
 // MODE 0 NW, 1 SHW, 2 HW.  STORE: keep the column store.  LDSPEQ: Peq slice in LDS
@@ -290,8 +316,10 @@ hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStr
 // NW inside Ukkonen's diagonal band for a fixed threshold K = desc.kinit (what the reference's
 // first/lastBlock bookkeeping converges to, edlib.cpp:744-830): a path of cost <= K only visits
 // diagonals d = j - i in [dmin, dmax] = [min(0,D) - p, max(0,D) + p], D = T - m, p = (K - |D|) / 2.
-// Block b therefore lives for columns [64b + dmin, 64b + 63 + dmax], and fewer than G consecutive
-// blocks are alive at a time when K <= ring_max_k(G).  A RING of G lanes (G = 4, 8, 16, 21, 32 or 64)
+// Block b therefore lives for columns [64b + dmin, 64b + 63 + dmax] -- steps [65b + dmin, 65b + 63 + dmax] of the
+// anti-diagonal schedule below -- and at most G consecutive blocks are at work in a step when K <= ring_max_k(G) =
+// 65 G - 64 (rounds 1-4 kept one lane idle between the bottom and the top of the band: 64 (G - 2); now a block stops
+// listening to the lane above when the block above leaves the band).  A RING of G lanes (G = 4, 8, 16, 21, 32 or 64)
 // therefore covers a query of any length, and a wave carries 64 / G independent units:
 //   * blocks are mapped to the ring's lanes round-robin (block b -> ring lane b % G).  When a lane's
 //     block leaves the band it re-arms for block b + G: state "+1 per row" below the upstream block's
@@ -366,6 +394,9 @@ __global__ void __launch_bounds__(64)
 scan_pairs_ring_kernel(const PairScanArgs a)
 {
     static_assert(H == 1 || !STORE, "the column store is laid out per 64-row block");
+    // A ring scan is a chain of dependent steps: next to a bandwidth kernel on another stream (the alphabet count, the Peq
+    // build of the whole batch beside the 16-wave divergence probe) its waves issue first.
+    __builtin_amdgcn_s_setprio(2);
     extern __shared__ __attribute__((aligned(16))) u64 s_dyn[];      // Peq words, then the target rings
     constexpr int U = 64 / G;                                         // units per wave (lanes past U * G idle)
     constexpr int RH = 64 * H;                                        // rows per ring lane
@@ -514,6 +545,15 @@ scan_pairs_ring_kernel(const PairScanArgs a)
     auto events = [&](const int t, const int x, u64 (&eqCur)[H], int& offCur) {
         if constexpr (!STORE) fold();
         const int upScore = ring_ror<G>(bscore, srcAddr);             // upstream's bottom score after step t - 1
+        // ---- the block above has sent its last carry (taken in step t - 1): from here on block b is the top of the band
+        // and takes +1 whatever arrives -- the lane above may already hold its next tenant, block b - 1 + G, when the
+        // band fills the ring (K up to ring_max_k(G) = 65 G - 64; with the lane above kept idle instead it was 64 (G - 2))
+        // (the block above is last updated at column RH b - 1 + dmax, unless the target ends first; its carry of that step
+        // is taken at step (RH + 1) b + dmax - 1)
+        if (ev == 0 && actm && xmask != 0u && b > 0 && t == (RH + 1) * b + dmax && RH * b + dmax < T) {
+            xmask = 0u; xfix = 1u;
+            ev = last_col(b) + b + 1 - t;
+        }
         if (ev == 0 && actm) {                                        // ---- closing block b
             const int colLast = t - 1 - b;
             if (colLast == T - 1) {                                   // it was alive at the stop column
@@ -568,6 +608,11 @@ scan_pairs_ring_kernel(const PairScanArgs a)
             c2 = 2u * (u32)(col + 2);
             actm = ~0u;
             ev = span + 1;                                            // closes at the top of the step after its last
+            if (b > 0 && RH * b + dmax < T) {                         // ... unless the block above leaves the band first
+                const int w = (RH + 1) * b + dmax - t;
+                if (w > 0) ev = w;
+                else { xmask = 0u; xfix = 1u; }                       // (a band of one diagonal: it already has)
+            }
         }
     };
 

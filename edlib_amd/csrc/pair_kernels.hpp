@@ -32,6 +32,16 @@ struct PairDesc {
                          // size G of scan_pairs_ring_kernel (band of threshold kinit)
 };
 
+// A pair batch's units as the device keeps them between runs: offsets and lengths of the resident inputs and the unit's slot
+// in a Peq pool that holds every unit.  A level of the NW threshold ladder that takes EVERY unit of a big batch (config 4:
+// 100,000 pairs on 21-lane rings) has its descriptors written from these by a kernel -- no host loop over the units, no
+// 9 MB upload -- and finds its Peq built while the divergence probe ran (Batch::prepareLevelAll / runLevelAll).
+struct LevelSpec { long long qoff, toff, peqOff; int qlen, tlen; };
+// descriptors of forward NW distance units on `ring`-lane rings: kinit = min(kcap, the whole matrix when the unit's blocks
+// all sit on the ring (numBlocks <= ringBlocks), else cap)
+hipError_t launch_fill_level_descs(const LevelSpec* specs, int numUnits, int kcap, int ringBlocks, int cap, int ring,
+                                   PairDesc* out, hipStream_t stream);
+
 // One block-step of the column store: what the traceback needs to know about the 64 cells of block b in column c, as two
 // bit planes (bit r = row 64 b + r).  The reference keeps Pv, Mv and the block score per column (AlignmentData,
 // edlib.cpp:22-47: 20 bytes) and re-derives the neighbours' values cell by cell (edlib.cpp:942-1141); the walk only ever
@@ -88,7 +98,11 @@ hipError_t launch_scan_pairs(int mode, bool store, const PairScanArgs& a, hipStr
 // kinit); a wave carries 64 / G units, whatever the query length (no strips).  Writes outScore and, when
 // colP is set, the (P, M, score) of the blocks alive at the last processed column (the caller pre-fills
 // the dump with "invalid").  store: also the column store in ring layout (ring_store_entries per unit).
-constexpr int ring_max_k(int G, int H = 1) { return 64 * H * (G - 2); }      // H: 64-row blocks per ring lane (1, 2 or 4)
+// Block b (64 H rows) is updated at steps [(64 H + 1) b + dmin, (64 H + 1) b + 64 H - 1 + dmax]: the next tenant of its lane,
+// block b + G, starts (64 H + 1) G steps later, so a band of dmax - dmin <= (64 H + 1) G - 64 H diagonals keeps the tenants
+// of a lane apart (tests/ring_model.py: ring_fits, ring_lanes_nw).  A whole-wave ring (G = 64) keeps one lane idle: with
+// 64 blocks alive the 256-column target ring of the kernel would be refilled over the column its oldest block starts on.
+constexpr int ring_max_k(int G, int H = 1) { return (64 * H + 1) * (G == 64 ? G - 1 : G) - 64 * H; }   // H: 64-row blocks per ring lane (1, 2 or 4)
 constexpr int kNumRings = 6;           // ring sizes 4, 8, 16, 21, 32, 64 (units per wave: 16, 8, 4, 3, 2, 1)
 constexpr int kMaxBandK = ring_max_k(64);
 // mode 1 (SHW) / 2 (HW): packed rings only (ringLanes 4, 8 or 16); every unit has numBlocks <= ringLanes (no band, kinit is

@@ -3,7 +3,7 @@
 //
 // Replaces, for long units, myersCalcEditDistanceNW with a fixed k (reference edlib.cpp:730-928; the band is Ukkonen's,
 // what the first/lastBlock bookkeeping of :744-830 converges to) and the column loop of myersCalcEditDistanceSemiGlobal
-// (:550-704).  The lane rings of pair_kernels.hip hold bands up to K = 3968 on one wave; above that scan_pairs_kernel
+// (:550-704).  The lane rings of pair_kernels.hip hold bands up to K = 4031 on one wave; above that scan_pairs_kernel
 // walked every block of every column with ONE wave, strip after strip (round 3: tens of seconds for the reference's
 // 1 Mb x 1 Mb Chromosome pairs, test_data/perf_tests.sh:180-191).  Here:
 //

@@ -21,7 +21,12 @@ M64 = (1 << 64) - 1
 
 
 def ring_max_k(G, RH=64):
-    return RH * (G - 2)
+    """scan_pairs_ring_kernel (RH = 64 H): tenants of a lane (RH + 1) G steps apart, a block's life RH + dmax - dmin steps
+    (pair_kernels.hpp: ring_max_k; the whole-wave ring keeps a lane idle for its target ring's sake).  The rings of 32-row
+    words (ring32_kernels.hip) keep the lane above a block idle until it closes: 32 (G - 2)."""
+    if RH == 32:
+        return RH * (G - 2)
+    return (RH + 1) * (G - 1 if G == 64 else G) - RH
 
 
 def band(m, T, K):
@@ -121,3 +126,112 @@ def banded_nw(q, t, K, RH=64, geom=None):
     sh = (m - 1) & (RH - 1)
     below = 0 if sh == RH - 1 else (M64 << (sh + 1)) & M64
     return bscore[last] - popc(P[last] & below) + popc(Mv[last] & below)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The same scan LANE BY LANE: G ring lanes, block b on lane b % G at steps col + b, carries that travel one lane per
+# step.  This restates what keeps the branch-light step of scan_pairs_ring_kernel correct, which the column-wise model
+# above takes for granted:
+#   * a lane outside its block's life SENDS +1 (and counts its score up by one per step);
+#   * a block LISTENS to the lane above only while the block above is alive: from the step after it has taken that
+#     block's last carry it takes +1 whatever arrives (`upstream_rule`) -- round 5.  Without the rule the lane above
+#     has to stay idle until the block closes, which costs a ring lane: K <= 64 (G - 2) instead of 65 G - 64.
+# Returns the score as the kernel decodes it (K + 1 when the last block is not alive at the stop column).
+
+def ring_lanes_nw(q, t, K, G, RH=64, upstream_rule=True):
+    m, T = len(q), len(t)
+    if K < abs(T - m):
+        return None
+    W = (1 << RH) - 1
+    nb = (m + RH - 1) // RH
+    peq = {}
+    for s in set(t):
+        v = 0
+        for i, ch in enumerate(q):
+            if ch == s:
+                v |= 1 << i
+        peq[s] = [(v >> (RH * b)) & W for b in range(nb)]
+    zero = [0] * nb
+    dmin, dmax = band(m, T, K)
+    first_col = lambda b: max(0, RH * b + dmin)
+    last_col = lambda b: min(T - 1, RH * b + RH - 1 + dmax)
+    NEVER = 1 << 60
+
+    class Lane:
+        pass
+    lanes = []
+    for rl in range(G):
+        L = Lane()
+        L.b, L.act, L.listen, L.P, L.M, L.bscore, L.carry, L.span = rl, False, True, W, 0, 0, 1, 0
+        lanes.append(L)
+
+    def arm(L, step):
+        ok = L.b < nb and first_col(L.b) <= last_col(L.b)
+        ts = first_col(L.b) + L.b if ok else NEVER
+        L.span = last_col(L.b) + L.b - ts if ok else 0
+        L.ev = ts - step if ok else NEVER
+    for L in lanes:
+        arm(L, 0)
+    result = K + 1
+    for step in range(T + nb + 1):
+        x = [lanes[(rl - 1) % G].carry for rl in range(G)]
+        up = [lanes[(rl - 1) % G].bscore for rl in range(G)]
+        for rl, L in enumerate(lanes):
+            if L.ev == 0 and L.act:
+                te, tl = last_col(L.b - 1) + L.b + 1 if L.b > 0 else NEVER, last_col(L.b) + L.b
+                if upstream_rule and L.listen and L.b > 0 and step == te and te <= tl:
+                    L.listen = False                                   # the block above has sent its last carry
+                    L.ev = tl + 1 - step
+                else:                                                  # closing
+                    if step - 1 - L.b == T - 1 and L.b == nb - 1:
+                        sh = (m - 1) & (RH - 1)
+                        below = 0 if sh == RH - 1 else (W << (sh + 1)) & W
+                        result = L.bscore - popc(L.P & below) + popc(L.M & below)
+                    L.act = False
+                    L.b += G
+                    L.listen = True
+                    arm(L, step)
+            if L.ev == 0 and not L.act:                                # the block starts with this step
+                col = step - L.b
+                L.P, L.M = W, 0
+                above = RH * L.b if col == 0 else up[rl] - x[rl]
+                L.bscore = above + RH
+                L.act = True
+                te, tl = last_col(L.b - 1) + L.b + 1 if L.b > 0 else NEVER, last_col(L.b) + L.b
+                L.ev = L.span + 1
+                if upstream_rule and L.b > 0 and te <= tl:
+                    if te > step:
+                        L.ev = te - step
+                    else:                                              # (a band of one diagonal: it already has)
+                        L.listen = False
+        new_carry = []
+        for rl, L in enumerate(lanes):
+            L.ev -= 1
+            if not L.act:
+                new_carry.append(1)
+                L.bscore += 1
+                continue
+            col = step - L.b
+            hin = 1 if (L.b == 0 or not L.listen) else x[rl]
+            eq = peq.get(t[col], zero)[L.b] if 0 <= col < T else 0
+            pv, mv = L.P, L.M
+            hneg = 1 if hin < 0 else 0
+            xv = eq | mv
+            eq2 = eq | hneg
+            xh = ((((eq2 & pv) + pv) & W) ^ pv) | eq2
+            ph = mv | (~(xh | pv) & W)
+            mh = pv & xh
+            hout = ((ph >> (RH - 1)) & 1) - ((mh >> (RH - 1)) & 1)
+            ph = (ph << 1) & W
+            mh = (mh << 1) & W
+            if hin < 0:
+                mh |= 1
+            elif hin > 0:
+                ph |= 1
+            L.P = (mh | ~(xv | ph)) & W
+            L.M = ph & xv
+            L.bscore += hout
+            new_carry.append(hout)
+        for L, c in zip(lanes, new_carry):
+            L.carry = c
+    return result

@@ -66,7 +66,7 @@ def test_distances_at_level_thresholds(engine, ref, oracle):
             q, t = _pair_with_edits(rng, n, edits, indel_frac=0.2)
             qs.append(q); ts.append(t)
     _check(engine, impl, qs, ts, "NW", "distance", -1, "thresholds")
-    for k in (127, 128, 129, 896, 1920, 3968, 5000):
+    for k in (127, 128, 129, 196, 896, 976, 1920, 2016, 3968, 4031, 5000):      # (round 5's ring limits: 196, 976, 2016, 4031)
         _check(engine, impl, qs[:28], ts[:28], "NW", "distance", k, "thresholds fixed k")
 
 
@@ -261,7 +261,7 @@ def test_round2_ring_sizes_8_and_21(engine, ref, oracle):
             q, t = _pair_with_edits(rng, n, edits, indel_frac=0.2)
             qs.append(q); ts.append(t)
     _check(engine, impl, qs, ts, "NW", "distance", -1, "8 / 21 thresholds")
-    for k in (383, 384, 385, 1215, 1216, 1217):
+    for k in (383, 384, 385, 456, 457, 1215, 1216, 1217, 1301, 1302):
         _check(engine, impl, qs, ts, "NW", "distance", k, "8 / 21 thresholds fixed k")
     # block counts at the ring sizes, similar / divergent / unrelated
     qs, ts = [], []
@@ -316,3 +316,110 @@ def test_big_batch_of_like_pairs(engine, checker):
     for i in range(0, 20000, 67):
         want = checker.align(qs[i].tobytes(), ts[i].tobytes(), "NW", "distance", -1)
         assert got["editDistance"][i] == want["editDistance"] and got["alphabetLength"][i] == want["alphabetLength"], i
+
+
+# ---------------------------------------------------------------- bands that fill the ring (round 5: ring_max_k = 65 G - 64)
+
+RING_CAPS = {4: 196, 8: 456, 16: 976, 21: 1301, 32: 2016, 64: 4031}      # pair_kernels.hpp: ring_max_k
+
+
+def _edge_pair(rng, p, core_len, nsub, upper, junk=(b"T", b"G")):
+    """the cheapest alignment runs p diagonals off the main one for the whole core (p symbols nothing matches on one end
+    of the target, p on the other end of the query): distance 2 p + nsub, ON the edge of the band of threshold 2 p --
+    the upper edge is where a block of the ring has the band's bottom block on the lane above it"""
+    core = synth.random_dna(rng.randrange(1 << 30), core_len).tobytes()
+    c2 = bytearray(core)
+    for i in rng.sample(range(core_len), nsub):
+        c2[i] = ord("A") if c2[i] != ord("A") else ord("C")
+    a, b = junk[0] * p + core, bytes(c2) + junk[1] * p
+    return (b, a) if upper else (a, b)                       # (query, target)
+
+
+@pytest.mark.parametrize("G", [4, 8, 16, 21, 32, 64])
+def test_bands_that_fill_the_ring(engine, checker, G):
+    """Fixed k = ring_max_k(G) (the band of that threshold puts a block on EVERY lane of the ring; rounds 1-4 kept one lane
+    idle) on pairs whose cheapest path runs along the edge of exactly that band, at distances k - 1 .. k + 3: every unit
+    against the reference, then the same batch with k = -1 (the levels climb through the rings), and one ring below /
+    above.  More than 512 units, so that the batch takes the levels (a handful goes straight to whole-wave rings)."""
+    rng = random.Random(5100 + G + SEED_SHIFT)
+    cap = RING_CAPS[G]
+    qs, ts = [], []
+    for i in range(540):
+        p = cap // 2 - (1 if i % 9 == 8 else 0)
+        q, t = _edge_pair(rng, p, max(64 * G + 300, 1100) + rng.randrange(0, 130), (0, 1, 1, 2, 3)[i % 5], upper=i % 4 != 3)
+        qs.append(q); ts.append(t)
+    for k in (cap, cap - 1, cap + 1, -1):
+        got = engine.align_pairs(qs, ts, mode="NW", task="distance", k=k, raw=True)
+        bad = []
+        for i in range(0, 540, 1 if k == cap else 5):
+            want = checker.align(qs[i], ts[i], "NW", "distance", k)
+            if any(got[i][f] != want[f] for f in FIELDS):
+                bad.append((i, got[i]["editDistance"], want["editDistance"]))
+        assert not bad, (G, k, bad[:5])
+
+
+@pytest.mark.parametrize("G", [4, 8, 16])
+def test_paths_inside_bands_that_fill_the_ring(engine, checker, G):
+    """the storing scan of a PATH runs inside the band of the unit's own distance (edlib.cpp:1196-1199): pairs whose
+    distance is ring_max_k(G) or just below land on G-lane rings with every lane at work, and the walk reads their store"""
+    rng = random.Random(5200 + G + SEED_SHIFT)
+    cap = RING_CAPS[G]
+    qs, ts = [], []
+    for i in range(24):
+        q, t = _edge_pair(rng, cap // 2 - i % 3, 1100 + rng.randrange(0, 200), 0 if i % 2 else 1, upper=i % 4 != 3)
+        qs.append(q); ts.append(t)
+    _check(engine, checker, qs, ts, "NW", "path", -1, "paths at the ring's limit")
+    _check(engine, checker, qs, ts, "NW", "path", cap, "paths at the ring's limit, fixed k")
+
+
+@pytest.mark.parametrize("G", [4, 8, 16])
+def test_prefix_bands_that_fill_the_ring(engine, checker, G):
+    """SHW inside the static band [-K, K] of a fixed k (2 K + 1 diagonals, solveSemiGlobalUnits): K = ring_max_k(G) / 2 fills
+    the ring; the cheapest prefix alignment skips K target symbols first and stays on the band's upper edge"""
+    rng = random.Random(5300 + G + SEED_SHIFT)
+    K = RING_CAPS[G] // 2
+    qs, ts = [], []
+    for i in range(300):
+        core = synth.random_dna(rng.randrange(1 << 30), max(64 * G + 200, 1100)).tobytes()
+        c2 = bytearray(core)
+        for j in rng.sample(range(len(core)), i % 3):
+            c2[j] = ord("A") if c2[j] != ord("A") else ord("C")
+        skip = K - (i % 7 == 6)
+        qs.append(bytes(c2)); ts.append(b"T" * skip + core + synth.random_dna(rng.randrange(1 << 30), rng.randrange(0, 40)).tobytes())
+    for k in (K, K + 1):
+        got = engine.align_pairs(qs, ts, mode="SHW", task="locations", k=k, raw=True)
+        bad = []
+        for i in range(0, 300, 2):
+            want = checker.align(qs[i], ts[i], "SHW", "locations", k)
+            if any(got[i][f] != want[f] for f in FIELDS):
+                bad.append((i, got[i]["editDistance"], want["editDistance"]))
+        assert not bad, (G, k, bad[:5])
+
+
+def test_level_that_takes_every_unit_and_its_tail(engine, checker):
+    """9,000 NW pairs of ~1,200 bases, most at 3 % divergence, every 40th at 30 %: the batch takes the divergence probe, its
+    first ring level takes EVERY unit (descriptors written on the device, the Peq of all units built next to the probe:
+    Batch::prepareLevelAll / runLevelAll), the divergent ones climb on.  Also with a fixed k below the tail, and a second
+    run of the same batch (the resident specs are reused)."""
+    rng = random.Random(5400 + SEED_SHIFT)
+    qs, ts = [], []
+    for i in range(9000):
+        t = synth.random_dna(rng.randrange(1 << 30), 1150 + rng.randrange(0, 120))
+        rate = 0.1 if i % 40 == 7 else 0.01
+        q, _ = synth.mutate(t, rng.randrange(1 << 30), rate, rate, rate)
+        qs.append(q.tobytes()); ts.append(t.tobytes())
+    for k in (-1, 150):
+        b = engine.PairBatch(qs, ts, mode="NW", task="distance", k=k)
+        try:
+            b.run()
+            first = b.results_flat()["editDistance"].copy()
+            b.run()
+            got = b.results_flat()
+        finally:
+            b.close()
+        assert np.array_equal(first, got["editDistance"])
+        for i in list(range(0, 9000, 61)) + list(range(7, 9000, 40))[:60]:
+            want = checker.align(qs[i], ts[i], "NW", "distance", k)
+            assert got["editDistance"][i] == want["editDistance"] and got["alphabetLength"][i] == want["alphabetLength"], (k, i)
+        if k == -1:
+            assert sum(1 for i in range(7, 9000, 40) if got["editDistance"][i] > 196) > 100      # the tail did leave the first level

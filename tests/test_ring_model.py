@@ -6,7 +6,7 @@ import random
 
 import pytest
 
-from ring_model import band, banded_nw, lives, ring_fits, ring_max_k
+from ring_model import band, banded_nw, lives, ring_fits, ring_lanes_nw, ring_max_k
 
 ACGT = b"ACGT"
 
@@ -33,12 +33,13 @@ def test_ring_max_k_keeps_tenants_apart(G):
         m = rng.randrange(1, 64 * 3 * G)
         T = max(1, m + rng.randrange(-min(K, m - 1), K + 1))
         assert ring_fits(m, T, K, G), (m, T, K, G)
-        # and never more than G blocks alive in one column
-        lv = [x for x in lives(m, T, K) if x]
-        for j in (0, T // 3, T // 2, T - 1):
-            assert sum(1 for f, l in lv if f <= j <= l) <= G
-    # the bound is not vacuous: far above it the tenants of a lane do collide
-    assert not ring_fits(64 * 4 * G, 64 * 4 * G, 66 * G, G)
+        # and never more than G blocks at work in one STEP (block b updates column step - b)
+        lv = lives(m, T, K)
+        for step in (0, T // 3, T // 2, T - 1, T + len(lv) // 2):
+            assert sum(1 for b, x in enumerate(lv) if x and x[0] <= step - b <= x[1]) <= G
+    # the bound is tight: one diagonal more and the tenants of a lane collide (the whole-wave ring gives a lane away)
+    assert not ring_fits(64 * 4 * G, 64 * 4 * G, 65 * G - 62, G)
+    assert ring_fits(64 * 4 * G, 64 * 4 * G, 65 * G - 64, G)
 
 
 def test_band_formula():
@@ -79,6 +80,74 @@ def test_config4_shape_on_the_21_lane_ring(oracle):
     assert banded_nw(q, t, ring_max_k(21)) == d
     assert banded_nw(q, t, d - 1) > d - 1
     assert ring_fits(len(q), len(t), ring_max_k(21), 21)
+
+
+def _edge_hugging_pair(rng, p, core_len, nsub, upper):
+    """the cheapest alignment runs `p` diagonals off the main one for the whole core: p symbols the other sequence cannot
+    match on one end, p on the other -- distance 2 p + nsub, on the edge of the band of threshold 2 p"""
+    core = bytes(rng.choice(ACGT) for _ in range(core_len))
+    c2 = bytearray(core)
+    for i in rng.sample(range(core_len), nsub):
+        c2[i] = ord("A") if c2[i] != ord("A") else ord("C")
+    a, b = b"T" * p + core, bytes(c2) + b"G" * p
+    return (b, a) if upper else (a, b)                       # (query, target)
+
+
+@pytest.mark.parametrize("G", [4, 8])
+def test_lane_by_lane_ring_is_exact_with_the_band_filling_the_ring(oracle, G):
+    """ring_lanes_nw restates the ring kernel's schedule lane by lane.  At K = ring_max_k(G) = 65 G - 64 every lane of the
+    ring can be at work in one step: the block at the top of the band then has the band's BOTTOM block on the lane above
+    it, and only stays exact because it stops listening once the block above has left the band.  Pairs whose cheapest path
+    runs along the band's upper edge at distance K + 1 tell the difference: without the rule a substitution on the edge is
+    forgiven and the scan reports K."""
+    rng = random.Random(G)
+    K = ring_max_k(G)
+    assert K == 65 * G - 64
+    wrong_without = 0
+    for it in range(36):
+        q, t = _edge_hugging_pair(rng, K // 2, 64 * G + 300, 1 if it % 3 else it % 4, upper=it % 6 != 5)
+        d = oracle.align(q, t, "NW", "distance", -1)["editDistance"]
+        got = ring_lanes_nw(q, t, K, G)
+        assert (got == d) if d <= K else (got > K), (G, it, d, got)
+        assert got == banded_nw(q, t, K)                              # lane by lane == column by column
+        loose = ring_lanes_nw(q, t, K, G, upstream_rule=False)
+        wrong_without += not ((loose == d) if d <= K else (loose > K))
+        # one lane kept idle (the rule of rounds 1-4) needs no listening rule
+        K0 = 64 * (G - 2)
+        got0 = ring_lanes_nw(q, t, K0, G, upstream_rule=False)
+        assert (got0 == d) if d <= K0 else (got0 > K0)
+    assert wrong_without > 0
+
+
+def test_lane_by_lane_ring_with_bands_of_a_few_diagonals():
+    """K = 0, 1, 2: the block above leaves the band in the very step a block starts, or right after"""
+    rng = random.Random(902)
+    for G in (4, 8):
+        for n in (64, 65, 200, 700):
+            t = bytes(rng.choice(ACGT) for _ in range(n))
+            for K in (0, 1, 2, 3):
+                assert ring_lanes_nw(t, t, K, G) == 0
+                q = bytearray(t); q[n // 2] = ord("A") if q[n // 2] != ord("A") else ord("C")
+                got = ring_lanes_nw(bytes(q), t, K, G)
+                assert got == 1 if K >= 1 else got > K
+                if n > 70:
+                    q2 = bytes(q[:n // 3] + q[n // 3 + 1:])              # one deletion as well: distance 2, one row short
+                    got = ring_lanes_nw(q2, t, K, G)
+                    assert (got == 2 if K >= 2 else (got is None or got > K)), (G, n, K, got)
+
+
+def test_lane_by_lane_ring_on_random_pairs(oracle):
+    rng = random.Random(901)
+    for it in range(40):
+        G = rng.choice([4, 4, 8])
+        t = bytes(rng.choice(ACGT) for _ in range(rng.choice([300, 700, 1000])))
+        q = _mutate(rng, t, rng.choice([0.05, 0.2, 0.35]))
+        d = oracle.align(q, t, "NW", "distance", -1)["editDistance"]
+        for K in (ring_max_k(G), d, d - 1):
+            if K < abs(len(t) - len(q)) or K > ring_max_k(G):
+                continue
+            got = ring_lanes_nw(q, t, K, G)
+            assert (got == d) if d <= K else (got > K), (G, len(q), len(t), d, K, got)
 
 
 # ---------------------------------------------------------------- rings of 32-row words (ring32_kernels.hip)
