@@ -99,17 +99,19 @@ build_peq_pairs_kernel(const PairDesc* __restrict__ descs, int numUnits, int per
                 const int tn = (nb - t0) < 64 ? (nb - t0) : 64;
                 for (int c0 = 0; c0 < ns; c0 += 4) {                       // four symbols per trip over the tile's bytes
                     u64 w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-                    // four blocks per trip: their four loads are in flight together (one load per trip left a wave
-                    // waiting out a full memory latency per block: 1.1 ms for the 500 MB of config 4's Peq)
-                    for (int j0 = 0; j0 < tn; j0 += 4) {
-                        u32 by[4];
+                    // sixteen blocks per trip: their loads are in flight together (one load per trip left a wave waiting out
+                    // a full memory latency per block: 1.1 ms for the 500 MB of config 4's Peq; four per trip: 0.75 ms)
+                    constexpr int TR = 16;
+                    for (int j0 = 0; j0 < tn; j0 += TR) {
+                        u32 by[TR];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
+                        for (int q = 0; q < TR; ++q) {
                             const int row = (t0 + j0 + q) * 64 + lane;
                             by[q] = (j0 + q < tn && row < qlen) ? (u32)qpool[qoff + (long long)row * qstep] : 0xffffffffu;
                         }
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
+                        for (int q = 0; q < TR; ++q) {
+                            if (j0 + q >= tn) break;                       // (wave-uniform)
                             const u32 mk = by[q] != 0xffffffffu ? s_mask[by[q]] >> c0 : 0u;
                             const u64 b0 = __builtin_amdgcn_ballot_w64((mk & 1u) != 0), b1 = __builtin_amdgcn_ballot_w64((mk & 2u) != 0);
                             const u64 b2 = __builtin_amdgcn_ballot_w64((mk & 4u) != 0), b3 = __builtin_amdgcn_ballot_w64((mk & 8u) != 0);
