@@ -457,21 +457,19 @@ void finalize_global(UnitResult& r, int kcfg, int mode, int T, int score) {
 // alphabetLength of the units the reads path does not cover (reference transformSequences, edlib.cpp:1417-1462:
 // the number of distinct bytes of query and target).  It depends on the sequences only, not on any scan, so it runs
 // on a side stream next to phase 1 and is collected after it.
-int Batch::alphabetLengthsBegin(bool markOnly, bool marked)
+int Batch::alphabetLengthsBegin()
 {
-    if (!marked) alphaPending_ = false;
+    alphaPending_ = false;
     if (alphaUnits_.empty() || alphaOnHost_) return 0;
     const size_t n = alphaUnits_.size();
     if (!side_) EDLIB_AMD_HIP(pool_stream(&side_));
     EDLIB_AMD_HIP(evA_.create());
-    // the inputs went up on stream_ (init): the side stream starts behind whatever stream_ held at the start of the run
-    // (a big pair batch launches the count later, next to its main scan -- the mark is taken first all the same)
-    if (!marked) EDLIB_AMD_HIP(hipEventRecord(evA_.e, stream_));
-    if (markOnly) return 0;
     if (!d_alphaIdx_.p) {
         EDLIB_AMD_HIP(d_alphaIdx_.alloc(n)); EDLIB_AMD_HIP(d_alphaOut_.alloc(n)); EDLIB_AMD_HIP(alphaPin_.alloc(n * sizeof(int)));
         EDLIB_AMD_HIP(hipMemcpyAsync(d_alphaIdx_.p, alphaUnits_.data(), n * sizeof(int), hipMemcpyHostToDevice, side_));
     }
+    // the inputs went up on stream_ (init): the side stream starts behind whatever stream_ holds now
+    EDLIB_AMD_HIP(hipEventRecord(evA_.e, stream_));
     EDLIB_AMD_HIP(hipStreamWaitEvent(side_, evA_.e, 0));
     if (alphaBytes_ <= 4096LL * (long long)n)                        // short sequences: a wave per unit
         hipLaunchKernelGGL(alphabet_count_short_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, side_,
@@ -583,11 +581,8 @@ int Batch::runImpl()
         else if (mode == EDLIB_MODE_SHW || mode == EDLIB_MODE_HW) { r.editDistance = m; r.ends.assign(1, -1); r.hasEnds = true; }
         else r.status = EDLIB_STATUS_ERROR;
     }
-    // (a big NW distance batch of pairs: the count reads 2 GB next to the Peq build of the whole batch, which the main scan
-    // waits for -- it is launched behind that scan instead, which does not touch HBM much: runLevelAll)
-    alphaDeferred_ = !flatPairs_ && cfg_.mode == EDLIB_MODE_NW && cfg_.task == EDLIB_TASK_DISTANCE && pairUnits_.size() >= 8192 &&
-                     groups_.empty() && longUnits_.empty();
-    if (alphabetLengthsBegin(alphaDeferred_, false)) return 1;
+    // (launched now: behind a big batch's main scan, which holds every wave slot of the chip, the count took 17 ms instead of 0.4)
+    if (alphabetLengthsBegin()) return 1;
     bool flatDone = false;
     if (flatPairs_) {                                   // ---- a flat pair batch: everything stays on the device
         bool over = false, fell = false;
@@ -680,7 +675,6 @@ int Batch::runImpl()
             fusedOps_.clear();
             lap("run: pair specs");
             if (solveGlobalDistances(units, score, fuse ? &fusedOps_ : nullptr)) return 1;
-            if (alphaDeferred_) { alphaDeferred_ = false; if (alphabetLengthsBegin(false, true)) return 1; }     // (no level took every unit)
             lap("run: global distances");
             // (alphabetLength of the same units, counted on the side stream meanwhile: set in this pass over the records
             // instead of in one of its own -- alphabetLengthsEnd() then finds nothing pending)

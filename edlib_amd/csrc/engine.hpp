@@ -246,8 +246,7 @@ private:
     // HW inside the static band of a threshold: diagonals [-K, (T - m) + 2 K] (queries in windows not much longer than themselves)
     int solveHwBanded(bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out);
     // alphabetLength of the empty / pair units: launched on a side stream before phase 1, collected after it
-    int alphabetLengthsBegin(bool markOnly = false, bool marked = false);     // markOnly: only note where stream_ stands; marked: launch behind that note
-    bool alphaDeferred_ = false;
+    int alphabetLengthsBegin();
     int alphabetLengthsEnd(std::vector<UnitResult>& res);
     std::vector<int> alphaUnits_; bool alphaOnHost_ = false, alphaPending_ = false; long long alphaBytes_ = 0;
     hipStream_t side_ = nullptr;

@@ -737,7 +737,6 @@ int Batch::runLevelAll(const std::vector<UnitSpec>& units, int ring, int ringH, 
     scanTimerStart();
     EDLIB_AMD_HIP(launch_scan_pairs_ring(ring, EDLIB_MODE_NW, false, a, stream_, ringH));
     scanTimerStop();
-    if (alphaDeferred_) { alphaDeferred_ = false; if (alphabetLengthsBegin(false, true)) return 1; }     // alphabetLength: next to this scan
     EDLIB_AMD_HIP(hipMemcpyAsync(h_levelScore_.p, d_outScore_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
     lap("nw level (every unit): kernels + D2H");

@@ -99,9 +99,10 @@ build_peq_pairs_kernel(const PairDesc* __restrict__ descs, int numUnits, int per
                 const int tn = (nb - t0) < 64 ? (nb - t0) : 64;
                 for (int c0 = 0; c0 < ns; c0 += 4) {                       // four symbols per trip over the tile's bytes
                     u64 w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-                    // sixteen blocks per trip: their loads are in flight together (one load per trip left a wave waiting out
-                    // a full memory latency per block: 1.1 ms for the 500 MB of config 4's Peq; four per trip: 0.75 ms)
-                    constexpr int TR = 16;
+                    // four blocks per trip: their four loads are in flight together (one load per trip left a wave
+                    // waiting out a full memory latency per block: 1.1 ms for the 500 MB of config 4's Peq; four per trip:
+                    // 0.75 ms; sixteen per trip, round 5: 0.72 -- the rest is the ballots and the stores)
+                    constexpr int TR = 4;
                     for (int j0 = 0; j0 < tn; j0 += TR) {
                         u32 by[TR];
 #pragma unroll
