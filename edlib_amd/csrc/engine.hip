@@ -457,7 +457,7 @@ void finalize_global(UnitResult& r, int kcfg, int mode, int T, int score) {
 // alphabetLength of the units the reads path does not cover (reference transformSequences, edlib.cpp:1417-1462:
 // the number of distinct bytes of query and target).  It depends on the sequences only, not on any scan, so it runs
 // on a side stream next to phase 1 and is collected after it.
-int Batch::alphabetLengthsBegin()
+int Batch::alphabetLengthsBegin(hipEvent_t after)
 {
     alphaPending_ = false;
     if (alphaUnits_.empty() || alphaOnHost_) return 0;
@@ -471,6 +471,7 @@ int Batch::alphabetLengthsBegin()
     // the inputs went up on stream_ (init): the side stream starts behind whatever stream_ holds now
     EDLIB_AMD_HIP(hipEventRecord(evA_.e, stream_));
     EDLIB_AMD_HIP(hipStreamWaitEvent(side_, evA_.e, 0));
+    if (after) EDLIB_AMD_HIP(hipStreamWaitEvent(side_, after, 0));
     if (alphaBytes_ <= 4096LL * (long long)n)                        // short sequences: a wave per unit
         hipLaunchKernelGGL(alphabet_count_short_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, side_,
                            d_qpool_.p, d_qoff_.p, d_tpool_.p, d_toff_.p, shared_ ? 1 : 0, d_presence_.p,
@@ -581,8 +582,12 @@ int Batch::runImpl()
         else if (mode == EDLIB_MODE_SHW || mode == EDLIB_MODE_HW) { r.editDistance = m; r.ends.assign(1, -1); r.hasEnds = true; }
         else r.status = EDLIB_STATUS_ERROR;
     }
-    // (launched now: behind a big batch's main scan, which holds every wave slot of the chip, the count took 17 ms instead of 0.4)
-    if (alphabetLengthsBegin()) return 1;
+    // (a big NW distance batch of pairs builds the Peq of all its units beside the divergence probe, and its main scan waits
+    // for that: the count -- 2 GB of reads for config 4 -- is queued BEHIND that build instead of next to it
+    // (solveGlobalDistances).  Not behind the main scan: that holds every wave slot of the chip, and the count took 17 ms.)
+    alphaDeferred_ = !flatPairs_ && cfg_.mode == EDLIB_MODE_NW && cfg_.task == EDLIB_TASK_DISTANCE && pairUnits_.size() >= 8192 &&
+                     groups_.empty() && longUnits_.empty();
+    if (!alphaDeferred_ && alphabetLengthsBegin()) return 1;
     bool flatDone = false;
     if (flatPairs_) {                                   // ---- a flat pair batch: everything stays on the device
         bool over = false, fell = false;

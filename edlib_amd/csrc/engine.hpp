@@ -246,7 +246,8 @@ private:
     // HW inside the static band of a threshold: diagonals [-K, (T - m) + 2 K] (queries in windows not much longer than themselves)
     int solveHwBanded(bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out);
     // alphabetLength of the empty / pair units: launched on a side stream before phase 1, collected after it
-    int alphabetLengthsBegin();
+    int alphabetLengthsBegin(hipEvent_t after = nullptr);      // after: the side stream also waits for this event
+    bool alphaDeferred_ = false;
     int alphabetLengthsEnd(std::vector<UnitResult>& res);
     std::vector<int> alphaUnits_; bool alphaOnHost_ = false, alphaPending_ = false; long long alphaBytes_ = 0;
     hipStream_t side_ = nullptr;

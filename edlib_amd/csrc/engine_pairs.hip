@@ -815,6 +815,10 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
         std::sort(r.begin(), r.end());
         rate = r[np / 2];
     }
+    if (alphaDeferred_) {                                               // alphabetLength: behind the Peq build of the batch, if there is one
+        alphaDeferred_ = false;
+        if (alphabetLengthsBegin(levelAllReady_ ? evLevelPeq_.e : nullptr)) return 1;
+    }
     // First level of a unit: the smallest ring that holds all its blocks or its extrapolated distance.  The distance
     // of a unit of length L at rate r scatters like a sum of L Bernoulli trials (sigma = sqrt(r L)).  A ring of G
     // lanes costs G / 64 of a wave per unit, so trying the smaller ring first pays as long as fewer than a quarter
