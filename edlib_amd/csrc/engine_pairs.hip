@@ -794,7 +794,9 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
     levelAllReady_ = false;
     if (n >= 256 && maxBlocks > 16 && !bandOff && !getenv("EDLIB_AMD_NOPROBE")) {
         // (a big batch: the Peq of every unit is built next to the probe -- prepareLevelAll)
-        if (paths == nullptr && n >= 8192 && &units == &pairSpecs_ && prepareLevelAll(units)) return 1;
+        // (only for units of like lengths: a level takes every unit when the batch's extremes land on the same ring)
+        if (paths == nullptr && n >= 8192 && &units == &pairSpecs_ && 4LL * shape.minLenHi <= 5LL * shape.minLenLo &&
+            prepareLevelAll(units)) return 1;
         // 64 strided units, the first 512 bases of the query against the first 512 + 128 of the target in PREFIX mode
         // (the best end column is free: a global alignment of two equally cut prefixes would add the indel drift at
         // the cut to the count, about one edit in a hundred bases at ONT-like rates).  16 waves of ~650 dependent steps:
