@@ -3,7 +3,8 @@ the banded column store + traceback behind EDLIB_TASK_PATH, against the compiled
 oracle restatement where it did not travel).
 
 Directed at what the generic fuzz only hits by chance: distances right at the level thresholds
-(128, 896, 1920, 3968), block counts right at the ring sizes (4, 16, 32, 64 blocks), mixed batches whose units
+(the rings' band limits of rounds 1-4: 128, 896, 1920, 3968, and round 5's: 196, 976, 2016, 4031; bands that FILL the
+ring: the last tests of this file), block counts right at the ring sizes (4, 16, 32, 64 blocks), mixed batches whose units
 resolve at different levels, batches large enough to take the prefix divergence probe, fixed k, rings
 sharing a wave with idle rings, and paths that run along the edge of the band."""
 import os
@@ -54,7 +55,8 @@ def _pair_with_edits(rng, n, edits, indel_frac=0.5):
 
 
 def test_distances_at_level_thresholds(engine, ref, oracle):
-    """Distances just below / at / above 128, 896, 1920 and 3968 (ring_max_k of the four ring sizes)."""
+    """Distances just below / at / above 128, 896, 1920 and 3968 (the band limits of the four ring sizes until round 4; fixed k
+    also at today's limits)."""
     rng = random.Random(4101 + SEED_SHIFT)
     impl = _impl(ref, oracle)
     qs, ts = [], []
@@ -249,8 +251,8 @@ def test_hw_long_queries_are_cut_into_target_segments(engine, oracle, m):
 
 
 def test_round2_ring_sizes_8_and_21(engine, ref, oracle):
-    """The rings added in round 2 (8 lanes: K = 384, 21 lanes: K = 1216, both carried by ds_bpermute): distances
-    just below / at / above their limits, block counts right at 8 and 21 blocks, batches of >= 256 long units that
+    """The rings added in round 2 (8 lanes: K = 384 then, 456 now; 21 lanes: K = 1216 then, 1301 now; both carried by
+    ds_bpermute): distances just below / at / above those limits, block counts right at 8 and 21 blocks, batches of >= 256 long units that
     take the prefix probe and start on the 21-lane ring with a tail that climbs to 32, fixed k, and paths whose
     storing scan lands on those rings (ring store row = block % 21)."""
     rng = random.Random(4110 + SEED_SHIFT)
@@ -283,7 +285,7 @@ def test_round2_ring_sizes_8_and_21(engine, ref, oracle):
             qs.append(q); ts.append(t)
     if ref is not None:
         _check(engine, ref, qs, ts, "NW", "path", -1, "8 / 21 paths (Hirschberg)")
-    # >= 256 long units: probe, first level 21 lanes, a tail above 1216
+    # >= 256 long units: probe, first level 21 lanes, a tail above its limit (every tenth pair: distance ~1380 > 1301)
     qs, ts = [], []
     for i in range(300):
         t = synth.random_dna(rng.randrange(1 << 30), 10000)
