@@ -679,7 +679,30 @@ int Batch::runImpl()
             for (size_t i = 0; fuse && i < units.size(); ++i) fuse = !needs_hirschberg(units[i].qlen, units[i].tlen);
             fusedOps_.clear();
             lap("run: pair specs");
-            if (solveGlobalDistances(units, score, fuse ? &fusedOps_ : nullptr)) return 1;
+            // What the records of NW units hold besides the distance does not depend on the scan (one end location, T - 1:
+            // edlib.cpp:221-225; alphabetLength from the side stream): a level that takes every unit (runLevelAll) runs this
+            // pass over the 16 MB of 100,000 records while the chip scans, and only the distances are filled in behind it.
+            bool prefilled = false;
+            if (!fuse && mode == EDLIB_MODE_NW) {
+                whileScanning_ = [&]() {
+                    if (alphaIsPairsVersion_ != pairSpecsVersion_) { alphaIsPairs_ = alphaUnits_ == pairUnits_; alphaIsPairsVersion_ = pairSpecsVersion_; }
+                    const int* alphaOut = nullptr;
+                    if (alphaPending_ && alphaIsPairs_ && !alphaOnHost_ && hipStreamSynchronize(side_) == hipSuccess) {
+                        alphaPending_ = false;
+                        alphaOut = reinterpret_cast<const int*>(alphaPin_.p);
+                    }
+                    for (size_t i = 0; i < units.size(); ++i) {
+                        UnitResult& r = res[pairUnits_[i]];
+                        if (deferReset) blank_record(r);
+                        r.hasEnds = true; r.ends.assign(1, units[i].tlen - 1);
+                        if (alphaOut) r.alphabetLength = alphaOut[i];
+                    }
+                    prefilled = true;
+                };
+            }
+            const int solved = solveGlobalDistances(units, score, fuse ? &fusedOps_ : nullptr);
+            whileScanning_ = nullptr;
+            if (solved) return 1;
             lap("run: global distances");
             // (alphabetLength of the same units, counted on the side stream meanwhile: set in this pass over the records
             // instead of in one of its own -- alphabetLengthsEnd() then finds nothing pending)
@@ -690,6 +713,14 @@ int Batch::runImpl()
                 alphaPending_ = false;
                 alphaOut = reinterpret_cast<const int*>(alphaPin_.p);
             }
+            if (prefilled) {
+                for (size_t i = 0; i < units.size(); ++i) {
+                    UnitResult& r = res[pairUnits_[i]];
+                    if (cfg_.k >= 0 && score[i] > cfg_.k) { r.editDistance = -1; r.hasEnds = false; r.ends.clear(); }      // as finalize_global
+                    else r.editDistance = score[i];
+                    if (alphaOut) r.alphabetLength = alphaOut[i];
+                }
+            } else
             for (size_t i = 0; i < units.size(); ++i) {
                 UnitResult& r = res[pairUnits_[i]];
                 if (deferReset) blank_record(r);

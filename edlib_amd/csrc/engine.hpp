@@ -9,6 +9,7 @@
 
 #include <chrono>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -292,6 +293,7 @@ private:
     hipStream_t aux_ = nullptr;
     Event evLevelIn_, evLevelPeq_;
     int prepareLevelAll(const std::vector<UnitSpec>& units);
+    std::function<void()> whileScanning_;        // host work of the run that does not depend on the scan: done behind the level's launch
     int runLevelAll(const std::vector<UnitSpec>& units, int ring, int ringH, int ringBlocks, int cap, int kcap, int nbMax);
     std::vector<OpsOut> fusedOps_;
     // ---- flat pair path (TASK_DISTANCE, every unit a pair of at most 16 blocks): descriptors built once and resident, a

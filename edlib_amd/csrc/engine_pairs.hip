@@ -738,6 +738,7 @@ int Batch::runLevelAll(const std::vector<UnitSpec>& units, int ring, int ringH, 
     EDLIB_AMD_HIP(launch_scan_pairs_ring(ring, EDLIB_MODE_NW, false, a, stream_, ringH));
     scanTimerStop();
     EDLIB_AMD_HIP(hipMemcpyAsync(h_levelScore_.p, d_outScore_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    if (whileScanning_) { auto f = std::move(whileScanning_); whileScanning_ = nullptr; f(); }
     EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
     lap("nw level (every unit): kernels + D2H");
     return 0;
