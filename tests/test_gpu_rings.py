@@ -425,3 +425,20 @@ def test_level_that_takes_every_unit_and_its_tail(engine, checker):
             assert got["editDistance"][i] == want["editDistance"] and got["alphabetLength"][i] == want["alphabetLength"], (k, i)
         if k == -1:
             assert sum(1 for i in range(7, 9000, 40) if got["editDistance"][i] > 196) > 100      # the tail did leave the first level
+
+
+@pytest.mark.parametrize("H,K,m", [(2, 968, 2300), (4, 1928, 4400)])
+def test_prefix_bands_that_fill_rings_of_tall_lanes(engine, checker, H, K, m):
+    """the same on 16-lane rings whose lanes hold H = 2 / 4 blocks (queries above 32 / 64 blocks): the static SHW band of
+    2 K = (64 H + 1) 16 - 64 H diagonals is the most such a ring holds (ring_max_k(16, H) = 1936 / 3856)"""
+    rng = random.Random(5500 + H + SEED_SHIFT)
+    qs, ts = [], []
+    for i in range(24):
+        core = synth.random_dna(rng.randrange(1 << 30), m + rng.randrange(0, 100)).tobytes()
+        c2 = bytearray(core)
+        for j in rng.sample(range(len(core)), i % 3):
+            c2[j] = ord("A") if c2[j] != ord("A") else ord("C")
+        skip = K - (i % 5 == 4)
+        qs.append(bytes(c2)); ts.append(b"T" * skip + core + synth.random_dna(rng.randrange(1 << 30), rng.randrange(0, 40)).tobytes())
+    for k in (K, K + 1, K - 1):
+        _check(engine, checker, qs, ts, "SHW", "locations", k, "tall ring lanes at their band limit")

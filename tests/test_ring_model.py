@@ -136,6 +136,20 @@ def test_lane_by_lane_ring_with_bands_of_a_few_diagonals():
                     assert (got == 2 if K >= 2 else (got is None or got > K)), (G, n, K, got)
 
 
+def test_lane_by_lane_ring_of_tall_lanes(oracle):
+    """ring lanes of 128 rows (H = 2 in the kernel): the same rules with RH = 128, band limit (RH + 1) G - RH"""
+    rng = random.Random(903)
+    G, RH = 4, 128
+    K = ring_max_k(G, RH)
+    assert K == 129 * G - 128
+    for it in range(10):
+        q, t = _edge_hugging_pair(rng, K // 2, RH * G + 300, it % 3, upper=it % 4 != 3)
+        d = oracle.align(q, t, "NW", "distance", -1)["editDistance"]
+        assert ring_fits(len(q), len(t), K, G, RH)
+        got = ring_lanes_nw(q, t, K, G, RH)
+        assert (got == d) if d <= K else (got > K), (it, d, got)
+
+
 def test_lane_by_lane_ring_on_random_pairs(oracle):
     rng = random.Random(901)
     for it in range(40):
