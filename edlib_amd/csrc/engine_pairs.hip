@@ -732,6 +732,7 @@ int Batch::runLevelAll(const std::vector<UnitSpec>& units, int ring, int ringH, 
     a.tlut = d_tlut_.p; a.sigmaT = tab_.sigmaT; a.peq = d_peqAll_.p; a.aux = d_aux_.p;
     a.peqRowStride = peq_row_stride(nbMax);
     a.peqFullStride = (int)std::min<long long>((long long)a.peqRowStride * tab_.sigmaT, 1 << 20);
+    if (getenv("EDLIB_AMD_PEQFULL") && getenv("EDLIB_AMD_PEQFULL")[0] == '0') a.peqFullStride = 0;      // (as solveChunk)
     a.outScore = d_outScore_.p; a.outCount = d_outCount_.p; a.outLast = d_outLast_.p; a.posPool = d_posPool_.p;
     a.wordSteps = ringStepsCounter();
     scanTimerStart();
