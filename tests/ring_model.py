@@ -138,9 +138,12 @@ def banded_nw(q, t, K, RH=64, geom=None):
 #     has to stay idle until the block closes, which costs a ring lane: K <= 64 (G - 2) instead of 65 G - 64.
 # Returns the score as the kernel decodes it (K + 1 when the last block is not alive at the stop column).
 
-def ring_lanes_nw(q, t, K, G, RH=64, upstream_rule=True):
+def ring_lanes_nw(q, t, K, G, RH=64, upstream_rule=True, geom=None, bottom_row=None):
+    """geom = (dmin, dmax): a static band instead of the NW band of K (SHW inside [-K, K]: solveSemiGlobalUnits);
+    bottom_row: a list that receives (column, D[m][column]) for every column at which the last block is at work -- what the
+    SHW / HW modes of the kernel track (the row above the query is +1 per column here, as for NW and SHW)"""
     m, T = len(q), len(t)
-    if K < abs(T - m):
+    if geom is None and K < abs(T - m):
         return None
     W = (1 << RH) - 1
     nb = (m + RH - 1) // RH
@@ -152,7 +155,7 @@ def ring_lanes_nw(q, t, K, G, RH=64, upstream_rule=True):
                 v |= 1 << i
         peq[s] = [(v >> (RH * b)) & W for b in range(nb)]
     zero = [0] * nb
-    dmin, dmax = band(m, T, K)
+    dmin, dmax = geom if geom else band(m, T, K)
     first_col = lambda b: max(0, RH * b + dmin)
     last_col = lambda b: min(T - 1, RH * b + RH - 1 + dmax)
     NEVER = 1 << 60
@@ -232,6 +235,10 @@ def ring_lanes_nw(q, t, K, G, RH=64, upstream_rule=True):
             L.M = ph & xv
             L.bscore += hout
             new_carry.append(hout)
+            if bottom_row is not None and L.b == nb - 1 and 0 <= col < T:
+                sh = (m - 1) & (RH - 1)
+                below = 0 if sh == RH - 1 else (W << (sh + 1)) & W
+                bottom_row.append((col, L.bscore - popc(L.P & below) + popc(L.M & below)))
         for L, c in zip(lanes, new_carry):
             L.carry = c
     return result

@@ -136,6 +136,30 @@ def test_lane_by_lane_ring_with_bands_of_a_few_diagonals():
                     assert (got == 2 if K >= 2 else (got is None or got > K)), (G, n, K, got)
 
 
+@pytest.mark.parametrize("G", [4, 8])
+def test_lane_by_lane_ring_inside_a_static_prefix_band(oracle, G):
+    """SHW with a fixed k runs inside the static band [-K, K] (2 K + 1 diagonals: Batch::solveShwBanded); K = ring_max_k(G) / 2
+    fills the ring.  The cheapest prefix alignment skips K target symbols and stays on the band's upper edge: the best
+    bottom-row score the lanes see is the reference's SHW distance when that is <= K, and nothing <= K otherwise."""
+    rng = random.Random(950 + G)
+    K = ring_max_k(G) // 2
+    for it in range(10):
+        core = bytes(rng.choice(ACGT) for _ in range(64 * G + 250))
+        c2 = bytearray(core)
+        for j in rng.sample(range(len(core)), it % 3):
+            c2[j] = ord("A") if c2[j] != ord("A") else ord("C")
+        q, t = bytes(c2), b"T" * (K - (it % 4 == 3)) + core
+        t = t[:len(q) + K]                                             # (columns past m + K cannot score <= K)
+        want = oracle.align(q, t, "SHW", "distance", K)["editDistance"]
+        rows = []
+        ring_lanes_nw(q, t, K, G, geom=(-K, K), bottom_row=rows)
+        best = min((v for _, v in rows), default=K + 1)
+        assert (best == want) if want >= 0 else (best > K), (G, it, want, best)
+        loose = []
+        ring_lanes_nw(q, t, K, G, upstream_rule=False, geom=(-K, K), bottom_row=loose)
+        assert min((v for _, v in loose), default=K + 1) <= best      # without the rule: never higher, sometimes too low
+
+
 def test_lane_by_lane_ring_of_tall_lanes(oracle):
     """ring lanes of 128 rows (H = 2 in the kernel): the same rules with RH = 128, band limit (RH + 1) G - RH"""
     rng = random.Random(903)
