@@ -457,10 +457,9 @@ void finalize_global(UnitResult& r, int kcfg, int mode, int T, int score) {
 // alphabetLength of the units the reads path does not cover (reference transformSequences, edlib.cpp:1417-1462:
 // the number of distinct bytes of query and target).  It depends on the sequences only, not on any scan, so it runs
 // on a side stream next to phase 1 and is collected after it.
-int Batch::alphabetLengthsBegin(hipEvent_t after)
+// the side stream and the buffers of the count (once per batch)
+int Batch::alphabetBuffers()
 {
-    alphaPending_ = false;
-    if (alphaUnits_.empty() || alphaOnHost_) return 0;
     const size_t n = alphaUnits_.size();
     if (!side_) EDLIB_AMD_HIP(pool_stream(&side_));
     EDLIB_AMD_HIP(evA_.create());
@@ -468,6 +467,15 @@ int Batch::alphabetLengthsBegin(hipEvent_t after)
         EDLIB_AMD_HIP(d_alphaIdx_.alloc(n)); EDLIB_AMD_HIP(d_alphaOut_.alloc(n)); EDLIB_AMD_HIP(alphaPin_.alloc(n * sizeof(int)));
         EDLIB_AMD_HIP(hipMemcpyAsync(d_alphaIdx_.p, alphaUnits_.data(), n * sizeof(int), hipMemcpyHostToDevice, side_));
     }
+    return 0;
+}
+
+int Batch::alphabetLengthsBegin(hipEvent_t after)
+{
+    alphaPending_ = false;
+    if (alphaUnits_.empty() || alphaOnHost_) return 0;
+    const size_t n = alphaUnits_.size();
+    if (alphabetBuffers()) return 1;
     // the inputs went up on stream_ (init): the side stream starts behind whatever stream_ holds now
     EDLIB_AMD_HIP(hipEventRecord(evA_.e, stream_));
     EDLIB_AMD_HIP(hipStreamWaitEvent(side_, evA_.e, 0));

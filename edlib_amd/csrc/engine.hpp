@@ -5,6 +5,7 @@
 #include "../../include/edlib_amd.h"
 #include "common.hpp"
 #include "pair_kernels.hpp"
+#include "lanepair.hpp"
 #include "reads_kernels.hpp"
 
 #include <chrono>
@@ -295,6 +296,22 @@ private:
     int prepareLevelAll(const std::vector<UnitSpec>& units);
     std::function<void()> whileScanning_;        // host work of the run that does not depend on the scan: done behind the level's launch
     int runLevelAll(const std::vector<UnitSpec>& units, int ring, int ringH, int ringBlocks, int cap, int kcap, int nbMax);
+    // ---- the lane-per-pair level of big NW distance batches over at most four target symbols (lanepair.hpp):
+    // a lane owns a unit, the band narrows with the scores.  The units' packed layout is resident like the offset arrays;
+    // a run packs the sequences (query / target bit planes; alphabetLength counted on the way) beside the divergence probe
+    // and scans every unit at the probe's threshold; what that leaves open climbs the rings.
+    int laneSpecsVersion_ = -1;
+    long long lanePlaneWords_ = -1, laneTgtWords_ = 0;
+    bool laneReady_ = false;
+    PinBuf h_laneUnits_, h_laneScore_;
+    DevBuf<lanepair::LaneUnit> d_laneUnits_;
+    DevBuf<lanepair::Plane2> d_lanePlanes_;
+    DevBuf<lanepair::Tgt2> d_laneTgts_;
+    DevBuf<int> d_laneFlags_, d_laneScore_;
+    Event evLanePack_;
+    int alphabetBuffers();
+    int prepareLaneLevel(const std::vector<UnitSpec>& units);
+    int runLaneLevel(const std::vector<UnitSpec>& units, double rate, int kcap, int W);
     std::vector<OpsOut> fusedOps_;
     // ---- flat pair path (TASK_DISTANCE, every unit a pair of at most 16 blocks): descriptors built once and resident, a
     // run is Peq build + ONE ring scan + an overflow census, results stay in HBM until results() (like the reads path)

@@ -745,6 +745,91 @@ int Batch::runLevelAll(const std::vector<UnitSpec>& units, int ring, int ringH, 
     return 0;
 }
 
+// ------------------------------------------------------ the lane-per-pair level
+
+// Packs every unit of the batch for the lane-per-pair scan (lanepair.hpp) on the third stream, beside the divergence probe:
+// query and target bit planes, the "not for this kernel" flags, and -- when the units the count is wanted for are exactly
+// these pairs -- alphabetLength on the way (the count used to read the batch's 2 GB a second time).  Returns 0 with
+// laneReady_ set when the pack is on its way.
+int Batch::prepareLaneLevel(const std::vector<UnitSpec>& units)
+{
+    laneReady_ = false;
+    if (tab_.sigmaT > 4) return 0;
+    const size_t n = units.size();
+    if (laneSpecsVersion_ != pairSpecsVersion_) {
+        EDLIB_AMD_HIP(h_laneUnits_.alloc(n * sizeof(lanepair::LaneUnit)));
+        lanepair::LaneUnit* lu = reinterpret_cast<lanepair::LaneUnit*>(h_laneUnits_.p);
+        long long pw = 0, tw = 0;
+        bool plain = true;
+        for (size_t i = 0; i < n; ++i) {
+            const UnitSpec& u = units[i];
+            plain = plain && u.qstep == 1 && u.tstep == 1 && u.skip == 0 && u.band == 0 && u.qlen > 0 && u.tlen > 0;
+            lu[i] = lanepair::LaneUnit{u.qoff, u.toff, pw, tw, u.qlen, u.tlen};
+            pw += (u.qlen + 31) / 32; tw += (u.tlen + 31) / 32;
+        }
+        lanePlaneWords_ = plain ? pw : -1; laneTgtWords_ = tw;
+        laneSpecsVersion_ = pairSpecsVersion_;
+        if (!plain) return 0;
+        EDLIB_AMD_HIP(d_laneUnits_.ensure(n));
+        EDLIB_AMD_HIP(hipMemcpyAsync(d_laneUnits_.p, lu, n * sizeof(lanepair::LaneUnit), hipMemcpyHostToDevice, stream_));
+    }
+    if (lanePlaneWords_ < 0) return 0;
+    EDLIB_AMD_HIP(d_lanePlanes_.ensure((size_t)lanePlaneWords_ + 1));
+    EDLIB_AMD_HIP(d_laneTgts_.ensure((size_t)laneTgtWords_ + 1));
+    EDLIB_AMD_HIP(d_laneFlags_.ensure(n));
+    EDLIB_AMD_HIP(d_laneScore_.ensure(n));
+    if (h_laneScore_.n < n * sizeof(int)) EDLIB_AMD_HIP(h_laneScore_.alloc(n * sizeof(int)));
+    if (!aux_) {
+        int least = 0, greatest = 0;
+        EDLIB_AMD_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        EDLIB_AMD_HIP(hipStreamCreateWithPriority(&aux_, hipStreamNonBlocking, least));
+    }
+    // alphabetLength on the way, when the count is wanted for exactly these units in this order
+    if (alphaIsPairsVersion_ != pairSpecsVersion_) { alphaIsPairs_ = alphaUnits_ == pairUnits_; alphaIsPairsVersion_ = pairSpecsVersion_; }
+    const bool fuseAlpha = alphaDeferred_ && alphaIsPairs_ && !alphaOnHost_ && !alphaUnits_.empty() && &units == &pairSpecs_;
+    if (fuseAlpha && alphabetBuffers()) return 1;
+    EDLIB_AMD_HIP(evLevelIn_.create()); EDLIB_AMD_HIP(evLanePack_.create());
+    EDLIB_AMD_HIP(hipEventRecord(evLevelIn_.e, stream_));           // the inputs and the units went up on stream_
+    EDLIB_AMD_HIP(hipStreamWaitEvent(aux_, evLevelIn_.e, 0));
+    lanepair::PackArgs pa{};
+    pa.qpool = d_qpool_.p; pa.tpool = d_tpool_.p; pa.tlut = d_tlut_.p; pa.eqtbl = d_eqtbl_.p; pa.sigmaT = tab_.sigmaT;
+    pa.units = d_laneUnits_.p; pa.numUnits = (int)n; pa.planes = d_lanePlanes_.p; pa.tgts = d_laneTgts_.p;
+    pa.flags = d_laneFlags_.p; pa.alphaOut = fuseAlpha ? d_alphaOut_.p : nullptr;
+    EDLIB_AMD_HIP(launch_lanepair_pack(pa, aux_));
+    EDLIB_AMD_HIP(hipEventRecord(evLanePack_.e, aux_));
+    if (fuseAlpha) {                                                // collected from the side stream like the count's own launch
+        alphaDeferred_ = false;
+        EDLIB_AMD_HIP(hipStreamWaitEvent(side_, evLanePack_.e, 0));
+        EDLIB_AMD_HIP(evB_.create());
+        EDLIB_AMD_HIP(hipEventRecord(evB_.e, side_));
+        EDLIB_AMD_HIP(hipMemcpyAsync(alphaPin_.p, d_alphaOut_.p, n * sizeof(int), hipMemcpyDeviceToHost, side_));
+        alphaPending_ = true;
+    }
+    laneReady_ = true;
+    return 0;
+}
+
+// the scan of the lane-per-pair level: computed distances into h_laneScore_ (pinned, units.size() ints; exact iff <= K)
+int Batch::runLaneLevel(const std::vector<UnitSpec>& units, double rate, int kcap, int W)
+{
+    const size_t n = units.size();
+    Lap lap;
+    stats.path |= 2;
+    lanepair::ScanArgs a{};
+    a.units = d_laneUnits_.p; a.flags = d_laneFlags_.p; a.numUnits = (int)n; a.planes = d_lanePlanes_.p; a.tgts = d_laneTgts_.p;
+    a.rate = (float)rate; a.kcap = kcap; a.kmax = lanepair::window_max_k(W); a.outScore = d_laneScore_.p; a.wordSteps = ringStepsCounter(); a.denySeed = 0;
+    if (const char* e = getenv("EDLIB_AMD_LANEPAIR_TRIM")) { if (e[0] == '0') a.denySeed = 0xffffffffu; }      // (A/B: the static band)
+    EDLIB_AMD_HIP(hipStreamWaitEvent(stream_, evLanePack_.e, 0));
+    scanTimerStart();
+    EDLIB_AMD_HIP(launch_lanepair_scan(a, W, stream_));
+    scanTimerStop();
+    EDLIB_AMD_HIP(hipMemcpyAsync(h_laneScore_.p, d_laneScore_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    if (whileScanning_) { auto f = std::move(whileScanning_); whileScanning_ = nullptr; f(); }
+    EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+    lap("nw lane level: kernels + D2H");
+    return 0;
+}
+
 // ------------------------------------------------------ NW distance levels
 
 // The reference finds the NW distance by doubling k from 64 until the banded scan succeeds
@@ -793,12 +878,15 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
     }
     const size_t maxBlocks = shape.maxBlocks;
     // (units of at most 16 blocks climb cheap levels -- the 16-lane ring holds them whole -- and skip the probe)
-    levelAllReady_ = false;
+    levelAllReady_ = false; laneReady_ = false;
     if (n >= 256 && maxBlocks > 16 && !bandOff && !getenv("EDLIB_AMD_NOPROBE")) {
         // (a big batch: the Peq of every unit is built next to the probe -- prepareLevelAll)
         // (only for units of like lengths: a level takes every unit when the batch's extremes land on the same ring)
-        if (paths == nullptr && n >= 8192 && &units == &pairSpecs_ && 4LL * shape.minLenHi <= 5LL * shape.minLenLo &&
-            prepareLevelAll(units)) return 1;
+        const bool bigAlike = paths == nullptr && n >= 8192 && &units == &pairSpecs_ && 4LL * shape.minLenHi <= 5LL * shape.minLenLo;
+        // four target symbols at most: the lane-per-pair level (a lane owns a unit; prepareLaneLevel); else the rings
+        const bool laneOff = getenv("EDLIB_AMD_LANEPAIR") && getenv("EDLIB_AMD_LANEPAIR")[0] == '0';
+        if (bigAlike && !laneOff && prepareLaneLevel(units)) return 1;
+        if (bigAlike && !laneReady_ && prepareLevelAll(units)) return 1;
         // 64 strided units, the first 512 bases of the query against the first 512 + 128 of the target in PREFIX mode
         // (the best end column is free: a global alignment of two equally cut prefixes would add the indel drift at
         // the cut to the count, about one edit in a hundred bases at ONT-like rates).  16 waves of ~650 dependent steps:
@@ -963,6 +1051,39 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
         }
     }
     if (levelAllReady_) EDLIB_AMD_HIP(hipStreamWaitEvent(stream_, evLevelPeq_.e, 0));      // whatever follows: the side work is over before stream_'s next synchronisation
+    // ---- the lane-per-pair level: every unit at its own threshold from the probe's rate (lanepair::unit_threshold; the
+    // reference doubles k from 64, edlib.cpp:197-217: any threshold >= the distance gives the same answer).  A lane's band is
+    // K + 1 diagonals at the start and narrows as the scores use the threshold up.  Units it leaves open (distance above the
+    // threshold, foreign symbols, a band beyond the window) climb the rings.
+    if (laneReady_) {
+        EDLIB_AMD_HIP(hipStreamWaitEvent(stream_, evLanePack_.e, 0));
+        // the window: what the longest unit's threshold needs (24 words: four waves per SIMD; 48: two)
+        const int kLong = lanepair::unit_threshold(shape.minLenHi, shape.minLenHi + shape.maxDiff, (float)rate, kcap, 0x3fffffff);
+        int W = lanepair::window_for_k(kLong);
+        if (W == 0 && kcap > lanepair::window_max_k(48)) W = 48;           // (what does not fit 48 words is left to the rings)
+        if (rate > 0.0 && W != 0) {
+            if (runLaneLevel(units, rate, kcap, W)) return 1;
+            const int* got = reinterpret_cast<const int*>(h_laneScore_.p);
+            size_t open = 0;
+            for (size_t i = 0; i < n; ++i) {
+                if (lvl[i] < 0) continue;
+                const int l = lvl[i], g = got[i];
+                if (g < lanepair::kAboveFinal) { score[i] = g; --atLevel[l]; lvl[i] = -1; }          // exact
+                else if (g == lanepair::kAboveFinal) { score[i] = kInf; --atLevel[l]; lvl[i] = -1; } // > k: final
+                else {
+                    if (g == lanepair::kAboveOpen) {                                                  // the rings, above its threshold
+                        const int Kl = lanepair::unit_threshold(units[i].qlen, units[i].tlen, (float)rate, kcap, lanepair::window_max_k(W));
+                        int up = l;
+                        while (up < nl && cap_of(up) <= Kl && blocks(i) > blocks_of(up)) ++up;
+                        if (up != l) { --atLevel[l]; lvl[i] = up; ++atLevel[up]; }
+                    }
+                    ++open;
+                }
+            }
+            if (getenv("EDLIB_AMD_DEBUG")) fprintf(stderr, "[edlib_amd] lane level: %d words, threshold of the longest unit %d, %zu of %zu units open\n", W, kLong, open, n);
+            lap("nw lane level: scores");
+        }
+    }
     for (int l = 0; l <= nl; ++l) {
         if (atLevel[l] == 0) continue;
         if (l == nl && wideLevel) break;

@@ -43,8 +43,10 @@ namespace lanepair {
 
 typedef uint32_t u32;
 
+#if !defined(LANEPAIR_HAVE_PLANES)
 struct Plane2 { u32 q0, q1; };        // 32 query rows: bit i of q0 / q1 = low / high bit of the symbol code of row 32 w + i
 struct Tgt2 { u32 t0, t1; };          // 32 target columns: bit j of t0 / t1 = low / high bit of the symbol code of column 32 b + j
+#endif
 
 // ({hi, lo} >> sh) & 0xffffffff, sh in 0..31
 LP_FN u32 lp_alignbit(u32 hi, u32 lo, u32 sh)
