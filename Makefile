@@ -9,13 +9,13 @@ OBJDIR  := build/obj
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -Wall -Wno-unused-function \
             -mllvm -disable-promote-alloca-to-vector
 
-SRCS := $(CSRC)/reads_kernels.hip $(CSRC)/reads_kernels_long.hip $(CSRC)/pair_kernels.hip $(CSRC)/wide_kernels.hip $(CSRC)/ring32_kernels.hip $(CSRC)/lanepair_kernels.hip $(CSRC)/lanepair_kernels24.hip $(CSRC)/flat_results.hip $(CSRC)/runtime.hip $(CSRC)/engine.hip $(CSRC)/engine_reads.hip $(CSRC)/engine_pairs.hip $(CSRC)/engine_paths.hip $(CSRC)/engine_flat.hip $(CSRC)/long_reads.hip $(CSRC)/one_pair.hip $(CSRC)/api.hip
+SRCS := $(CSRC)/reads_kernels.hip $(CSRC)/reads_kernels_long.hip $(CSRC)/pair_kernels.hip $(CSRC)/wide_kernels.hip $(CSRC)/ring32_kernels.hip $(CSRC)/lanepair_kernels.hip $(CSRC)/lanepair_kernels42.hip $(CSRC)/lanepair_kernels24.hip $(CSRC)/flat_results.hip $(CSRC)/runtime.hip $(CSRC)/engine.hip $(CSRC)/engine_reads.hip $(CSRC)/engine_pairs.hip $(CSRC)/engine_paths.hip $(CSRC)/engine_flat.hip $(CSRC)/long_reads.hip $(CSRC)/one_pair.hip $(CSRC)/api.hip
 OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 
 all: edlib_amd/libedlib.so build/edlib-aligner-batch build/latency build/cu_hog build/libcu_hog.so
 
 # the lane-per-pair scans (a ladder of unrolled loops per window height: minutes each) depend on their own headers only
-$(OBJDIR)/lanepair_kernels.o $(OBJDIR)/lanepair_kernels24.o: $(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/lanepair.hpp $(CSRC)/lanepair_core.hpp $(CSRC)/lanepair_kernels.hpp
+$(OBJDIR)/lanepair_kernels.o $(OBJDIR)/lanepair_kernels42.o $(OBJDIR)/lanepair_kernels24.o: $(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/lanepair.hpp $(CSRC)/lanepair_core.hpp $(CSRC)/lanepair_asm.hpp $(CSRC)/lanepair_kernels.hpp
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -818,7 +818,7 @@ int Batch::runLaneLevel(const std::vector<UnitSpec>& units, double rate, int kca
     lanepair::ScanArgs a{};
     a.units = d_laneUnits_.p; a.flags = d_laneFlags_.p; a.numUnits = (int)n; a.planes = d_lanePlanes_.p; a.tgts = d_laneTgts_.p;
     a.rate = (float)rate; a.kcap = kcap; a.kmax = lanepair::window_max_k(W); a.outScore = d_laneScore_.p; a.wordSteps = ringStepsCounter(); a.denySeed = 0;
-    if (const char* e = getenv("EDLIB_AMD_LANEPAIR_TRIM")) { if (e[0] == '0') a.denySeed = 0xffffffffu; }      // (A/B: the static band)
+    if (const char* e = getenv("EDLIB_AMD_LANEPAIR")) { if (e[0] == 's') a.denySeed = 0xffffffffu; }           // ("static": A/B against the static band)
     EDLIB_AMD_HIP(hipStreamWaitEvent(stream_, evLanePack_.e, 0));
     scanTimerStart();
     EDLIB_AMD_HIP(launch_lanepair_scan(a, W, stream_));
@@ -1057,8 +1057,9 @@ int Batch::solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<
     // threshold, foreign symbols, a band beyond the window) climb the rings.
     if (laneReady_) {
         EDLIB_AMD_HIP(hipStreamWaitEvent(stream_, evLanePack_.e, 0));
-        // the window: what the longest unit's threshold needs (24 words: four waves per SIMD; 48: two)
-        const int kLong = lanepair::unit_threshold(shape.minLenHi, shape.minLenHi + shape.maxDiff, (float)rate, kcap, 0x3fffffff);
+        // the window: what the threshold of a unit of the batch's longest length needs (its own length difference aside: a
+        // unit whose threshold the window caps is scanned with the cap, and climbs the rings if that was too little)
+        const int kLong = lanepair::unit_threshold(shape.minLenHi, shape.minLenHi, (float)rate, kcap, 0x3fffffff);
         int W = lanepair::window_for_k(kLong);
         if (W == 0 && kcap > lanepair::window_max_k(48)) W = 48;           // (what does not fit 48 words is left to the rings)
         if (rate > 0.0 && W != 0) {

@@ -19,7 +19,8 @@ static constexpr int kAboveFinal = 0x3ffffffd;    // its distance exceeds the ca
 
 // The threshold of a unit at this level: the probe's rate (edits per base, edlibAlign's k-doubling replaced by an estimate:
 // any threshold >= the distance gives the same answer, edlib.cpp:197-217) times the shorter length, plus what the length
-// difference exceeds three sigma of an indel drift by, plus four sigma of a count of that mean, capped by the caller's k and
+// difference exceeds three sigma of an indel drift by, plus 3.5 sigma of a count of that mean (config 4: distances of 1136 +- 28 get
+// 1143 + 118 + 16: what a unit's own scatter and a probe that reads 2 % low leave is still three of its sigmas), capped by the caller's k and
 // by what the window holds.  One formula for the kernel and for whoever wants to know what a unit was scanned with.
 __host__ __device__ inline int unit_threshold(int m, int T, float rate, int kcap, int kmax)
 {
@@ -27,7 +28,7 @@ __host__ __device__ inline int unit_threshold(int m, int T, float rate, int kcap
     const float sd = sqrtf(mean > 1.0f ? mean : 1.0f);
     const float diff = (float)(m > T ? m - T : T - m);
     const float tail = diff > 3.0f * sd ? diff - 3.0f * sd : 0.0f;
-    long long k = (long long)(mean + tail + 4.0f * sd + 16.0f);
+    long long k = (long long)(mean + tail + 3.5f * sd + 16.0f);
     if (k > kmax) k = kmax;
     if (k > kcap) k = kcap;
     return (int)k;
@@ -69,20 +70,23 @@ struct ScanArgs {
     unsigned denySeed;         // tests / benchmark: 0 = trims as the lanes vote; 0xffffffff = never trim (the static band)
 };
 
-// the smallest instantiated window (words of 32 rows) that holds threshold K for every |T - m|: the band is K + 1 diagonals
-// at most and the window covers it at every c % 32, (K + 1 + 62) / 32 words; 0 = beyond this kernel
+// The instantiated windows (words of 32 rows per lane): 16 (four waves per SIMD), 24 (three), 42 and 48 (two).  A scan kernel
+// is a ladder of one loop per window height down from W, and the allocator parks query planes in scratch in the stages where
+// 4 NA + ~85 registers exceed its budget -- with the stages above 42 compiled in, from 30 words on (tools/lanepair_ubench.hip:
+// 31 ns per word-column at 41 words against 18); so 42 is its own kernel, and 48 serves the thresholds beyond it.
+// window_for_k: the smallest window that holds threshold K for every |T - m| -- the band is K + 1 diagonals at most and the
+// window covers it at every c % 32: (K + 1 + 62) / 32 words; 0 = beyond this kernel.
+inline int window_max_k(int W) { return 32 * W - 32; }
 inline int window_for_k(int K)
 {
-    const int need = (K + 1 + 62) / 32;
-    if (need <= 24) return 24;
-    if (need <= 48) return 48;
+    static const int ws[4] = {16, 24, 42, 48};
+    for (int w : ws) if (K <= window_max_k(w)) return w;
     return 0;
 }
-inline int window_max_k(int W) { return 32 * W - 32; }
 
 }  // namespace lanepair
 
 hipError_t launch_lanepair_pack(const lanepair::PackArgs& a, hipStream_t s);
-hipError_t launch_lanepair_scan(const lanepair::ScanArgs& a, int W, hipStream_t s);     // W: 24 or 48 (a.kmax <= window_max_k(W))
+hipError_t launch_lanepair_scan(const lanepair::ScanArgs& a, int W, hipStream_t s);     // W: 16, 24, 42 or 48 (a.kmax <= window_max_k(W))
 
 }  // namespace edlib_amd

@@ -28,9 +28,12 @@
 // The result is exact iff it is <= K (Ukkonen: cells outside the window only enter as upper bounds).
 //
 // This header compiles for the device (lanepair_kernels.hip) AND for the host (tests/lanepair_host.cpp: the same code, one
-// lane at a time, checked against the oracle on the CPU: tests/test_lanepair_model.py).
+// lane at a time, checked against the reference on the CPU: tests/test_lanepair_model.py).
 #pragma once
 #include <stdint.h>
+#if defined(__HIPCC__)
+#include "lanepair_asm.hpp"
+#endif
 
 #if defined(__HIPCC__)
 #define LP_FN __host__ __device__ __forceinline__
@@ -96,43 +99,9 @@ struct Window {
 // v_bitop3_b32: bit (a*4 + b*2 + c) of the immediate is f(a, b, c)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LP_BITOP3(a, b, c, imm) __builtin_amdgcn_bitop3_b32((a), (b), (c), (imm))
-#define LP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-// CODE LAYOUT IS PART OF THE KERNEL (tools/data_ubench.hip, tools/mix_ubench.hip; MI355X): a stream that mixes full-rate
-// (v_bitop3, v_xor ...) and half-rate (v_alignbit, v_addc_co ...) VALU instructions issues at the sum of their rates only
-// while its 8-byte instructions start at addresses that are 4 mod 8; at 0 mod 8 EVERY instruction costs a half-rate slot
-// (this word: 1.13 ns against 1.68 ns per instruction per SIMD, the same instructions, one s_nop apart).  So the column
-// starts behind an alignment fence and its words are asm blocks of 8-byte (VOP3) encodings only -- the compiler shrinks
-// v_xor / v_and / v_addc_co to 4 bytes and answers asm results that are consumed at once with s_nop (4 bytes): either flips
-// the phase for the rest of the column.  tests/test_lanepair_layout.py reads the phase back from the built object.
-#define LP_PHASE_FENCE() asm volatile(".p2align 3\n\ts_nop 0")
+// (the column itself: lanepair_asm.hpp -- one asm statement per window height, and why)
 #define LP_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0f70)          /* s_waitcnt vmcnt(0) */
-typedef unsigned long long lp_carry_t;            // an SGPR pair: the add-carry chain of the column
-// stage A of a word: x = Q0 ^ s0 . ne = (Q1 ^ s1) | x (= ~Eq) . t = Pv & ~ne . s = t + Pv + carry
-#define LP_A1 "v_bitop3_b32 %[x], %[q0], %[s0], %[s0] bitop3:0x3c\n\t"
-#define LP_A2 "v_bitop3_b32 %[ne], %[q1], %[x], %[s1] bitop3:0xde\n\t"
-#define LP_A3 "v_bitop3_b32 %[t], %[pva], %[ne], %[ne] bitop3:0x30\n\t"
-#define LP_A4 "v_addc_co_u32_e64 %[sv], %[cy], %[t], %[pva], %[cy]\n\t"
-#define LP_A4_FIRST "v_add_co_u32_e64 %[sv], %[cy], %[t], %[pva]\n\t"
-// stage B: Xh = (s ^ Pv) | ~ne . Ph = Mv | ~(Xh | Pv) . Mh = Pv & Xh
-#define LP_B1 "v_bitop3_b32 %[xh], %[svb], %[neb], %[pvb] bitop3:0x7b\n\t"
-#define LP_B2 "v_bitop3_b32 %[phb], %[mvb], %[xh], %[pvb] bitop3:0xf1\n\t"
-#define LP_B3 "v_and_b32_e64 %[mhb], %[pvb], %[xh]\n\t"
-// stage C: ph, mh = Ph, Mh << 1 across words . Xv = ~ne | Mv . Pv' = mh | ~(Xv | ph) . Mv' = ph & Xv
-#define LP_C1 "v_alignbit_b32 %[ph], %[phc], %[php], 31\n\t"
-#define LP_C2 "v_alignbit_b32 %[mh], %[mhc], %[mhp], 31\n\t"
-#define LP_C1_TOP "v_alignbit_b32 %[ph], %[phc], -1, 31\n\t"       /* the window's top takes hin = +1 */
-#define LP_C2_TOP "v_alignbit_b32 %[mh], %[mhc], 0, 31\n\t"
-#define LP_C3 "v_bitop3_b32 %[xv], %[nec], %[mvc], %[mvc] bitop3:0xcf\n\t"
-#define LP_C4 "v_bitop3_b32 %[pvc], %[mh], %[xv], %[ph] bitop3:0xf1\n\t"
-#define LP_C5 "v_and_b32_e64 %[mvc], %[ph], %[xv]\n\t"
-#define LP_A_OUT [ne] "=&v"(ne[ia]), [sv] "=&v"(sv[ia]), [t] "=&v"(t), [cy] "+s"(carry)
-#define LP_A_OUT_FIRST [ne] "=&v"(ne[ia]), [sv] "=&v"(sv[ia]), [t] "=&v"(t), [cy] "=s"(carry)
-#define LP_A_IN [x] "v"(x), [q1] "v"(L.Q1[ia]), [pva] "v"(L.Pv[ia]), [s1] "v"(s1)
-#define LP_B_OUT [phb] "=&v"(Ph[ib]), [mhb] "=&v"(Mh[ib]), [xh] "=&v"(Xh)
-#define LP_B_IN [svb] "v"(sv[ib]), [neb] "v"(ne[ib]), [pvb] "v"(L.Pv[ib]), [mvb] "v"(L.Mv[ib])
-#define LP_C_OUT [pvc] "=&v"(L.Pv[ic]), [mvc] "+v"(L.Mv[ic]), [ph] "=&v"(ph), [mh] "=&v"(mh), [xv] "=&v"(Xv)
-#define LP_C_IN [phc] "v"(Ph[ic]), [mhc] "v"(Mh[ic]), [nec] "v"(ne[ic])
-#define LP_C_IN_PREV , [php] "v"(Ph[ic - 1]), [mhp] "v"(Mh[ic - 1])
+#define LP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 LP_FN u32 lp_bitop3_host(u32 a, u32 b, u32 c, u32 imm)
 {
@@ -142,10 +111,8 @@ LP_FN u32 lp_bitop3_host(u32 a, u32 b, u32 c, u32 imm)
     return r;
 }
 #define LP_BITOP3(a, b, c, imm) lp_bitop3_host((a), (b), (c), (imm))
-#define LP_SCHED_FENCE() do { } while (0)
-#define LP_PHASE_FENCE() do { } while (0)
 #define LP_WAIT_LOADS() do { } while (0)
-typedef u32 lp_carry_t;
+#define LP_SCHED_FENCE() do { } while (0)
 #endif
 
 // One column over the NA active words, top-down.  hin at the window's top is +1: row -1 of NW while the window still
@@ -160,74 +127,44 @@ typedef u32 lp_carry_t;
 // instruction's producer is three instructions back.  (Word by word, as the recurrence reads, the first build ran at
 // 67-90 SIMD cycles per word-column against the 30 its instructions take: tools/lanepair_ubench.hip.)
 template <int W, int NA>
-LP_FN void lp_column(Window<W>& L, const u32 s0, const u32 s1, int& sb)
+LP_FN void lp_column(Window<W>& L, const u32 t0, const u32 t1, int& sb)
 {
-    static_assert(NA >= 3, "the pipeline of lp_column is three words deep");
-    u32 ne[NA], sv[NA], Ph[NA], Mh[NA];
+    static_assert(NA >= 3 && NA <= 48, "the pipeline of lp_column is three words deep; lanepair_asm.hpp spells heights up to 48");
 #if defined(__HIP_DEVICE_COMPILE__)
-    lp_carry_t carry;
+    u32 s0, s1, x, t, sv, xh, phs, mhs, xv, ne0, ne1, ne2, ph0, ph1, ph2, mh0, mh1, mh2;
+    unsigned long long cy;
+    LP_COLUMN_DISPATCH(NA)
 #else
-    lp_carry_t carry = 0;
-#endif
-    u32 x = 0;
-    LP_PHASE_FENCE();
-#pragma unroll
-    for (int g = 0; g < NA + 2; ++g) {
-        const int ia = g, ib = g - 1, ic = g - 2;
-        u32 t, Xh, ph, mh, Xv;
-#if defined(__HIP_DEVICE_COMPILE__)
-        // One asm block per group: stage A of word g, B of g - 1, C of g - 2, instruction by instruction across the stages.
-        // A1 (x = Q0 ^ s0) of the NEXT group is an ordinary instruction between two blocks: the hazard recogniser puts a
-        // wait state (s_nop, 4 bytes) between two asm statements of which the second reads what the first wrote.
-        if (g == 0) {
-            x = LP_BITOP3(L.Q0[0], s0, s0, 0x3c);
-            asm(LP_A2 LP_A3 LP_A4_FIRST : LP_A_OUT_FIRST : LP_A_IN);
-        } else if (g == 1)
-            asm(LP_B1 LP_A2 LP_B2 LP_A3 LP_B3 LP_A4 : LP_A_OUT, LP_B_OUT : LP_A_IN, LP_B_IN);
-        else if (g == 2)
-            asm(LP_B1 LP_C1_TOP LP_A2 LP_B2 LP_C2_TOP LP_A3 LP_B3 LP_C3 LP_A4 LP_C4 LP_C5 : LP_A_OUT, LP_B_OUT, LP_C_OUT : LP_A_IN, LP_B_IN, LP_C_IN);
-        else if (g < NA)
-            asm(LP_B1 LP_C1 LP_A2 LP_B2 LP_C2 LP_A3 LP_B3 LP_C3 LP_A4 LP_C4 LP_C5 : LP_A_OUT, LP_B_OUT, LP_C_OUT : LP_A_IN, LP_B_IN, LP_C_IN LP_C_IN_PREV);
-        else if (g == NA)
-            asm(LP_B1 LP_C1 LP_B2 LP_C2 LP_B3 LP_C3 LP_C4 LP_C5 : LP_B_OUT, LP_C_OUT : LP_B_IN, LP_C_IN LP_C_IN_PREV);
-        else
-            asm(LP_C1 LP_C2 LP_C3 LP_C4 LP_C5 : LP_C_OUT : LP_C_IN LP_C_IN_PREV);
-        LP_SCHED_FENCE();
-        if (g + 1 < NA) x = LP_BITOP3(L.Q0[g + 1], s0, s0, 0x3c);
-        else if (g == NA) x = LP_BITOP3(s0, s0, s0, 0xf0);              // (something between the last two blocks as well)
-        LP_SCHED_FENCE();
-        (void)t; (void)Xh; (void)ph; (void)mh; (void)Xv;
-#else
-        if (ia < NA) {
-            x = L.Q0[ia] ^ s0;
-            ne[ia] = (L.Q1[ia] ^ s1) | x;
-            t = L.Pv[ia] & ~ne[ia];
-            const uint64_t w = (uint64_t)t + L.Pv[ia] + carry;
-            sv[ia] = (u32)w; carry = (u32)(w >> 32);
-        }
-        if (ib >= 0 && ib < NA) {
-            Xh = (sv[ib] ^ L.Pv[ib]) | ~ne[ib];
-            Ph[ib] = L.Mv[ib] | ~(Xh | L.Pv[ib]);
-            Mh[ib] = L.Pv[ib] & Xh;
-        }
-        if (ic >= 0 && ic < NA) {
-            ph = lp_alignbit(Ph[ic], ic == 0 ? ~0u : Ph[ic - 1], 31);
-            mh = lp_alignbit(Mh[ic], ic == 0 ? 0u : Mh[ic - 1], 31);
-            Xv = ~ne[ic] | L.Mv[ic];
-            L.Pv[ic] = mh | ~(Xv | ph);
-            L.Mv[ic] = ph & Xv;
-        }
-#endif
+    // the same recurrence, word by word (the host model of tests/lanepair_host.cpp)
+    const u32 s0 = 0u - (t0 & 1u), s1 = 0u - (t1 & 1u);
+    u32 carry = 0, php = ~0u, mhp = 0u, Phl = 0, Mhl = 0;
+    for (int i = 0; i < NA; ++i) {
+        const u32 ne = (L.Q1[i] ^ s1) | (L.Q0[i] ^ s0);
+        const u32 pv = L.Pv[i], mv = L.Mv[i];
+        const u32 tt = pv & ~ne;
+        const uint64_t w = (uint64_t)tt + pv + carry;
+        const u32 s = (u32)w; carry = (u32)(w >> 32);
+        const u32 Xh = (s ^ pv) | ~ne;
+        const u32 Ph = mv | ~(Xh | pv), Mh = pv & Xh;
+        const u32 ph = lp_alignbit(Ph, php, 31), mh = lp_alignbit(Mh, mhp, 31);       // the window's top takes hin = +1
+        php = Ph; mhp = Mh; Phl = Ph; Mhl = Mh;
+        const u32 Xv = ~ne | mv;
+        L.Pv[i] = mh | ~(Xv | ph);
+        L.Mv[i] = ph & Xv;
     }
-    sb += (int)(Ph[NA - 1] >> 31) - (int)(Mh[NA - 1] >> 31);   // the bottom row of the window moves with its horizontal delta
+    sb += (int)(Phl >> 31) - (int)(Mhl >> 31);         // the bottom row of the window moves with its horizontal delta
+#endif
 }
 
 // the words move up one register (the top word leaves)
 template <int W, int NA>
 LP_FN void lp_shift_up(Window<W>& L)
 {
-#pragma unroll
+#if defined(__HIP_DEVICE_COMPILE__)
+    LP_SHIFT_DISPATCH(NA)
+#else
     for (int i = 0; i + 1 < NA; ++i) { L.Pv[i] = L.Pv[i + 1]; L.Mv[i] = L.Mv[i + 1]; L.Q0[i] = L.Q0[i + 1]; L.Q1[i] = L.Q1[i + 1]; }
+#endif
 }
 
 // What a lane carries besides its window.
@@ -275,10 +212,7 @@ LP_FN int lp_block(Window<W>& L, LaneCtl& s, Tgt2& tg, const Tgt2* tgt, const in
     u32 t0 = tg.t0, t1 = tg.t1;
 #pragma unroll 1
     for (int j = 0; j < 32; ++j) {
-        if (c0 + j < s.T) {
-            const u32 s0 = 0u - (t0 & 1u), s1 = 0u - (t1 & 1u);
-            lp_column<W, NA>(L, s0, s1, s.sb);
-        }
+        if (c0 + j < s.T) lp_column<W, NA>(L, t0, t1, s.sb);
         t0 >>= 1; t1 >>= 1;
     }
     const int cnext = c0 + 32;
@@ -362,6 +296,7 @@ LP_FN void lp_init(Window<W>& L, LaneCtl& s, const int m, const int T, const int
         u32 mv;
         if (R >= 0) mv = 0u; else if (R <= -32) mv = ~0u; else mv = (1u << (u32)(-R)) - 1u;
         L.Mv[j] = mv; L.Pv[j] = ~mv;
+        LP_SCHED_FENCE();                             // (word by word: 2 W loads in flight at once cost 2 W registers for nothing)
     }
     s.score = 0x3fffffff;
     s.wi = wi0 + naInit;

@@ -95,7 +95,7 @@ lanepair_pack_kernel(const PackArgs a)
 
 // ------------------------------------------------------------------ the scan
 template <int W>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W > 28 ? 2 : 4)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W <= 16 ? 4 : (W <= 24 ? 3 : 2))))
 lanepair_scan_kernel(const ScanArgs a)
 {
     const int lane = threadIdx.x;
@@ -133,14 +133,24 @@ inline hipError_t launch_pack(const PackArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 #endif
+// LANEPAIR_WINDOWS: which instantiations this translation unit carries (bit 0: 16, 1: 24, 2: 42, 3: 48)
+#if !defined(LANEPAIR_WINDOWS)
+#define LANEPAIR_WINDOWS 15
+#endif
 inline hipError_t launch_scan(const ScanArgs& a, int W, hipStream_t s)
 {
     if (a.numUnits <= 0) return hipSuccess;
     const dim3 grid((a.numUnits + 63) / 64), block(64);
-#if !defined(LANEPAIR_NO_W24) && !defined(LANEPAIR_ONLY48)
+#if LANEPAIR_WINDOWS & 1
+    if (W == 16) { hipLaunchKernelGGL(lanepair_scan_kernel<16>, grid, block, 0, s, a); return hipGetLastError(); }
+#endif
+#if LANEPAIR_WINDOWS & 2
     if (W == 24) { hipLaunchKernelGGL(lanepair_scan_kernel<24>, grid, block, 0, s, a); return hipGetLastError(); }
 #endif
-#if !defined(LANEPAIR_NO_W48)
+#if LANEPAIR_WINDOWS & 4
+    if (W == 42) { hipLaunchKernelGGL(lanepair_scan_kernel<42>, grid, block, 0, s, a); return hipGetLastError(); }
+#endif
+#if LANEPAIR_WINDOWS & 8
     if (W == 48) { hipLaunchKernelGGL(lanepair_scan_kernel<48>, grid, block, 0, s, a); return hipGetLastError(); }
 #endif
     return hipErrorInvalidValue;

@@ -82,7 +82,7 @@ def test_static_band_and_trimmed_band_agree(engine, checker):
     rng = random.Random(6200 + SEED_SHIFT)
     qs, ts = _batch(rng, 8500, 2800, 3300, lambda i: 0.03 + 0.02 * (i % 3))
     a, _ = _run(engine, qs, ts, -1)
-    b, _ = _run(engine, qs, ts, -1, {"EDLIB_AMD_LANEPAIR_TRIM": "0"})
+    b, _ = _run(engine, qs, ts, -1, {"EDLIB_AMD_LANEPAIR": "static"})
     assert np.array_equal(a["editDistance"], b["editDistance"])
     _compare(checker, qs, ts, -1, a, range(0, 8500, 211))
 
