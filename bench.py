@@ -586,6 +586,16 @@ def main():
             out["parity_sample"] = parity
             if args.config == 2:
                 out["invariants"] = invariants_config2(w, flat)
+                # the WHOLE batch against the reference's committed answers (tests/golden/c2_full_ref.npz), when this is the
+                # batch they were made for (1,000,000 reads, rank 0, weak scaling)
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    import full_parity_c2
+                    pf = full_parity_c2.compare_with_fixture(flat, w["target"], w["reads"])
+                    if pf is not None:
+                        out["parity_full"] = pf
+                except Exception as e:                                 # the headline line must survive
+                    out["parity_full"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and args.config == 2 and not args.no_e2e:
             r = e2e_config2(w)
             if isinstance(r, tuple):

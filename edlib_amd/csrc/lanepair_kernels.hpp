@@ -11,19 +11,52 @@ namespace edlib_amd {
 namespace lanepair {
 
 // ------------------------------------------------------------------ packing
-// One workgroup per unit.  Lane i of a wave loads byte 64 k + i of the sequence (one coalesced line per wave), looks its
-// symbol code up and two ballots ARE the bit planes of those 64 rows / columns (the cooperative build of
-// build_peq_reads_kernel).  Query codes: the target symbol the byte equals (eqtbl: 16-bit set of target symbols per byte,
-// EqualityDefinition edlib.cpp:63-94); a byte that equals none takes a code no target symbol has when there are fewer
-// than four, and a byte that equals none of four symbols, or more than one, marks the unit as not for this kernel
-// (flags[unit] = 1: it stays on the rings).  alphaOut (optional): the unit's alphabetLength (distinct bytes of query and
-// target, edlib.cpp:162) -- every byte of both is in a register here anyway.
+// One workgroup per unit; waves 0 / 1 take the query, 2 / 3 the target, 1024 bytes per wave and trip: a lane loads 16 bytes
+// (one dwordx4), looks the symbol code of each up (LDS: 256 entries) and builds 16 bits of each plane; two neighbours make a
+// word.  (The first build loaded a byte per lane and let two ballots be the planes: 0.96 TB/s.)  Query codes: the target
+// symbol the byte equals (eqtbl: 16-bit set of target symbols per byte, EqualityDefinition edlib.cpp:63-94); a byte that
+// equals none takes a code no target symbol has when there are fewer than four, and a byte that equals none of four symbols,
+// or more than one, marks the unit as not for this kernel (flags[unit] = 1: it stays on the rings).  alphaOut (optional): the
+// unit's alphabetLength (distinct bytes of query and target, edlib.cpp:162) -- every byte of both is in a register here
+// anyway: each marks its entry of a 256-entry table in LDS, as alphabet_count_kernel does.
 #if !defined(LANEPAIR_NO_PACK)
+template <bool QUERY>
+__device__ __forceinline__ bool lanepair_pack_sequence(const uint8_t* __restrict__ seq, const int len, const uint8_t* code, uint8_t* mark,
+                                                       const bool doMark, uint32_t* __restrict__ out, const int lane, const int sub)
+{
+    bool foreign = false;
+    for (int base = sub * 1024; base < len; base += 2048) {
+        const int r0 = base + 16 * lane;
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (r0 < len) __builtin_memcpy(w, seq + r0, 16);                 // (the pools are padded: 16 bytes past a sequence's end exist)
+        uint32_t b0 = 0, b1 = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 255u;
+            if (r0 + k < len) {
+                if (doMark) mark[b] = 1;
+                uint32_t c = code[b];
+                if (QUERY && c == 255u) { foreign = true; c = 0; }
+                b0 |= (c & 1u) << k; b1 |= ((c >> 1) & 1u) << k;
+            }
+        }
+        const uint32_t mine = b0 | (b1 << 16);
+        const uint32_t other = (uint32_t)__shfl_xor((int)mine, 1);
+        if (!(lane & 1) && r0 < len) {
+            uint2 v;
+            v.x = (mine & 0xffffu) | (other << 16);                      // plane 0: my 16 rows below my neighbour's
+            v.y = (mine >> 16) | (other & 0xffff0000u);                  // plane 1
+            *reinterpret_cast<uint2*>(out + 2 * (r0 >> 5)) = v;
+        }
+    }
+    return foreign;
+}
+
 __global__ void __launch_bounds__(256)
 lanepair_pack_kernel(const PackArgs a)
 {
     __shared__ uint8_t qcode[256], tcode[256], mark[256];
-    __shared__ int bad;
+    __shared__ int bad, cnt[4];
     const int u = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
@@ -39,50 +72,14 @@ lanepair_pack_kernel(const PackArgs a)
     }
     __syncthreads();
     const LaneUnit un = a.units[u];
-    const uint8_t* q = a.qpool + un.qoff;
-    const uint8_t* t = a.tpool + un.toff;
-    Plane2* pl = a.planes + un.planeOff;
-    Tgt2* tg = a.tgts + un.tgtOff;
     bool foreign = false;
-    // four chunks of 64 rows per trip and wave: four loads in flight
-    for (int base = wave * 256; base < un.m; base += 1024) {
-        uint8_t b[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { const int i = base + 64 * k + lane; b[k] = i < un.m ? q[i] : q[0]; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = base + 64 * k + lane;
-            uint32_t c = 0;
-            if (i < un.m) {
-                mark[b[k]] = 1;
-                c = qcode[b[k]];
-                if (c == 255) { foreign = true; c = 0; }
-            }
-            const unsigned long long b0 = __ballot(c & 1u), b1 = __ballot(c & 2u);
-            const int w = (base + 64 * k) >> 5;
-            if (lane == 0 && base + 64 * k < un.m) pl[w] = Plane2{(u32)b0, (u32)b1};
-            if (lane == 1 && base + 64 * k + 32 < un.m) pl[w + 1] = Plane2{(u32)(b0 >> 32), (u32)(b1 >> 32)};
-        }
-    }
-    for (int base = wave * 256; base < un.T; base += 1024) {
-        uint8_t b[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { const int i = base + 64 * k + lane; b[k] = i < un.T ? t[i] : t[0]; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = base + 64 * k + lane;
-            uint32_t c = 0;
-            if (i < un.T) { mark[b[k]] = 1; c = tcode[b[k]]; }
-            const unsigned long long b0 = __ballot(c & 1u), b1 = __ballot(c & 2u);
-            const int w = (base + 64 * k) >> 5;
-            if (lane == 0 && base + 64 * k < un.T) tg[w] = Tgt2{(u32)b0, (u32)b1};
-            if (lane == 1 && base + 64 * k + 32 < un.T) tg[w + 1] = Tgt2{(u32)(b0 >> 32), (u32)(b1 >> 32)};
-        }
-    }
+    if (wave < 2) foreign = lanepair_pack_sequence<true>(a.qpool + un.qoff, un.m, qcode, mark, a.alphaOut != nullptr,
+                                                         reinterpret_cast<uint32_t*>(a.planes + un.planeOff), lane, wave);
+    else lanepair_pack_sequence<false>(a.tpool + un.toff, un.T, tcode, mark, a.alphaOut != nullptr,
+                                       reinterpret_cast<uint32_t*>(a.tgts + un.tgtOff), lane, wave - 2);
     if (foreign) bad = 1;
     __syncthreads();
     const unsigned long long seen = __ballot(mark[tid] != 0);
-    __shared__ int cnt[4];
     if (lane == 0) cnt[wave] = __popcll(seen);
     __syncthreads();
     if (tid == 0) {
@@ -90,7 +87,6 @@ lanepair_pack_kernel(const PackArgs a)
         if (a.alphaOut) a.alphaOut[u] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
     }
 }
-
 #endif
 
 // ------------------------------------------------------------------ the scan

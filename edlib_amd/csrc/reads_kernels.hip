@@ -36,6 +36,7 @@
 //                                       workgroup, S = 4 / 8 / 16 Peq rows per word.
 #include "reads_kernels.hpp"
 #include "reads_scan.hpp"
+#include "reads_column_asm.hpp"
 
 namespace edlib_amd {
 
@@ -232,6 +233,17 @@ template <int NWD, int MODE>
 __device__ __forceinline__ void column_step(const u32 (&Eq)[NWD], u32 (&Pv)[NWD], u32 (&Mv)[NWD],
                                             int& score, const u32 sh)
 {
+    if constexpr (NWD <= 8) {
+        // one asm statement: VOP3 encodings behind an alignment fence (reads_column_asm.hpp: why)
+        u32 t_, s_, xh_, ph0_, ph1_, mh0_, mh1_, phs_, mhs_, xv_, Pn[NWD], Mn[NWD];
+        int scoreN;
+        unsigned long long cy_;
+        if constexpr (MODE == 2) { RC_COLUMN_DISPATCH(NWD, RC_WORD0_HW) } else { RC_COLUMN_DISPATCH(NWD, RC_WORD0_NW) }
+#pragma unroll
+        for (int i = 0; i < NWD; ++i) { Pv[i] = Pn[i]; Mv[i] = Mn[i]; }
+        score = scoreN;
+        return;
+    }
     u32 Ph[NWD], Mh[NWD];
     u32 carry = 0;
 #pragma unroll

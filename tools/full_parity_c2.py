@@ -124,9 +124,58 @@ def leg_compare(args):
         json.dump(out, open(args.json, "w"), indent=1)
 
 
+FIXTURE = os.path.join(ROOT, "tests", "golden", "c2_full_ref.npz")
+
+
+def leg_fixture(args):
+    """the reference's answers for the WHOLE batch as one compact committed fixture: what bench.py's
+    `parity_full` and tests/test_gpu_full_parity_c2.py compare the resident results of the timed batch with"""
+    meta = json.load(open(os.path.join(args.ref, "meta.json")))
+    n = meta["units"]
+    ed, nl, al, ends = [], [], [], []
+    for a in range(0, n, meta["chunk"]):
+        r = np.load(os.path.join(args.ref, "chunk_%07d.npz" % a))              # (a missing chunk is an error: the fixture is whole)
+        assert (r["status"] == 0).all()
+        ed.append(r["editDistance"].astype(np.int16)); nl.append(r["numLocations"].astype(np.int32))
+        al.append(r["alphabetLength"].astype(np.uint8)); ends.append(r["ends"].astype(np.int32))
+    out = args.out if args.out and args.out.endswith(".npz") else FIXTURE
+    np.savez_compressed(out, editDistance=np.concatenate(ed), numLocations=np.concatenate(nl), alphabetLength=np.concatenate(al),
+                        ends=np.concatenate(ends), sha256=np.frombuffer(meta["sha256"].encode(), dtype=np.uint8),
+                        note=np.frombuffer(b"edlibAlign(HW, DISTANCE, k = -1) of the UNMODIFIED reference (oracle/_ref) over bench.py's config-2 "
+                                           b"batch, rank 0, weak scaling (target seed 12345, reads seed 12346); made by tools/full_parity_c2.py ref + fixture", dtype=np.uint8))
+    print("[fixture] %d units -> %s (%.1f MB)" % (n, out, os.path.getsize(out) / 1e6))
+
+
+def compare_with_fixture(flat, target, reads, fixture=FIXTURE):
+    """whole-batch comparison of results_flat() arrays with the committed reference answers; None when the fixture is absent
+    or was made for other inputs"""
+    if not os.path.exists(fixture):
+        return None
+    f = np.load(fixture)
+    n = len(f["editDistance"])
+    if len(reads) != n or bytes(f["sha256"]).decode() != digest(target, np.ascontiguousarray(reads)):
+        return {"checked": 0, "note": "fixture is for other inputs"}
+    bad = (flat["editDistance"].astype(np.int64) != f["editDistance"]) | (flat["numLocations"].astype(np.int64) != f["numLocations"]) | \
+          (flat["alphabetLength"].astype(np.int64) != f["alphabetLength"]) | (flat["status"].astype(np.int64) != 0)
+    off = flat["locOff"].astype(np.int64)
+    roff = np.concatenate([[0], np.cumsum(f["numLocations"].astype(np.int64))])
+    if not bad.any() and off[-1] == roff[-1]:
+        same = flat["ends"].astype(np.int64)[: off[-1]] == f["ends"]
+        cs = np.concatenate([[0], np.cumsum(~same)])
+        bad |= (cs[roff[1:]] - cs[roff[:-1]]) > 0
+    else:
+        ge, fe = flat["ends"], f["ends"]
+        for i in np.nonzero(~bad)[0]:
+            if not np.array_equal(ge[off[i]:off[i + 1]], fe[roff[i]:roff[i + 1]]):
+                bad[i] = True
+    return {"checked": int(n), "bit_exact": int((~bad).sum()), "failing_units": [int(i) for i in np.nonzero(bad)[0][:20]],
+            "fields": "status, editDistance, numLocations, alphabetLength, every endLocation",
+            "reference": "tests/golden/c2_full_ref.npz: the unmodified reference over the whole batch (tools/full_parity_c2.py ref, CPU hours)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("leg", choices=["ref", "gpu", "compare"])
+    ap.add_argument("leg", choices=["ref", "gpu", "compare", "fixture"])
     ap.add_argument("--units", type=int, default=1_000_000)
     ap.add_argument("--threads", type=int, default=6)
     ap.add_argument("--chunk", type=int, default=20000)
@@ -135,9 +184,9 @@ def main():
     ap.add_argument("--gpu", default=os.path.join(ROOT, "gpurun_out", "c2gpu.npz"))
     ap.add_argument("--json", default=None)
     args = ap.parse_args()
-    if args.out is None:
+    if args.out is None and args.leg != "fixture":
         args.out = args.ref if args.leg == "ref" else args.gpu
-    {"ref": leg_ref, "gpu": leg_gpu, "compare": leg_compare}[args.leg](args)
+    {"ref": leg_ref, "gpu": leg_gpu, "compare": leg_compare, "fixture": leg_fixture}[args.leg](args)
 
 
 if __name__ == "__main__":
