@@ -50,11 +50,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9        # CUs x SIMDs x lanes/clk x Hz (MI355X_MICROARCH.md)
 VALU_OPS_PER_WORD_STEP = 10.0               # DP ops per 32-row word-column (7 logic + add + 2 shift), from the gfx950 ISA
+VALU_OPS_PER_WORD_STEP_OF = {4: 12.0}       # config 4's lane-per-pair column: the same 10 + 2 that synthesise Eq from the query's bit planes
 CONFIGS = {
     2: dict(units=1_000_000, name="1M x 150bp HW reads vs 5Mb target", mode="HW", task="distance",
             kernel="scan_reads_banded_kernel<5> (+ scan_reads_kernel<5,2> for pass 2)", dtype="u32"),
     4: dict(units=100_000, name="100k x 10kb NW pairs, distance", mode="NW", task="distance",
-            kernel="scan_pairs_ring_kernel<21,0,false,1> (+ <32,0,false,1> as two half scans for units above K = 1301)", dtype="u64 (2 x u32)"),
+            kernel="lanepair_scan_kernel<42> (a lane per pair, the band narrows with the scores; scan_pairs_ring_kernel for units it leaves open)", dtype="u32"),
     5: dict(units=10_000, name="10k x 1kb NW pairs, path + CIGAR", mode="NW", task="path",
             kernel="scan_pairs_ring32_kernel<8,true> + traceback32_kernel<32> (+ the collection: flat_write_kernel, cigar_kernel)", dtype="u32"),
 }
@@ -297,6 +298,23 @@ def e2e_config2(w):
 
 
 
+def device_clocks(device):
+    """sclk / mclk / fclk, power and temperature of the device as rocm-smi reports them right now (a 27 %
+    box-to-box swing on config 4 could not be attributed because the line carried no clocks); {} when the tool is not there"""
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(device), "--showclocks", "--showpower", "--showtemp", "--showperflevel", "--json"],
+                           capture_output=True, text=True, timeout=20)
+        card = next(iter(json.loads(r.stdout).values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "socclk", "power (w)", "socket power", "temperature (sensor junction)", "temperature (sensor memory)", "performance level")):
+                keep[k] = v
+        return keep
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def traffic_of(cfg_id, units):
     """HBM bytes per step from the rocprofv3 --pmc passes of tools/gpu_visit.sh (profiles/hbm_traffic.json records the
     commit they were taken at); None when there is no entry for this batch size"""
@@ -319,7 +337,8 @@ def report(cfg_id, w, st, scan_ms, launches, steps, warmup, dt, value, world, sc
     algo_bytes = st["algo_bytes"]
     achieved = algo_bytes / (main_scan_ms * 1e-3) / 1e9 if main_scan_ms > 0 else 0.0
     traffic, traffic_src = traffic_of(cfg_id, w["n"])
-    lane_ops = st["word_steps"] * VALU_OPS_PER_WORD_STEP
+    ops_per_word = VALU_OPS_PER_WORD_STEP_OF.get(cfg_id, VALU_OPS_PER_WORD_STEP)
+    lane_ops = st["word_steps"] * ops_per_word
     valu_achieved = lane_ops / (main_scan_ms * 1e-3) if main_scan_ms > 0 else 0.0
     return {
         "metric": "GCUPS (cell updates/s), %s" % c["name"],
@@ -340,7 +359,7 @@ def report(cfg_id, w, st, scan_ms, launches, steps, warmup, dt, value, world, sc
                           "peak": round(VALU_LANE_OPS / 1e12, 2), "unit": "T lane-ops/s",
                           "frac": round(valu_achieved / VALU_LANE_OPS, 4),
                           "word_steps_per_step": st["word_steps"],
-                          "valu_ops_per_word_step": VALU_OPS_PER_WORD_STEP},
+                          "valu_ops_per_word_step": ops_per_word},
         "overflow_units": st["overflow_units"],
     }
 
@@ -541,6 +560,7 @@ def main():
     dt_local = time.perf_counter() - t0
     sync()
     dt_sync = time.perf_counter() - t0
+    clocks_after = device_clocks(device) if rank == 0 else None          # (outside the timed region)
     from edlib_amd.parallel import aggregate_throughput, gather_int_results
     # whole-job cells (SUM over ranks) and the slowest rank's time (MAX over ranks, barrier included)
     cells_all, dt = aggregate_throughput(st["cells"] * args.steps, dt_sync, dist, coll_dev)
@@ -571,6 +591,8 @@ def main():
             if not coll_note.get("inside_step"):
                 coll_note["ms_per_step_plus_one_collection"] = round(out["ms_per_step"] + coll_note["results_flat_ms"], 3)
             out["collection"] = coll_note
+        out["clocks"] = {"right_after_the_timed_steps": clocks_after, "after_the_run": device_clocks(device),
+                         "source": "rocm-smi --showclocks --showpower --showtemp (rank 0's device)"}
         out["per_rank_ms_per_step"] = per_rank_ms
         out["devices"] = devices
         out["devices_distinct"] = len(set(devices))
