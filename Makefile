@@ -34,7 +34,7 @@ build/edlib-aligner-batch: apps/aligner_batch.cpp edlib_amd/libedlib.so include/
 # microseconds per edlibAlign() call for any library with the edlib C ABI
 build/latency: tools/latency.cpp
 	@mkdir -p build
-	g++ -O2 -std=c++14 tools/latency.cpp -ldl -o $@
+	g++ -O2 -std=c++14 -pthread tools/latency.cpp -ldl -o $@
 
 # a second process that holds most wave slots of the device for a few seconds (tests/test_gpu_wide.py)
 build/cu_hog: tools/cu_hog.hip

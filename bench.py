@@ -58,7 +58,12 @@ CONFIGS = {
             kernel="lanepair_scan_kernel<42> (a lane per pair, the band narrows with the scores; scan_pairs_ring_kernel for units it leaves open)", dtype="u32"),
     5: dict(units=10_000, name="10k x 1kb NW pairs, path + CIGAR", mode="NW", task="path",
             kernel="scan_pairs_ring32_kernel<8,true> + traceback32_kernel<32> (+ the collection: flat_write_kernel, cigar_kernel)", dtype="u32"),
+    # config 5 sixteen times over: the same recipe with enough pairs to fill the chip (10,000 pairs are 0.6 waves per SIMD:
+    # that line measures launches and the link, not the kernels) -- VERDICT r5 item 6
+    6: dict(units=160_000, name="160k x 1kb NW pairs, path + CIGAR (config 5 x 16: a chip-filling PATH batch)", mode="NW", task="path",
+            kernel="scan_pairs_ring32_kernel<8,true> + traceback32_kernel<32> (+ the collection: flat_write_kernel, cigar_kernel)", dtype="u32"),
 }
+PATH_CONFIGS = (5, 6)
 TARGET_LEN, READ_LEN = 5_000_000, 150
 
 
@@ -98,7 +103,7 @@ def make_workload(cfg_id, units, rank, world, strong):
         w["describe"] = ("per GPU: %d x %dbp reads (1%% sub, 0.05%% ins/del, 5%% unrelated), EDLIB_MODE_HW, k=-1, "
                          "EDLIB_TASK_DISTANCE, vs one %d-base uniform ACGT target" % (n, READ_LEN, TARGET_LEN))
     else:
-        length, seed, rates = (10000, 12349, (0.04, 0.04, 0.04)) if cfg_id == 4 else (1000, 12350, (0.03, 0.01, 0.01))
+        length, seed, rates = (10000, 12349, (0.04, 0.04, 0.04)) if cfg_id == 4 else (1000, 12350, (0.03, 0.01, 0.01))      # (5 and 6)
         if strong and world > 1:
             lo, hi = shard_range(units, rank, world)
         else:
@@ -193,6 +198,12 @@ def cpu_baseline_and_parity(w, flat, sample_target, batch=None):
         ga, ra = flat["alnOff"], ref["alnOff"]
         alen = (ga[1:] - ga[:-1])[sel]
         bad |= alen != (ra[1:] - ra[:-1])
+        if len(sel) < n and not bad.any():          # a sample: the op bytes of every sampled unit
+            fa, rr = flat["alignment"], ref["alignment"]
+            for j, i in enumerate(sel):
+                if not np.array_equal(fa[ga[i]:ga[i + 1]], rr[ra[j]:ra[j + 1]]):
+                    bad[j] = True
+            detail = {"op_bytes_compared": int(ra[-1])}
         if len(sel) == n and not bad.any():
             same = np.array_equal(flat["alignment"], ref["alignment"])
             ext, std = cigars_of(flat)
@@ -410,16 +421,21 @@ def measure_chromosome(repeat=2):
 def measure_collection(cfg_id, batch, ms_per_step):
     """the collection on its own clock: the results view (+ both CIGAR views for the PATH workload, after one more run --
     the timed steps have already collected theirs)"""
-    if cfg_id == 5:
+    if cfg_id in PATH_CONFIGS:
         batch.run()
     tc = time.perf_counter()
     flat = batch.results_flat(copy=False)
     t1 = time.perf_counter()
-    if cfg_id == 5:
+    if cfg_id in PATH_CONFIGS:
         batch.cigars(True, copy=False); batch.cigars(False, copy=False)
     t2 = time.perf_counter()
     note = collection_note((t2 - tc) * 1e3, ms_per_step)
-    if cfg_id == 5:
+    if cfg_id in PATH_CONFIGS:
+        # the link: what one collection brings over PCIe (the dense op bytes dominate) against the time the view took
+        nbytes = int(sum(v.nbytes for v in flat.values() if isinstance(v, np.ndarray)))
+        note["link"] = {"bytes_per_collection": nbytes, "view_ms": round((t1 - tc) * 1e3, 3),
+                        "GBps": round(nbytes / max(t1 - tc, 1e-9) / 1e9, 2),
+                        "note": "results view only (device-made arrays in one block, D2H into pinned memory); op bytes travel at one byte per op"}
         note["what"] = ("edlibAmdBatchResultsView (device-made arrays, one block D2H: %.3f ms) + edlibAmdBatchCigarView x 2 (%.3f ms); "
                         "ALREADY INSIDE ms_per_step for this config" % ((t1 - tc) * 1e3, (t2 - t1) * 1e3))
         note["ms_per_step_plus_one_collection"] = ms_per_step
@@ -438,7 +454,7 @@ def collection_note(collect_ms, ms_per_step):
 def run_step(cfg_id, batch):
     """one timed step: the device pass; for the PATH workload also the collection of everything a caller gets"""
     st = batch.run()
-    if cfg_id == 5:
+    if cfg_id in PATH_CONFIGS:
         batch.results_flat(copy=False)
         batch.cigars(True, copy=False)
         batch.cigars(False, copy=False)
@@ -473,7 +489,7 @@ def measure_secondary(cfg_id, device, torch, steps=5, warmup=2):
         dt = time.perf_counter() - t0
         out = report(cfg_id, w, st, scan_ms, launches, steps, warmup, dt, st["cells"] * steps / dt / 1e9, 1, "weak")
         out["collection"], flat = measure_collection(cfg_id, batch, out["ms_per_step"])
-        out["cpu_baseline"], out["parity_sample"] = cpu_baseline_and_parity(w, flat, w["n"], batch if cfg_id == 5 else None)
+        out["cpu_baseline"], out["parity_sample"] = cpu_baseline_and_parity(w, flat, w["n"] if cfg_id != 6 else 10000, batch if cfg_id == 5 else None)
     finally:
         batch.close()
     return out
@@ -599,7 +615,7 @@ def main():
         if args.share_gpu:
             out["dry_run_shared_gpu"] = True
         if not args.no_cpu_baseline:
-            sample = args.parity_sample if args.parity_sample is not None else (20000 if args.config == 2 else w["n"])
+            sample = args.parity_sample if args.parity_sample is not None else (20000 if args.config == 2 else (10000 if args.config == 6 else w["n"]))
             base, parity = cpu_baseline_and_parity(w, flat, sample, batch if args.config == 5 else None)
             if world > 1:
                 base["sample"] += "; rank 0's shard of a %d-rank run (the other ranks idle at the barrier meanwhile)" % world
@@ -634,11 +650,11 @@ def main():
     # default run carries a driver-visible line for them (value, rooflines, reference baseline, whole-batch parity)
     if rank == 0 and world == 1 and args.config == 2 and args.units is None and not args.no_secondary and not args.no_cpu_baseline:
         out["secondary"] = {}
-        for cid in (4, 5):
+        for cid in (4, 5, 6):
             try:
-                out["secondary"]["config%d" % cid] = measure_secondary(cid, device, torch)
+                out["secondary"]["config%s" % ("5x" if cid == 6 else cid)] = measure_secondary(cid, device, torch)
             except Exception as e:                                    # the headline line must survive
-                out["secondary"]["config%d" % cid] = {"error": "%s: %s" % (type(e).__name__, e)}
+                out["secondary"]["config%s" % ("5x" if cid == 6 else cid)] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:
             out["secondary"]["chromosome"] = measure_chromosome()
         except Exception as e:

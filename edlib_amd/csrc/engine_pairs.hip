@@ -100,10 +100,12 @@ int Batch::solveChunk(int mode, bool wantPositions, bool wantPath, const std::ve
     // A storing scan on 4-lane rings over a chunk that cannot fill the chip (edlibAlign() with TASK_PATH on a 1 kb pair is
     // one unit) is bound by the latency of its waves' instruction streams: it takes the rings of 32-row words and their
     // walk instead (ring32_kernels.hip, DESIGN.md 4d: 0.18 against 0.48 us per step, a walk of ~T / 32 trips).  Every unit
-    // of a 4-lane launch fits an 8-lane ring of words: at most 4 blocks = 8 words, or a band of K <= 128 <= ring32_max_k(8).
-    // (ring == kRing32: the caller asks for 16-lane rings of words -- bands up to K = 448 -- and has checked ring32_fits())
-    const int g32 = ring == kRing32 ? 16 : 8;
+    // of a 4-lane launch fits a ring of words: at most 4 blocks = 8 words on 8 lanes, or -- a unit of more words at the 4-lane
+    // ring's band limit of 196, above ring32_max_k(8) = 192 -- the band on 16 lanes (ring32_max_k(16) = 448).
+    // (ring == kRing32: the caller asks for 16-lane rings of words and has checked ring32_fits())
+    int g32 = ring == kRing32 ? 16 : 8;
     bool use32 = wantPath && (ring == 4 || ring == kRing32) && mode == EDLIB_MODE_NW && ring32_fits(units, ua, ub, g32);
+    if (!use32 && wantPath && ring == 4 && mode == EDLIB_MODE_NW && ring32_fits(units, ua, ub, 16)) { g32 = 16; use32 = true; }
     int maxWords32 = 1;
     for (size_t i = 0; use32 && i < n; ++i) maxWords32 = std::max(maxWords32, (units[ua + i].qlen + 31) / 32);
     if (ring == kRing32 && !use32) { set_error("ring32 level on units that do not fit it"); return 1; }

@@ -122,6 +122,9 @@ EDLIB_API void edlibAmdFreeResults(EdlibAlignResult* results, int n);
 /* Releases the process-wide cache of device / pinned blocks and idle streams the library keeps between calls. */
 EDLIB_API void edlibAmdTrim(void);
 
+/* Counters of the last Run.  The struct GROWS AT ITS END between versions of this library (wide_retries came last) and
+ * edlibAmdBatchStats() writes all of it: this additive surface is versioned with the library, not frozen like edlib.h --
+ * build clients against the header of the library they load. */
 typedef struct {
     double run_ms;          /* HIP-event time of the whole last Run on its stream           */
     double scan_ms;         /* HIP-event time of the dominant scan kernel(s) in that Run     */

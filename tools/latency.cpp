@@ -5,12 +5,17 @@
 // Shapes: the reference's own published single-call numbers are 100 x 100 and 1 k x 1 k
 // (/root/reference/bindings/python/README-tmpl.rst:194-215); 10 k x 10 k and a 150 bp read against 5 Mb (HW)
 // are the BASELINE.json shapes seen one call at a time.  Sequences: uniform ACGT, query = target with 5 % edits.
+//   build/latency <library.so> --threads N [scale]   calls per second with N host threads looping edlibAlign() concurrently
+//   (the caller this serves releases the GIL around the call: /root/reference/bindings/python/edlib.pyx:128-129): the small
+//   shapes only, every thread its own pair.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <dlfcn.h>
 #include <string>
+#include <thread>
 #include <vector>
+#include <cstring>
 
 struct EqPair { char a, b; };
 struct Config { int k, mode, task; const EqPair* eqs; int neq; };
@@ -29,6 +34,43 @@ int main(int argc, char** argv)
     align_fn align = (align_fn)dlsym(h, "edlibAlign");
     free_fn release = (free_fn)dlsym(h, "edlibFreeAlignResult");
     if (!align || !release) { fprintf(stderr, "no edlibAlign in %s\n", argv[1]); return 1; }
+    if (argc > 3 && !strcmp(argv[2], "--threads")) {
+        const int nt = atoi(argv[3]);
+        const double sc = argc > 4 ? atof(argv[4]) : 1.0;
+        struct S { const char* name; int m, mode, task, reps; };
+        const S small[] = {{"100 x 100 NW distance", 100, 0, 0, 2000}, {"100 x 100 NW path", 100, 0, 2, 2000},
+                           {"1k x 1k NW distance", 1000, 0, 0, 1000}, {"1k x 1k NW path", 1000, 0, 2, 500}};
+        printf("{\"library\": \"%s\", \"threads\": %d, \"calls_per_second\": {", argv[1], nt);
+        bool first = true;
+        for (const S& s : small) {
+            std::vector<std::string> qs(nt), ts(nt);
+            for (int k = 0; k < nt; ++k) {
+                ts[k].assign(s.m, 'A');
+                for (auto& c : ts[k]) c = "ACGT"[next() & 3];
+                for (int i = 0; i < s.m; ++i) {
+                    const unsigned r = next() % 100;
+                    if (r < 2) continue;
+                    if (r < 4) qs[k].push_back("ACGT"[next() & 3]);
+                    qs[k].push_back(r < 5 ? "ACGT"[next() & 3] : ts[k][i]);
+                }
+            }
+            const int reps = (int)(s.reps * sc) > 0 ? (int)(s.reps * sc) : 1;
+            Config cfg{-1, s.mode, s.task, nullptr, 0};
+            for (int k = 0; k < nt; ++k) { Result r = align(qs[k].data(), (int)qs[k].size(), ts[k].data(), s.m, cfg); release(r); }
+            std::vector<long long> chk(nt, 0);
+            const auto t0 = std::chrono::steady_clock::now();
+            std::vector<std::thread> th;
+            for (int k = 0; k < nt; ++k) th.emplace_back([&, k] {
+                for (int i = 0; i < reps; ++i) { Result r = align(qs[k].data(), (int)qs[k].size(), ts[k].data(), s.m, cfg); chk[k] += r.ed + r.status * 1000000; release(r); }
+            });
+            for (auto& t : th) t.join();
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            printf("%s\"%s\": %.0f", first ? "" : ", ", s.name, (double)reps * nt / sec);
+            first = false;
+        }
+        printf("}}\n");
+        return 0;
+    }
     const double scale = argc > 2 ? atof(argv[2]) : 1.0;
     struct Shape { const char* name; int m, T, mode, task, reps; };
     const Shape shapes[] = {
