@@ -127,6 +127,43 @@ def pair_case():
     return nq, compare(got, ref, task, "pairs mode=%s task=%s k=%d nq=%d base=%d sigma=%d" % (mode, task, k, nq, base, sig))
 
 
+def lane_case():
+    """a big NW distance batch of pairs of like lengths above 16 blocks over at most four symbols: the lane-per-pair level
+     -- its pack kernel, per-unit thresholds from the probe, wave-uniform trims over 64 different lanes, units it
+    leaves open (a divergent tail, unrelated pairs, foreign query bytes) and the rings that take them"""
+    nq = int(rng.choice([8192, 8200, 9000, 12000]))
+    base = int(rng.choice([1100, 1400, 2000, 3000]))
+    sig = int(rng.choice([2, 3, 4, 4, 4]))
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)[:sig]
+    bulk = float(rng.choice([0.003, 0.02, 0.05, 0.1]))
+    foreign = rng.random() < 0.3
+    qs, ts = [], []
+    for i in range(nq):
+        tn = int(base * (1.0 + 0.08 * rng.random()))
+        t = alpha[rng.integers(0, sig, tn)]
+        x = rng.random()
+        if x < 0.01:
+            q = alpha[rng.integers(0, sig, int(base * (1.0 + 0.08 * rng.random())))]
+        else:
+            rate = 0.3 if x < 0.03 else bulk * (0.5 + rng.random())
+            q = mutate(np.concatenate([t, alpha[rng.integers(0, sig, 64)]]), int(tn * (0.97 + 0.06 * rng.random())), rate)
+        if foreign and rng.random() < 0.02:
+            q = q.copy(); q[int(rng.integers(0, len(q)))] = ord("N")
+        qs.append(np.ascontiguousarray(q)); ts.append(np.ascontiguousarray(t))
+    k = int(rng.choice([-1, -1, -1, int(bulk * base), int(3 * bulk * base) + 20, 5000]))
+    what = "lane level: nq=%d base=%d sigma=%d bulk=%.3f k=%d foreign=%d" % (nq, base, sig, bulk, k, foreign)
+    trace(what)
+    b = edlib_amd.PairBatch(qs, ts, mode="NW", task="distance", k=k)
+    try:
+        b.run(); got = b.results_flat()
+    finally:
+        b.close()
+    qoff = np.zeros(nq + 1, dtype=np.int64); qoff[1:] = np.cumsum([len(r) for r in qs])
+    toff = np.zeros(nq + 1, dtype=np.int64); toff[1:] = np.cumsum([len(r) for r in ts])
+    ref = O.pool_align(np.concatenate(qs), qoff, np.concatenate(ts), toff, False, "NW", "distance", k)
+    return nq, compare(got, ref, "distance", what)
+
+
 def long_pair_case():
     """a few long pairs: the wide kernel (NW bands beyond the rings, two half scans, Hirschberg halves), SHW / HW queries
     of many strips, SHW inside the band of a threshold"""
@@ -180,7 +217,10 @@ def single_case():
 t0 = time.time(); cases = units = 0; failures = []
 while time.time() - t0 < budget and cases < max_cases:
     x = rng.random()
-    n, err = shared_case() if x < 0.5 else (pair_case() if x < 0.8 else (long_pair_case() if x < 0.9 else single_case()))
+    if os.environ.get("SOAK_ONLY") == "lane" or x > 0.97:
+        n, err = lane_case()
+    else:
+        n, err = shared_case() if x < 0.5 else (pair_case() if x < 0.8 else (long_pair_case() if x < 0.9 else single_case()))
     cases += 1; units += n
     if err:
         failures.append(err); print("MISMATCH", err, file=sys.stderr)
