@@ -333,7 +333,13 @@ def traffic_of(cfg_id, units):
     try:
         ent = json.load(open(tpath)).get("configs", {}).get(str(cfg_id))
         if ent and ent.get("units") == units:
-            return ent.get("bytes_per_step"), {"file": "profiles/hbm_traffic.json", "commit": ent.get("commit"),
+            head = None
+            try:                                  # (.git does not travel to the GPU box; tools/gpu_visit.sh leaves the commit of the visit)
+                head = open(os.path.join(ROOT, ".visit_commit")).read().strip() or None
+            except Exception:
+                pass
+            return ent.get("bytes_per_step"), {"file": "profiles/hbm_traffic.json", "commit": ent.get("commit"), "head": head,
+                                               "taken_at_head": (head is not None and str(ent.get("commit", "")).startswith(head[:7])) if head else None,
                                                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_visit.sh traffic) at "
                                                        "that commit, not measured inside this run"}
     except Exception:

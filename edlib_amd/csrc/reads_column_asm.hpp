@@ -65,6 +65,12 @@
 #define RC_TEMPS [t] "=&v"(t_), [s] "=&v"(s_), [xh] "=&v"(xh_), [ph0] "=&v"(ph0_), [ph1] "=&v"(ph1_), [mh0] "=&v"(mh0_), [mh1] "=&v"(mh1_), [phs] "=&v"(phs_), [mhs] "=&v"(mhs_), [xv] "=&v"(xv_), [cy] "=&s"(cy_)
 #define RC_SCORE_X(c) RC_SCORE(c)
 #define RC_COLUMN_ASM(N, WORD0) asm(RC_HEAD WORD0 RC_REST_##N RC_SCORE_X(RC_LAST_##N) : RC_OUTS_##N, [scoreN] "=&v"(scoreN), RC_TEMPS : RC_INS_##N, [score] "v"(score), [sh] "v"(sh))
+// the same column without a followed row (the band of scan_reads_banded_kernel below its full height)
+#define RC_COLUMN_ASM_NS(N, WORD0) asm(RC_HEAD WORD0 RC_REST_##N : RC_OUTS_##N, RC_TEMPS : RC_INS_##N)
+#define RC_COLUMN_DISPATCH_NS(NA, WORD0) \
+    if constexpr (NA == 1) RC_COLUMN_ASM_NS(1, WORD0); if constexpr (NA == 2) RC_COLUMN_ASM_NS(2, WORD0); if constexpr (NA == 3) RC_COLUMN_ASM_NS(3, WORD0); \
+    if constexpr (NA == 4) RC_COLUMN_ASM_NS(4, WORD0); if constexpr (NA == 5) RC_COLUMN_ASM_NS(5, WORD0); if constexpr (NA == 6) RC_COLUMN_ASM_NS(6, WORD0); \
+    if constexpr (NA == 7) RC_COLUMN_ASM_NS(7, WORD0); if constexpr (NA == 8) RC_COLUMN_ASM_NS(8, WORD0);
 #define RC_COLUMN_DISPATCH(NWD, WORD0) \
     if constexpr (NWD == 1) RC_COLUMN_ASM(1, WORD0); if constexpr (NWD == 2) RC_COLUMN_ASM(2, WORD0); if constexpr (NWD == 3) RC_COLUMN_ASM(3, WORD0); \
     if constexpr (NWD == 4) RC_COLUMN_ASM(4, WORD0); if constexpr (NWD == 5) RC_COLUMN_ASM(5, WORD0); if constexpr (NWD == 6) RC_COLUMN_ASM(6, WORD0); \

@@ -5,6 +5,7 @@
 #pragma once
 #include "lds_check.hpp"
 #include "reads_kernels.hpp"
+#include "reads_column_asm.hpp"
 
 namespace edlib_amd {
 
@@ -211,6 +212,23 @@ template <int NA, int NWD, bool CHAIN = false>
 __device__ __forceinline__ void column_step_hw(const u32 (&Eq)[NA], u32 (&Pv)[NWD], u32 (&Mv)[NWD],
                                                int& e, int& flag, const u32 sh, u32& cin, u32& cout)
 {
+    if constexpr (!CHAIN && NWD <= 8 && NA >= 2) {
+        // one asm statement of VOP3 encodings behind an alignment fence (reads_column_asm.hpp: a compiled column mixes 4- and
+        // 8-byte encodings, and a stream of full- and half-rate instructions only issues at the sum of their rates in one phase)
+        u32 t_, s_, xh_, ph0_, ph1_, mh0_, mh1_, phs_, mhs_, xv_, Pn[NA], Mn[NA];
+        unsigned long long cy_;
+        if constexpr (NA == NWD) {
+            int score = e, scoreN;
+            RC_COLUMN_DISPATCH(NA, RC_WORD0_HW)
+            e = scoreN;
+            flag |= e;
+        } else {
+            RC_COLUMN_DISPATCH_NS(NA, RC_WORD0_HW)
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) { Pv[i] = Pn[i]; Mv[i] = Mn[i]; }
+        return;
+    }
     u32 Ph[NA], Mh[NA];
     u32 carry = 0;
     u32 hpos = 0, hneg = 0;
