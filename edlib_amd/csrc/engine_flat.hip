@@ -183,7 +183,9 @@ int Batch::initFlatPairs()
         // kernel's 32-bit offsets reach, a Peq table per unit that fits a wave's LDS.  SHW / HW paths: queries of at most
         // 4 blocks = 8 words, whole on an 8-lane ring.
         flatMaxWords_ = maxWords;
-        flatRing32_ = store32 < 0xF0000000LL && ring32_lds_bytes(flatG32_, tab_.sigmaT, maxWords) <= 48 * 1024;
+        // NW (the phase-1 scan IS the storing scan): a batch whose store exceeds what 32-bit offsets reach runs in chunks of
+        // units, each scanned and walked before the next reuses the store (160,000 x 1 kb: 6.4 GB of store as two chunks)
+        flatRing32_ = (flatNwStore_ || store32 < 0xF0000000LL) && ring32_lds_bytes(flatG32_, tab_.sigmaT, maxWords) <= 48 * 1024;
     }
     flatStarts_ = cfg_.task != EDLIB_TASK_DISTANCE && mode == EDLIB_MODE_HW;
     PinBuf pin;
@@ -225,12 +227,18 @@ int Batch::initFlatPairs()
         // upper bounds that depend on the batch only, laid out once
         flatOpsOffHost_.assign((size_t)n_ + 1, 0);
         std::vector<long long> storeBase((size_t)n_);
-        long long entries = 0;
+        long long entries = 0, maxEntries = 0;
+        flatChunkStart_.assign(1, 0);
+        const long long chunkCap = 0xE0000000LL / 8;                      // 8-byte entries a ring32 launch can address
         for (int u = 0; u < n_; ++u) {
             flatOpsOffHost_[u + 1] = flatOpsOffHost_[u] + qlen(u) + window(u) + 8;
+            const long long e = flatRing32_ ? ring32_store_entries(flatG32_, qlen(u), window(u)) : ring_store_entries(flatRing_, qlen(u), window(u));
+            if (flatRing32_ && flatNwStore_ && entries + e > chunkCap && entries > 0) { flatChunkStart_.push_back(u); maxEntries = std::max(maxEntries, entries); entries = 0; }
             storeBase[u] = entries;
-            entries += flatRing32_ ? ring32_store_entries(flatG32_, qlen(u), window(u)) : ring_store_entries(flatRing_, qlen(u), window(u));
+            entries += e;
         }
+        flatChunkStart_.push_back(n_);
+        entries = std::max(maxEntries, entries);
         flatOpsTotal_ = flatOpsOffHost_[n_];
         EDLIB_AMD_HIP(d_flatOpsOff_.alloc((size_t)n_ + 1)); EDLIB_AMD_HIP(d_flatStoreBase_.alloc((size_t)n_));
         EDLIB_AMD_HIP(hipMemcpyAsync(d_flatOpsOff_.p, flatOpsOffHost_.data(), ((size_t)n_ + 1) * sizeof(long long), hipMemcpyHostToDevice, stream_));
@@ -286,16 +294,35 @@ int Batch::runPairsFlat(bool& overflowed, bool& fellBack)
         EDLIB_AMD_HIP(launch_target_symbols(d_tpool_.p, d_tlut_.p, (long long)d_tpool_.n, d_tsym_.p, stream_));
         a.tsym = d_tsym_.p;
     }
-    scanTimerStart();
-    if (ring32) EDLIB_AMD_HIP(launch_scan_pairs_ring32(flatG32_, true, a, flatMaxWords_, stream_));
-    else EDLIB_AMD_HIP(launch_scan_pairs_ring(flatRing_, scanMode, flatNwStore_, a, stream_));
-    scanTimerStop();
+    const bool chunked = ring32 && flatChunkStart_.size() > 2;
+    if (!chunked) {
+        scanTimerStart();
+        if (ring32) EDLIB_AMD_HIP(launch_scan_pairs_ring32(flatG32_, true, a, flatMaxWords_, stream_));
+        else EDLIB_AMD_HIP(launch_scan_pairs_ring(flatRing_, scanMode, flatNwStore_, a, stream_));
+        scanTimerStop();
+    }
     overflowed = false;
     if (flatNwStore_) {
         // NW paths: the distance scan was the storing scan (one band level); walk it, and see whether every unit got its answer
         TracebackArgs tb{};
         tb.descs = d_flatDescs_.p; tb.numUnits = n_; tb.score = d_flatOut3_.p; tb.store = d_store_.p;
         tb.ops = d_flatOps_.p; tb.opsOff = d_flatOpsOff_.p; tb.opsLen = d_flatOpsLen_.p;
+        if (chunked) {
+            // a store beyond the 32-bit offsets of the ring32 kernels: chunk by chunk, each scanned and walked before the next
+            // reuses the store (store offsets are relative to the chunk: initFlatPairs)
+            for (size_t c = 0; c + 1 < flatChunkStart_.size(); ++c) {
+                const int u0 = flatChunkStart_[c], nu = flatChunkStart_[c + 1] - u0;
+                PairScanArgs ac = a;
+                ac.descs = a.descs + u0; ac.numUnits = nu;
+                ac.outScore = a.outScore + u0; ac.outCount = a.outCount + u0; ac.outLast = a.outLast + u0;
+                scanTimerStart();
+                EDLIB_AMD_HIP(launch_scan_pairs_ring32(flatG32_, true, ac, flatMaxWords_, stream_));
+                scanTimerStop();
+                TracebackArgs tc = tb;
+                tc.descs = tb.descs + u0; tc.numUnits = nu; tc.score = tb.score + u0; tc.opsOff = tb.opsOff + u0; tc.opsLen = tb.opsLen + u0;
+                EDLIB_AMD_HIP(launch_traceback32(tc, flatG32_, stream_));
+            }
+        } else
         if (ring32) EDLIB_AMD_HIP(launch_traceback32(tb, flatG32_, stream_));
         else EDLIB_AMD_HIP(launch_traceback(tb, stream_));
         EDLIB_AMD_HIP(hipMemsetAsync(d_flatCensus_.p, 0, 2 * sizeof(int), stream_));
