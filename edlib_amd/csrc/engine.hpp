@@ -239,6 +239,7 @@ private:
     // k-doubling, edlib.cpp:197-217, with thresholds chosen for the hardware)
     // paths != null (TASK_PATH, every unit below the 1 MiB rule): the levels run with the column store and the traceback, so
     // that a unit's first successful level is also its path (one scan instead of the distance scan + the storing scan)
+    bool hwBandSplit_ = false;                   // solveSemiGlobal: the units its HW band does not take are on their way through it again
     int solveGlobalDistances(const std::vector<UnitSpec>& units, std::vector<int>& score, std::vector<OpsOut>* paths = nullptr);
     // SHW / HW units: short queries packed on 4- and 16-lane rings, the rest on the strips
     int solveSemiGlobal(int mode, bool wantPositions, const std::vector<UnitSpec>& units, SolveOut& out);

@@ -447,9 +447,33 @@ int Batch::solveSemiGlobal(int mode, bool wantPositions, const std::vector<UnitS
     }
     if (mode == EDLIB_MODE_HW && n > 0 && !(getenv("EDLIB_AMD_HWBAND") && getenv("EDLIB_AMD_HWBAND")[0] == '0')) {
         // a query in a window not much longer than itself, with a threshold well below its length: the band of solveHwBanded
-        bool any = false;
-        for (size_t i = 0; i < n && !any; ++i) any = hw_band_rows(units[i], std::min(units[i].kinit, 64)) + 64 <= 64LL * ((units[i].qlen + 63) / 64 - 1);
-        if (any) return solveHwBanded(wantPositions, units, out);
+        // (only the units that qualify: the others keep the path below, which cuts long targets into segments when the batch
+        // alone does not fill the chip -- a narrow-window unit next to a few long-target ones used to pull those past it)
+        std::vector<char> qual(n);
+        size_t nq = 0;
+        for (size_t i = 0; i < n; ++i) { qual[i] = hw_band_rows(units[i], std::min(units[i].kinit, 64)) + 64 <= 64LL * ((units[i].qlen + 63) / 64 - 1); nq += qual[i]; }
+        if (nq == n) return solveHwBanded(wantPositions, units, out);
+        if (nq > 0 && !hwBandSplit_) {
+            std::vector<UnitSpec> part[2]; std::vector<size_t> where(n);
+            for (size_t i = 0; i < n; ++i) { where[i] = part[qual[i]].size(); part[qual[i]].push_back(units[i]); }
+            SolveOut so[2];
+            if (solveHwBanded(wantPositions, part[1], so[1])) return 1;
+            hwBandSplit_ = true;                                    // (the rest: this function again, without the band)
+            const int rc = solveSemiGlobal(mode, wantPositions, part[0], so[0]);
+            hwBandSplit_ = false;
+            if (rc) return 1;
+            out.score.resize(n); out.count.resize(n); out.last.resize(n);
+            out.posStart.assign(n + 1, 0); out.posFlat.clear();
+            out.opsPtr.assign(n, nullptr); out.opsLen.assign(n, 0); out.opsBufs.clear();
+            for (size_t i = 0; i < n; ++i) {
+                const SolveOut& p = so[qual[i]];
+                const size_t q = where[i];
+                out.score[i] = p.score[q]; out.count[i] = p.count[q]; out.last[i] = p.last[q];
+                out.posFlat.insert(out.posFlat.end(), p.posFlat.begin() + p.posStart[q], p.posFlat.begin() + p.posStart[q + 1]);
+                out.posStart[i + 1] = (long long)out.posFlat.size();
+            }
+            return 0;
+        }
     }
     if (mode != EDLIB_MODE_HW || n == 0 || n >= 4096) return solveSemiGlobalUnits(mode, wantPositions, units, out);
     const long long smax = std::max<long long>(1, 8192 / (long long)n);

@@ -442,3 +442,23 @@ def test_prefix_bands_that_fill_rings_of_tall_lanes(engine, checker, H, K, m):
         qs.append(bytes(c2)); ts.append(b"T" * skip + core + synth.random_dna(rng.randrange(1 << 30), rng.randrange(0, 40)).tobytes())
     for k in (K, K + 1, K - 1):
         _check(engine, checker, qs, ts, "SHW", "locations", k, "tall ring lanes at their band limit")
+
+
+def test_hw_band_takes_only_the_units_that_qualify(engine, checker):
+    """a mixed HW batch: queries in windows barely longer than themselves (the static HW band) next to queries in long
+    windows (every block of every column, cut into target segments): each kind takes its own path (Batch::solveSemiGlobal
+    partitions the units), every field as the reference has it"""
+    rng = random.Random(5900 + SEED_SHIFT)
+    qs, ts = [], []
+    for i in range(12):
+        core = synth.random_dna(rng.randrange(1 << 30), 900 + rng.randrange(0, 300)).tobytes()
+        q = bytearray(core)
+        for j in rng.sample(range(len(q)), 6):
+            q[j] = ord("A") if q[j] != ord("A") else ord("C")
+        pad = 60 if i % 3 else 30000 + rng.randrange(0, 20000)           # narrow window / long window
+        left = synth.random_dna(rng.randrange(1 << 30), pad // 2).tobytes()
+        right = synth.random_dna(rng.randrange(1 << 30), pad - pad // 2).tobytes()
+        qs.append(bytes(q)); ts.append(left + core + right)
+    for task in ("distance", "locations", "path"):
+        for k in (20, -1):
+            _check(engine, checker, qs, ts, "HW", task, k, "mixed HW batch")
