@@ -780,7 +780,10 @@ int Batch::runLevelAll(const std::vector<UnitSpec>& units, int ring, int ringH, 
 int Batch::prepareLaneLevel(const std::vector<UnitSpec>& units)
 {
     laneReady_ = false;
-    if (tab_.sigmaT > 4) return 0;
+    // more than four target symbols in the batch (a genome with N, soft-masked stretches): every unit is coded from its own
+    // target's bytes -- identity equality only; with additional equalities a byte may equal several symbols
+    const bool perUnit = tab_.sigmaT > 4;
+    if (perUnit && (!tab_.eq8.empty() || tab_.sigmaT > 16)) return 0;       // (protein-sized alphabets: hardly a unit would stay within four)
     const size_t n = units.size();
     if (laneSpecsVersion_ != pairSpecsVersion_) {
         EDLIB_AMD_HIP(h_laneUnits_.alloc(n * sizeof(lanepair::LaneUnit)));
@@ -818,7 +821,7 @@ int Batch::prepareLaneLevel(const std::vector<UnitSpec>& units)
     EDLIB_AMD_HIP(hipEventRecord(evLevelIn_.e, stream_));           // the inputs and the units went up on stream_
     EDLIB_AMD_HIP(hipStreamWaitEvent(aux_, evLevelIn_.e, 0));
     lanepair::PackArgs pa{};
-    pa.qpool = d_qpool_.p; pa.tpool = d_tpool_.p; pa.tlut = d_tlut_.p; pa.eqtbl = d_eqtbl_.p; pa.sigmaT = tab_.sigmaT;
+    pa.qpool = d_qpool_.p; pa.tpool = d_tpool_.p; pa.tlut = d_tlut_.p; pa.eqtbl = d_eqtbl_.p; pa.sigmaT = tab_.sigmaT; pa.perUnit = perUnit ? 1 : 0;
     pa.units = d_laneUnits_.p; pa.numUnits = (int)n; pa.planes = d_lanePlanes_.p; pa.tgts = d_laneTgts_.p;
     pa.flags = d_laneFlags_.p; pa.alphaOut = fuseAlpha ? d_alphaOut_.p : nullptr;
     EDLIB_AMD_HIP(launch_lanepair_pack(pa, aux_));

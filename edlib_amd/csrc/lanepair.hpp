@@ -48,6 +48,8 @@ struct PackArgs {
     const uint8_t* tlut;      // [256] target byte -> symbol id
     const uint16_t* eqtbl;    // [256] query byte -> set of target symbols it equals
     int sigmaT;
+    int perUnit;              // 1: a unit's codes come from ITS target's distinct bytes (batches over more than four target symbols, identity
+                              // equality only): a genome with N or soft-masked stretches keeps the level for every unit that stays within four
     const LaneUnit* units;
     int numUnits;
     Plane2* planes;

@@ -73,6 +73,33 @@ lanepair_pack_kernel(const PackArgs a)
     __syncthreads();
     const LaneUnit un = a.units[u];
     bool foreign = false;
+    if (a.perUnit) {
+        // the unit's own alphabet: mark the bytes of its target, rank them (byte order), code = rank; a query byte outside
+        // takes the free code when there is one.  More than four: the unit stays on the rings.
+        __shared__ uint8_t tmark[256];
+        tmark[tid] = 0;
+        __syncthreads();
+        const uint8_t* t = a.tpool + un.toff;
+        for (int r0 = 16 * tid; r0 < un.T; r0 += 16 * 256) {
+            uint32_t w[4];
+            __builtin_memcpy(w, t + r0, 16);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) if (r0 + k < un.T) tmark[(w[k >> 2] >> (8 * (k & 3))) & 255u] = 1;
+        }
+        __syncthreads();
+        const bool mk = tmark[tid] != 0;
+        const unsigned long long bal = __ballot(mk);
+        if (lane == 0) cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int rank = __popcll(bal & ((1ull << lane) - 1ull));
+        for (int w2 = 0; w2 < wave; ++w2) rank += cnt[w2];
+        const int total = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        __syncthreads();                                   // (cnt is used again below)
+        tcode[tid] = (uint8_t)(mk ? (rank & 3) : 0);
+        qcode[tid] = (uint8_t)(mk ? (rank & 3) : (total < 4 ? 3 : 255));
+        if (total > 4) foreign = true;
+        __syncthreads();
+    }
     if (wave < 2) foreign = lanepair_pack_sequence<true>(a.qpool + un.qoff, un.m, qcode, mark, a.alphaOut != nullptr,
                                                          reinterpret_cast<uint32_t*>(a.planes + un.planeOff), lane, wave);
     else lanepair_pack_sequence<false>(a.tpool + un.toff, un.T, tcode, mark, a.alphaOut != nullptr,

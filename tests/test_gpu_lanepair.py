@@ -109,3 +109,21 @@ def test_config4_shape_sample(engine, checker):
     qs = [q.tobytes() for q in qs]; ts = [t.tobytes() for t in ts]
     got, st = _run(engine, qs, ts, -1)
     _compare(checker, qs, ts, -1, got, range(0, 10000, 199))
+
+
+def test_batches_over_more_than_four_symbols_code_every_unit_from_its_own_target(engine, checker):
+    """a genome-like batch: most pairs ACGT, some soft-masked (acgt: four symbols of their own, nine in the batch), some with
+    a run of N in the target (five symbols: those units stay on the rings), an N in a query whose target has none"""
+    rng = random.Random(6400 + SEED_SHIFT)
+    qs, ts = _batch(rng, 8300, 1400, 1600, lambda i: 0.04)
+    for i in range(0, 8300, 70):
+        qs[i] = qs[i].lower(); ts[i] = ts[i].lower()
+    for i in range(11, 8300, 50):
+        t = bytearray(ts[i]); t[300:340] = b"N" * 40; ts[i] = bytes(t)
+    for i in range(23, 8300, 90):
+        q = bytearray(qs[i]); q[100] = ord("N"); qs[i] = bytes(q)
+    got, _ = _run(engine, qs, ts, -1)
+    idx = list(range(0, 8300, 70))[:40] + list(range(11, 8300, 50))[:40] + list(range(23, 8300, 90))[:30] + list(range(1, 8300, 157))
+    _compare(checker, qs, ts, -1, got, idx)
+    ring, _ = _run(engine, qs, ts, -1, {"EDLIB_AMD_LANEPAIR": "0"})
+    assert np.array_equal(ring["editDistance"], got["editDistance"]) and np.array_equal(ring["alphabetLength"], got["alphabetLength"])

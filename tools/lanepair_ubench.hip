@@ -83,7 +83,7 @@ int main(int argc, char** argv)
     CK(hipMemcpy(d_lu, lu.data(), sizeof(LaneUnit) * units, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 
-    PackArgs pa{}; pa.qpool = d_q; pa.tpool = d_t; pa.tlut = d_tlut; pa.eqtbl = d_eq; pa.sigmaT = 4;
+    PackArgs pa{}; pa.qpool = d_q; pa.tpool = d_t; pa.tlut = d_tlut; pa.eqtbl = d_eq; pa.sigmaT = 4; pa.perUnit = 0;
     pa.units = d_lu; pa.numUnits = units; pa.planes = d_pl; pa.tgts = d_tg; pa.flags = d_flags; pa.alphaOut = d_alpha;
     float packMs = 1e9f;
     for (int r = 0; r < reps; ++r) {
