@@ -796,6 +796,7 @@ int Batch::prepareLaneLevel(const std::vector<UnitSpec>& units)
             lu[i] = lanepair::LaneUnit{u.qoff, u.toff, pw, tw, u.qlen, u.tlen};
             pw += (u.qlen + 31) / 32; tw += (u.tlen + 31) / 32;
         }
+        plain = plain && pw < (1LL << 31) && tw < (1LL << 31);         // (32-bit offsets into the plane pools)
         lanePlaneWords_ = plain ? pw : -1; laneTgtWords_ = tw;
         laneSpecsVersion_ = pairSpecsVersion_;
         if (!plain) return 0;

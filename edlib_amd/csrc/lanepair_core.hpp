@@ -176,6 +176,7 @@ struct LaneCtl {
     int wi;                   // index of the plane word that holds the row below the window's bottom
     u32 sh;                   // bit offset of the window's rows inside the plane words (constant: top moves by 32)
     Plane2 lo;                // plane word wi
+    u32 planeOff, tgtOff;     // the unit's first Plane2 / Tgt2 in the pools
 };
 
 LP_FN int lp_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -200,15 +201,18 @@ LP_FN int lp_final_score(const Window<W>& L, const LaneCtl& s)
 // 32 columns (c0 .. c0 + 31; a lane stops at its own T), then the dead tests, the slide and the trims.
 // Returns the number of active words of the next block.  `more` = this lane has columns beyond the block.
 template <int W, int NA>
-LP_FN int lp_block(Window<W>& L, LaneCtl& s, Tgt2& tg, const Tgt2* tgt, const int nblkOwn, const int b, const Plane2* planes, const int nplanes, const u32 deny)
+LP_FN int lp_block(Window<W>& L, LaneCtl& s, Tgt2& tg, const Tgt2* tgt, const int b, const Plane2* planes, const u32 deny)
 {
     const int c0 = 32 * b;
     // what the previous block requested has had 32 columns to arrive; waiting HERE keeps every s_waitcnt (4 bytes) out of
     // the column loop, where it would flip the code's phase (LP_PHASE_FENCE).  Then this block's requests: the target
     // planes of the next 32 columns and the plane word the slide may take.
     LP_WAIT_LOADS();
-    const Tgt2 tnext = tgt[b + 1 < nblkOwn ? b + 1 : nblkOwn - 1];
-    const Plane2 hiPre = planes[lp_clampi(s.wi + 1, 0, nplanes - 1)];
+    // (`planes` / `tgt` are the POOLS -- wave-uniform, scalar registers -- and the lane's own 32-bit offsets into them sit in
+    // LaneCtl; the unit's word counts are recomputed from m and T: every register that lives through the scan counts)
+    const int nblkOwn = s.T > 0 ? (s.T + 31) >> 5 : 1, nplanes = (s.m + 31) >> 5;
+    const Tgt2 tnext = tgt[s.tgtOff + (u32)(b + 1 < nblkOwn ? b + 1 : nblkOwn - 1)];
+    const Plane2 hiPre = planes[s.planeOff + (u32)lp_clampi(s.wi + 1, 0, nplanes - 1)];
     u32 t0 = tg.t0, t1 = tg.t1;
 #pragma unroll 1
     for (int j = 0; j < 32; ++j) {
@@ -275,8 +279,10 @@ LP_FN int lp_band_words(int m, int T, int K)
 }
 
 template <int W>
-LP_FN void lp_init(Window<W>& L, LaneCtl& s, const int m, const int T, const int K, const int naInit, const Plane2* planes, const int nplanes)
+LP_FN void lp_init(Window<W>& L, LaneCtl& s, const int m, const int T, const int K, const int naInit, const Plane2* planes, const u32 planeOff, const u32 tgtOff)
 {
+    const int nplanes = (m + 31) >> 5;
+    s.planeOff = planeOff; s.tgtOff = tgtOff;
     s.m = m; s.T = T; s.K = K; s.delta = T - m;
     const int ad = s.delta < 0 ? -s.delta : s.delta;
     const int p = (K - ad) >> 1;
@@ -285,10 +291,10 @@ LP_FN void lp_init(Window<W>& L, LaneCtl& s, const int m, const int T, const int
     s.top = off;
     s.sh = (u32)off & 31u;
     const int wi0 = off >> 5;                         // floor
-    Plane2 prev = planes[lp_clampi(wi0, 0, nplanes - 1)];
+    Plane2 prev = planes[planeOff + (u32)lp_clampi(wi0, 0, nplanes - 1)];
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-        const Plane2 nx = planes[lp_clampi(wi0 + j + 1, 0, nplanes - 1)];
+        const Plane2 nx = planes[planeOff + (u32)lp_clampi(wi0 + j + 1, 0, nplanes - 1)];
         L.Q0[j] = lp_alignbit(nx.q0, prev.q0, s.sh);
         L.Q1[j] = lp_alignbit(nx.q1, prev.q1, s.sh);
         prev = nx;
@@ -300,7 +306,7 @@ LP_FN void lp_init(Window<W>& L, LaneCtl& s, const int m, const int T, const int
     }
     s.score = 0x3fffffff;
     s.wi = wi0 + naInit;
-    s.lo = planes[lp_clampi(s.wi, 0, nplanes - 1)];
+    s.lo = planes[planeOff + (u32)lp_clampi(s.wi, 0, nplanes - 1)];
     s.sb = off + 32 * naInit;                         // D[r][-1] = r + 1 at the bottom row r = off + 32 naInit - 1
 }
 
@@ -315,26 +321,26 @@ LP_FN void lp_init(Window<W>& L, LaneCtl& s, const int m, const int T, const int
                 if (denySeed == 0xffffffffu) deny = 3u;                                                     \
                 else if (denySeed) { denySeed = denySeed * 1664525u + 1013904223u; deny = (denySeed >> 28) & 3u; } \
                 steps += N;                                                                                 \
-                na = lp_uniform(lp_block<W, N>(L, s, tg, tgt, nblkOwn, b, planes, nplanes, deny));          \
+                na = lp_uniform(lp_block<W, N>(L, s, tg, tgt, b, planes, deny));                                    \
                 ++b;                                                                                        \
             } while (na == N && b < nblkWave);                                                              \
         }                                                                                                   \
     }
 
-// The whole scan of one lane.  tgt: the lane's target as bit planes (Tgt2 per 32 columns, ceil(T / 32) entries).
+// The whole scan of one lane.  planes / tgt: the pools; planeOff / tgtOff: where the lane's query planes (ceil(m / 32) entries)
+// and target planes (ceil(T / 32) entries) start in them.
 // naWave / nblkWave: wave-uniform (the device passes the wave's maxima).  denySeed (tests): trims are refused in blocks
 // where an LCG says so -- a lane must stay exact when the wave does not follow its vote; 0xffffffff = never trim.
 template <int W>
-LP_FN int lp_scan(const Plane2* planes, const int nplanes, const Tgt2* tgt, const int m, const int T, const int K,
+LP_FN int lp_scan(const Plane2* planes, const u32 planeOff, const Tgt2* tgt, const u32 tgtOff, const int m, const int T, const int K,
                   const int naWave, const int nblkWave, u32 denySeed, int* wordSteps)
 {
     Window<W> L;
     LaneCtl s;
-    lp_init<W>(L, s, m, T, K, naWave, planes, nplanes);
+    lp_init<W>(L, s, m, T, K, naWave, planes, planeOff, tgtOff);
     int na = naWave;
     long long steps = 0;
-    const int nblkOwn = T > 0 ? (T + 31) / 32 : 1;
-    Tgt2 tg = tgt[0];
+    Tgt2 tg = tgt[tgtOff];
     int b = 0;
     LP_STAGE(48) LP_STAGE(47) LP_STAGE(46) LP_STAGE(45) LP_STAGE(44) LP_STAGE(43) LP_STAGE(42) LP_STAGE(41) LP_STAGE(40) LP_STAGE(39)
     LP_STAGE(38) LP_STAGE(37) LP_STAGE(36) LP_STAGE(35) LP_STAGE(34) LP_STAGE(33) LP_STAGE(32) LP_STAGE(31) LP_STAGE(30) LP_STAGE(29)

@@ -131,17 +131,14 @@ lanepair_scan_kernel(const ScanArgs a)
     if (need > W || (a.flags && have && a.flags[idx])) need = 0;
     const bool live = need > 0;
     int m = un.m, T = un.T, K = Kl;
-    const Plane2* planes = a.planes + un.planeOff;
-    const Tgt2* tgt = a.tgts + un.tgtOff;
-    int nplanes = (un.m + 31) / 32;
-    if (!live) { m = 1; T = 0; K = 0; nplanes = 1; }            // never active: reads its unit's first words, writes nothing
+    if (!live) { m = 1; T = 0; K = 0; }                          // never active: reads its unit's first words, writes nothing
     const int naWave = lp_wave_max(need < 3 ? (live ? 3 : 0) : need);
     const int nblkWave = lp_wave_max(live ? (T + 31) / 32 : 0);
     int score = kNoBand;
     if (naWave > 0) {
         int ws = 0;
         unsigned deny = a.denySeed;
-        const int got = lp_scan<W>(planes, nplanes, tgt, m, T, K, naWave, nblkWave, deny, &ws);
+        const int got = lp_scan<W>(a.planes, (u32)un.planeOff, a.tgts, (u32)un.tgtOff, m, T, K, naWave, nblkWave, deny, &ws);
         if (live) score = got <= Kl ? got : (Kl >= a.kcap ? kAboveFinal : kAboveOpen);
         if (a.wordSteps && lane == 0) atomicAdd(a.wordSteps, (unsigned long long)ws * 32ull * 64ull);
     }

@@ -11,7 +11,7 @@ using namespace edlib_amd::lanepair;
 template <int W>
 static int run(const std::vector<Plane2>& planes, const std::vector<Tgt2>& tgt, int m, int T, int K, int na, int nblk, unsigned deny, int* ws)
 {
-    return lp_scan<W>(planes.data(), (int)planes.size(), tgt.data(), m, T, K, na, nblk, deny, ws);
+    return lp_scan<W>(planes.data(), 0u, tgt.data(), 0u, m, T, K, na, nblk, deny, ws);
 }
 
 // q, t: symbol codes 0..3.  extraWords / extraBlocks: the wave's maxima exceed this lane's own needs by that much.

@@ -117,7 +117,7 @@ int main(int argc, char** argv)
         for (int c = 0; c < len; ++c) { const u32 s = tlut[tpool[(size_t)i * len + c]]; tg[c >> 5].t0 |= (s & 1u) << (c & 31); tg[c >> 5].t1 |= ((s >> 1) & 1u) << (c & 31); }
         const int na = lp_band_words((int)qs[i].size(), len, K);
         int want = kNoBand;
-        if (na > 0 && na <= W) want = lp_scan<48>(pl.data(), (int)pl.size(), tg.data(), (int)qs[i].size(), len, K, na < 3 ? 3 : na, (len + 31) / 32, 0u, nullptr);
+        if (na > 0 && na <= W) want = lp_scan<48>(pl.data(), 0u, tg.data(), 0u, (int)qs[i].size(), len, K, na < 3 ? 3 : na, (len + 31) / 32, 0u, nullptr);
         ++checked;
         // exact iff <= K: the device may hold more words than the lane alone (wave maxima), so values above K may differ
         if (want <= K ? score[i] == want : score[i] >= kAboveFinal) ++equal;
