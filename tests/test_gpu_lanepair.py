@@ -127,3 +127,38 @@ def test_batches_over_more_than_four_symbols_code_every_unit_from_its_own_target
     _compare(checker, qs, ts, -1, got, idx)
     ring, _ = _run(engine, qs, ts, -1, {"EDLIB_AMD_LANEPAIR": "0"})
     assert np.array_equal(ring["editDistance"], got["editDistance"]) and np.array_equal(ring["alphabetLength"], got["alphabetLength"])
+
+
+def test_thresholds_at_the_edges_of_the_windows(engine, checker):
+    """fixed k right at what a window holds (32 W - 32: 480 / 736 / 1312 / 1504) and one beyond, on pairs whose distances
+    straddle it: the level scans with the cap, answers above it climb the rings or are final (> k)"""
+    rng = random.Random(6500 + SEED_SHIFT)
+    for length, rate, ks in ((4000, 0.04, (479, 480, 481)), (6000, 0.04, (735, 736, 737)), (11000, 0.04, (1311, 1312, 1313)), (12500, 0.04, (1503, 1504, 1505))):
+        qs, ts = _batch(rng, 8192, length - 100, length + 100, lambda i: rate * (0.8 + 0.4 * ((i * 7919) % 100) / 100.0))
+        idx = list(range(0, 8192, 431))
+        for k in ks:
+            got, _ = _run(engine, qs, ts, k)
+            _compare(checker, qs, ts, k, got, idx)
+
+
+def test_tiny_caps_identical_pairs_and_long_units(engine, checker):
+    rng = random.Random(6600 + SEED_SHIFT)
+    # (a) identical pairs and pairs one edit apart under k = 0 / 1 / 2
+    qs, ts = _batch(rng, 8200, 1200, 1300, lambda i: 0.0)
+    for i in range(0, 8200, 3):
+        q = bytearray(qs[i]); q[len(q) // 2] = ord("A") if q[len(q) // 2] != ord("A") else ord("C"); qs[i] = bytes(q)
+    for i in range(1, 8200, 3):
+        qs[i] = qs[i][:600] + qs[i][601:]
+    for k in (0, 1, 2, -1):
+        got, _ = _run(engine, qs, ts, k)
+        _compare(checker, qs, ts, k, got, range(0, 8200, 97))
+    # (b) 40 kb pairs at 2 %: 1,250 blocks of 32 columns, thresholds around 900
+    qs, ts = _batch(rng, 8192, 39000, 41000, lambda i: 0.007)
+    got, _ = _run(engine, qs, ts, -1)
+    _compare(checker, qs, ts, -1, got, range(0, 8192, 683))
+    # (c) lengths that differ by up to the like-lengths limit, and queries much shorter than their targets (no band within the threshold)
+    qs, ts = _batch(rng, 8300, 2000, 2400, lambda i: 0.03)
+    for i in range(5, 8300, 40):
+        qs[i] = qs[i][: len(qs[i]) - 350]
+    got, _ = _run(engine, qs, ts, -1)
+    _compare(checker, qs, ts, -1, got, list(range(5, 8300, 40))[:60] + list(range(0, 8300, 211)))
