@@ -11,7 +11,7 @@
 //     two bit planes Q0, Q1 per word), updated top-down with one add-carry chain (the whole window is one long Myers
 //     word: no hin / hout between words, no cross-lane traffic);
 //   * Eq is SYNTHESISED: the lane's target symbol of the column as two all-ones / all-zeros masks s0, s1 gives
-//     Eq = ~(Q0 ^ s0) & ~(Q1 ^ s1) -- one v_xor + one v_bitop3: no Peq, no LDS;
+//     ~Eq = (Q1 ^ s1) | (Q0 ^ s0) -- two v_bitop3: no Peq, no LDS;
 //   * the window follows the diagonal: every 32 columns (at the same column for all lanes) the words move up one
 //     register and a fresh word enters below as "+1 per row" (the reference's new block, edlib.cpp:803-808).  The row
 //     the window starts on is PRIVATE to the lane (top = 32 * (c / 32) - dmax of ITS band): lanes never meet, so nothing
@@ -117,15 +117,11 @@ LP_FN u32 lp_bitop3_host(u32 a, u32 b, u32 c, u32 imm)
 
 // One column over the NA active words, top-down.  hin at the window's top is +1: row -1 of NW while the window still
 // starts above the matrix, a cell outside the band afterwards (edlib.cpp:779).  12 VALU ops per word (9 full rate + the
-// add-carry and two v_alignbit at half rate):
-//   A: x = Q0 ^ s0 . ne = (Q1 ^ s1) | x  (= ~Eq) . t = Pv & ~ne . s = t + Pv + carry
-//   B: Xh = (s ^ Pv) | ~ne . Mh = Pv & Xh . Ph = Mv | ~(Xh | Pv)
-//   C: ph, mh = Ph, Mh << 1 across words . Xv = ~ne | Mv . Pv' = mh | ~(Xv | ph) . Mv' = ph & Xv
-// A wave has one or two neighbours on its SIMD (the window is 4 registers per word), so the dependent issue latency of
-// ~7 cycles is the wave's own to hide: the words are SOFTWARE-PIPELINED -- group g runs stage A of word g, stage B of
-// word g - 1 and stage C of word g - 2, written instruction by instruction across the three stages, so that every
-// instruction's producer is three instructions back.  (Word by word, as the recurrence reads, the first build ran at
-// 67-90 SIMD cycles per word-column against the 30 its instructions take: tools/lanepair_ubench.hip.)
+// add-carry and two v_alignbit at half rate).  On the device the column is ONE asm statement per window height
+// (lanepair_asm.hpp: VOP3 encodings behind an alignment fence, the words software-pipelined three deep -- a wave has one
+// neighbour on its SIMD at most, so the ~7-cycle dependent-issue latency is its own to hide; word by word, as the recurrence
+// reads and as the host path below spells it, the first build ran at 67-90 SIMD cycles per word-column against the 30 its
+// instructions take: tools/lanepair_ubench.hip).
 template <int W, int NA>
 LP_FN void lp_column(Window<W>& L, const u32 t0, const u32 t1, int& sb)
 {
@@ -205,7 +201,7 @@ LP_FN int lp_block(Window<W>& L, LaneCtl& s, Tgt2& tg, const Tgt2* tgt, const in
 {
     const int c0 = 32 * b;
     // what the previous block requested has had 32 columns to arrive; waiting HERE keeps every s_waitcnt (4 bytes) out of
-    // the column loop, where it would flip the code's phase (LP_PHASE_FENCE).  Then this block's requests: the target
+    // the column loop (lanepair_asm.hpp: the phase of the code).  Then this block's requests: the target
     // planes of the next 32 columns and the plane word the slide may take.
     LP_WAIT_LOADS();
     // (`planes` / `tgt` are the POOLS -- wave-uniform, scalar registers -- and the lane's own 32-bit offsets into them sit in
