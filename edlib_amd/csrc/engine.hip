@@ -290,12 +290,24 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
     const bool readsOk = shared_ && tlen(0) > 0 && (tab_.sigmaT <= 4 || (tab_.sigmaT <= 16 && modeIn == EDLIB_MODE_HW));
     syms_ = tab_.sigmaT <= 4 ? 4 : (tab_.sigmaT <= 8 ? 8 : 16);
     banded_ = mode == EDLIB_MODE_HW;
-    // HW queries longer than kernel A's 256 rows against the shared target: piece filter + window verification
-    // (long_reads.hip); EDLIB_AMD_FILTER=0 restores the groups of 12 / 16 / 24 / 32 words (up to 1024 bases) and kernel W
-    static const bool filterOn = !(getenv("EDLIB_AMD_FILTER") && getenv("EDLIB_AMD_FILTER")[0] == '0');
-    const bool filter = filterOn && readsOk && banded_ && modeIn == EDLIB_MODE_HW;
-    const int maxReadLen = 32 * ((banded_ && modeIn == EDLIB_MODE_HW && syms_ <= 8 && !filter)
-                                     ? (syms_ == 4 ? kMaxLongReadWords4 : kMaxLongReadWords) : kMaxReadWords);
+    // Long HW queries against the shared target: piece filter + window verification (long_reads.hip) from kFilterFromWords
+    // words on; below that the banded groups of kernel A.  257..384 bases on the 12-word group: 50.7 / 53.5 / 59.7 ms per
+    // 16,384 reads of 257 / 300 / 384 bases against 54.6 / 73.2 / 73.0 through the filter; from 385 on (16 KB of LDS rows per
+    // wave) the two are level, and from 513 the filter wins 109 to 189.  EDLIB_AMD_FILTER=<words> moves the switch (9 = rounds
+    // 3-5: everything above 256 bases), EDLIB_AMD_FILTER=0 restores round 2's routing (groups of 12 / 16 / 24 / 32 words up
+    // to 1024 bases, kernel W above).
+    static const int filterFrom = [] {
+        const char* e = getenv("EDLIB_AMD_FILTER");
+        if (!e || !e[0]) return kFilterFromWords;
+        const int v = atoi(e);
+        return v <= 0 ? 0 : std::max(kMaxReadWords + 1, std::min(v, kMaxLongReadWords4 + 1));
+    }();
+    const bool filter = filterFrom > 0 && readsOk && banded_ && modeIn == EDLIB_MODE_HW;
+    int groupWords = kMaxReadWords;              // the tallest group of kernel A that takes reads of this batch
+    if (banded_ && modeIn == EDLIB_MODE_HW && syms_ <= 8)
+        for (int w : {12, 16, 24, 32})
+            if (w <= (syms_ == 4 ? kMaxLongReadWords4 : kMaxLongReadWords) && (!filter || w < filterFrom)) groupWords = w;
+    const int maxReadLen = 32 * groupWords;
     std::vector<std::vector<int>> byWords(kMaxLongReadWords4 + 1);
     for (int u = 0; u < n; ++u) {
         const int m = qlen(u), T = tlen(u);

@@ -1,4 +1,5 @@
-// long_reads.hip -- HW queries longer than kernel A's 256 rows against the shared target.
+// long_reads.hip -- long HW queries against the shared target (385 rows and more by default: engine.hip, kFilterFromWords;
+// 257..384 rows run on kernel A's 12-word group, which is as fast or faster there).
 //
 // What the reference does for such a query (edlib.cpp:197-217, 550-704): myersCalcEditDistanceSemiGlobal over the whole
 // target inside Ukkonen's band for k = 64, 128, ... until the distance fits.  The band of a semi-global scan is anchored

@@ -12,6 +12,7 @@ constexpr int kMaxReadWords = 8;      // queries up to 256 symbols: one kernel i
 // the group's last four (eight) words
 constexpr int kMaxLongReadWords = 16;       // targets of 5..8 symbols
 constexpr int kMaxLongReadWords4 = 32;      // targets of up to 4 symbols
+constexpr int kFilterFromWords = 13;        // HW queries of this many words and more take the piece filter (long_reads.hip)
 inline int read_group_words(int m) { const int w = (m + 31) / 32; return w <= kMaxReadWords ? w : (w <= 12 ? 12 : (w <= 16 ? 16 : (w <= 24 ? 24 : 32))); }
 constexpr int kLanes = 64;            // wave64, hard-coded (gfx950)
 

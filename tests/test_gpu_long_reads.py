@@ -285,6 +285,34 @@ def test_round2_word_groups_still_agree():
     assert p.returncode == 0 and "ok" in p.stdout, p.stdout[-800:] + p.stderr[-2000:]
 
 
+def test_filter_from_257_bases_still_agrees():
+    """EDLIB_AMD_FILTER=9 moves the switch back to where rounds 3-5 had it: reads of 257..384 bases through the piece filter
+    (the default keeps them on kernel A's 12-word group: test_reads_of_257_to_384_bases_stay_on_the_lanes)"""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, edlib_amd\nfrom edlib_amd import synth\nfrom test_gpu_long_reads import _reads, _check\n"
+            "t = synth.random_dna(219, 30000)\n"
+            "r = _reads(t, [257, 288, 300, 320, 321, 352, 383, 384] * 12, 220, unrelated_every=9)\n"
+            "for task in ('distance', 'path'):\n"
+            "    st = _check(edlib_amd, r, t, task); assert st['path'] & 4, st\nprint('ok')\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, EDLIB_AMD_FILTER="9"))
+    assert p.returncode == 0 and "ok" in p.stdout, p.stdout[-800:] + p.stderr[-2000:]
+
+
+@pytest.mark.parametrize("task", ["distance", "locations", "path"])
+def test_reads_of_257_to_384_bases_stay_on_the_lanes(engine, task):
+    """the 12-word group of kernel A (4- and 5-symbol targets) takes them; 385 bases and more go through the filter"""
+    for target in (synth.random_dna(221, 60_000), synth.masked_genome(222, 60_000, frac_lower=0.0)):
+        rng = np.random.default_rng(223)
+        lengths = [257, 258, 288, 289, 320, 321, 352, 353, 383, 384] * 3 + [int(x) for x in rng.integers(257, 385, 200)]
+        reads = _reads(target, lengths, 224, unrelated_every=8, max_err=0.06)
+        st = _check(engine, reads, target, task)
+        assert st["path"] & 1 and not st["path"] & 4, st          # (bit 1: the pair kernels of start locations / paths)
+        st = _check(engine, reads + _reads(target, [385, 386, 400], 225), target, task)
+        assert st["path"] & 4 and st["path"] & 1, st
+
+
 def test_tall_unrelated_queries_on_chained_strips(engine):
     """queries the filter hands back that are taller than the lane kernel's 32 words run as strips of 1024 rows chained
     through HBM (long_reads.hip: solveTallFull); EDLIB_AMD_TALL_MIN_WAVES=1 lets a small batch take that path.  Unrelated

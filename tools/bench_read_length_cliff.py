@@ -20,9 +20,10 @@ ap.add_argument("--lengths", default="150,256,257,300,384,512,513,768,1024,1025,
 ap.add_argument("--n", type=int, default=16384)
 ap.add_argument("--sample", type=int, default=24, help="reads per batch checked against the reference")
 ap.add_argument("--no-extra", action="store_true")
+ap.add_argument("--masked", action="store_true", help="ACGT + runs of N (five symbols: the eight-row Peq layout)")
 args = ap.parse_args()
 
-T = synth.random_dna(12345, 5_000_000)
+T = synth.masked_genome(12345, 5_000_000, frac_lower=0.0) if args.masked else synth.random_dna(12345, 5_000_000)
 toff = np.array([0, len(T)], dtype=np.int64)
 out = {}
 
