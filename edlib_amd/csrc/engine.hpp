@@ -392,7 +392,7 @@ void finalize_global(UnitResult& r, int kcfg, int mode, int T, int score);
 long long hw_band_rows(const UnitSpec& u, long long K);     // rows per column of the HW band of threshold K
 // helpers shared by engine.hip and long_reads.hip
 int roundup(int x, int q);
-void plan_segments(int nlanes, int T, int mode, int warmFull, long long wantWaves, int& S, int& segLen, int& warm);
+void plan_segments(int nlanes, int T, int mode, int warmFull, long long wantWaves, int& S, int& segLen, int& warm, int minSegCols = 4096);
 // waves of the 24- / 32-word full-height lane kernels (24 / 32 KB of LDS rows each) the chip runs without two of them sharing
 // a SIMD: one per SIMD of 256 CUs (swept in round 4: DESIGN.md 3c)
 inline long long tall_round_waves() { return 1024; }

@@ -86,13 +86,13 @@ int Batch::scanGroup(ReadGroup& g, int mode, const int* d_slotmap, int nlanes, i
 
 // segmentation of a launch over `nlanes` lanes: enough waves to fill the chip, segments >= 4096 columns
 void plan_segments(int nlanes, int T, int mode, int warmFull, long long wantWaves,
-                          int& S, int& segLen, int& warm)
+                          int& S, int& segLen, int& warm, int minSegCols)
 {
     S = 1; segLen = roundup(T, 16); warm = 0;
     if (mode != EDLIB_MODE_HW) return;
     const long long nrblk = ((long long)nlanes + 63) / 64;
     long long want = (wantWaves + nrblk - 1) / nrblk;
-    want = std::max(1LL, std::min<long long>(want, std::min(65535, std::max(1, T / 4096))));   // gridDim.y limit
+    want = std::max(1LL, std::min<long long>(want, std::min(65535, std::max(1, T / minSegCols))));   // gridDim.y limit
     if (warmFull > 0) want = std::max(1LL, std::min<long long>(want, std::max<long long>(1, T / (4LL * warmFull))));   // >= four warm-ups per segment
     segLen = roundup((int)((T + want - 1) / want), 16);
     S = (T + segLen - 1) / segLen;
@@ -134,7 +134,9 @@ int Batch::runGroupScans(ReadGroup& g, bool fullOnly)
         // full scan, unresolved units then pay the full scan on top).  Probe 2048 evenly strided slots
         // first (0.2 % of the work at 1M reads) and fall back to one full-threshold pass if fewer than
         // 30 % of them resolve (e.g. noisy long-read chemistry, unrelated sequences).
-        const int np = 2048;
+        // (2048 slots are an eighth of a 16,384-read batch: 2.5 of its 28.6 ms, and 8 MB of per-segment results to walk;
+        // smaller batches probe a 32nd of their slots, at least 512)
+        const int np = std::max(512, std::min(2048, g.nslots / 32));
         std::vector<int> probe(np);
         for (int i = 0; i < np; ++i) probe[i] = (int)((long long)i * g.nslots / np);
         // best score of the probe slots in `map` with thresholds capped at kc (-1: nothing <= kc)
@@ -362,7 +364,9 @@ int Batch::runGroupExact(ReadGroup& g)
     const size_t no = g.ovfSlots.size();
     if (!no) return 0;
     int S2, segLen2, warm2;
-    plan_segments((int)no, T, mode, g.warm, 16384, S2, segLen2, warm2);
+    // (a handful of slots is a handful of waves per segment: the pass takes what ONE wave takes for its segment, so the
+    // segments go down to four warm-ups -- 18 slots of a 16,384-read batch: 2 x 0.83 ms at 4,112 columns)
+    plan_segments((int)no, T, mode, g.warm, 16384, S2, segLen2, warm2, no <= 256 ? 1024 : 4096);
     const size_t items = no * (size_t)S2;
     DevBuf<int> d_map, d_caps, d_sb, d_sc; DevBuf<long long> d_off;
     EDLIB_AMD_HIP(d_map.alloc(no)); EDLIB_AMD_HIP(d_sb.alloc(items)); EDLIB_AMD_HIP(d_sc.alloc(items));
