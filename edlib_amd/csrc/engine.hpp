@@ -344,6 +344,7 @@ private:
     int collectPairsFlat(std::vector<UnitResult>& res);
     // rings of 32-row words for the storing scans and walks of a flat PATH batch (ring32_kernels.hip)
     bool flatRing32_ = false; int flatG32_ = 8, flatMaxWords_ = 0;
+    bool deferReadsReset_ = false;                // this run blanks the recycled records of reads-path units where it fills them (collectGroup)
     std::vector<int> flatChunkStart_;             // ring32 NW store: unit ranges whose store fits 32-bit offsets (one range = the usual case)
     DevBuf<uint8_t> d_tsym_;
     // the caller-facing arrays of the last run: made on the device for a flat batch (buildFlatView), from the records otherwise

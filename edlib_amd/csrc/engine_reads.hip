@@ -445,6 +445,7 @@ int Batch::collectGroup(ReadGroup& g, std::vector<UnitResult>& res)
         const int u = g.perm[s];
         if (u < 0) continue;
         UnitResult& r = res[u];
+        if (deferReadsReset_) blank_record(r);
         r.alphabetLength = tab_.sigmaT + extra[s];
         const int m = qlen(u);
         if (mode == EDLIB_MODE_HW || mode == EDLIB_MODE_SHW) {
