@@ -345,8 +345,12 @@ def traffic_of(cfg_id, units):
                 head = open(os.path.join(ROOT, ".visit_commit")).read().strip() or None
             except Exception:
                 pass
+            from edlib_amd.parallel import sources_sha
+            here = sources_sha(ROOT)
             return ent.get("bytes_per_step"), {"file": "profiles/hbm_traffic.json", "commit": ent.get("commit"), "head": head,
                                                "taken_at_head": (head is not None and str(ent.get("commit", "")).startswith(head[:7])) if head else None,
+                                               "sources_sha": {"measured_on": ent.get("sources_sha"), "running": here},
+                                               "sources_identical": (ent.get("sources_sha") == here) if ent.get("sources_sha") else None,
                                                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_visit.sh traffic) at "
                                                        "that commit, not measured inside this run"}
     except Exception:

@@ -71,3 +71,22 @@ def gather_int_results(local, n_units, dist=None, device=None):
         lo, hi = shard_range(n_units, r, world)
         keep.append(full[r * per: r * per + (hi - lo)])
     return np.concatenate(keep)
+
+
+def sources_sha(root):
+    """sha256 over the product's sources and bench.py (names and contents, sorted): profiles/hbm_traffic.json records it with
+    the counters, bench.py recomputes it at run time -- `sources_identical` says whether the counters were taken on the very
+    code that is running, whatever commits of documents and profiles lie in between."""
+    import glob
+    import hashlib
+    import os
+    h = hashlib.sha256()
+    files = [os.path.join(root, "bench.py"), os.path.join(root, "Makefile")]
+    for pat in ("edlib_amd/csrc/*", "edlib_amd/*.py", "include/*.h"):
+        files += glob.glob(os.path.join(root, pat))
+    for f in sorted(set(files)):
+        if not os.path.isfile(f):
+            continue
+        h.update(os.path.relpath(f, root).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]

@@ -86,3 +86,19 @@ def test_strong_scaling_shards_partition_the_global_batch():
             parts.append(again["reads"][lo:hi])
         assert covered == n
         assert np.array_equal(np.concatenate(parts), full["reads"])
+
+
+def test_sources_digest_follows_the_product_sources(tmp_path):
+    """profiles/hbm_traffic.json carries the digest of the sources its counters were taken on; bench.py compares it with the
+    running tree's (`roofline.traffic_source.sources_identical`)"""
+    from edlib_amd.parallel import sources_sha
+    (tmp_path / "edlib_amd" / "csrc").mkdir(parents=True)
+    (tmp_path / "include").mkdir()
+    (tmp_path / "bench.py").write_text("x = 1\n")
+    (tmp_path / "edlib_amd" / "csrc" / "k.hip").write_text("kernel\n")
+    (tmp_path / "README.md").write_text("docs\n")
+    a = sources_sha(str(tmp_path))
+    (tmp_path / "README.md").write_text("other docs\n")
+    assert sources_sha(str(tmp_path)) == a                       # documents do not count
+    (tmp_path / "edlib_amd" / "csrc" / "k.hip").write_text("kernel 2\n")
+    assert sources_sha(str(tmp_path)) != a

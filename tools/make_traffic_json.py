@@ -15,6 +15,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from edlib_amd.parallel import sources_sha           # one digest over the product's sources + bench.py: what the counters were taken on
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles")
 R = sys.argv[2] if len(sys.argv) > 2 else "r03"
 commit = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] else subprocess.run(
@@ -48,6 +50,6 @@ for cfg, units in (("2", 1000000), ("4", 100000), ("5", 10000)):
     total = sum(2 * v["fetch_kb"] + v["write_kb"] for v in items.values()) * 1024
     for v in items.values():
         v["bytes"] = int((2 * v["fetch_kb"] + v["write_kb"]) * 1024)
-    out["configs"][cfg] = {"units": units, "commit": commit, "bytes_per_step": int(total), "per_kernel": items}
+    out["configs"][cfg] = {"units": units, "commit": commit, "sources_sha": sources_sha(ROOT), "bytes_per_step": int(total), "per_kernel": items}
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps({k: v["bytes_per_step"] for k, v in out["configs"].items()}))
