@@ -234,8 +234,8 @@ def cpu_baseline_and_parity(w, flat, sample_target, batch=None):
                         (", alignment, both CIGAR strings" if want_cigar else "")}
     parity.update(detail)
     # The reference pool pins glibc's mmap / trim thresholds for its own sake (oracle/ref_pool.cpp) and leaves gigabytes of freed
-    # heap behind; the NEXT batch's steps then ran on that heap (config 5 after config 4's leg: 1.85 ms per step against 0.71
-    # -- tools/… probe of round 6: malloc_trim(0) in between restores it).  The harness cleans up after its own checker.
+    # heap behind: the harness cleans up after its own checker.  (Config 5's 1.85 ms steps after config 4's leg, first blamed on
+    # this heap, were the device's clocks coming back from idle: measure_secondary.)
     try:
         C.CDLL(None).malloc_trim(0)
     except Exception:
@@ -494,14 +494,21 @@ def measure_secondary(cfg_id, device, torch, steps=5, warmup=2):
     w = make_workload(cfg_id, CONFIGS[cfg_id]["units"], 0, 1, False)
     batch = make_batch(w, device)
     try:
-        for _ in range(warmup):
-            run_step(cfg_id, batch)
+        # The device has idled through this config's workload generation and the leg of the reference before it, and its clocks
+        # take tens of milliseconds of work to come back: config 5's steps (0.7 ms) were timed at 0.7 or at 1.8 ms depending on
+        # what had run how long before (tools probe of round 6: 13 slow steps, then 0.70 ms for good).  Warm-up and timed region
+        # are therefore at least `warmup` / `steps` steps AND at least 0.25 s / 0.1 s long; both counts are in the line.
+        tw, nw = time.perf_counter(), 0
+        while nw < warmup or (time.perf_counter() - tw < 0.25 and nw < 5000):
+            run_step(cfg_id, batch); nw += 1
+        warmup = nw
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        scan_ms, launches, st = 0.0, 0, None
-        for _ in range(steps):
-            st = run_step(cfg_id, batch)
+        scan_ms, launches, st, ns = 0.0, 0, None, 0
+        while ns < steps or (time.perf_counter() - t0 < 0.1 and ns < 5000):
+            st = run_step(cfg_id, batch); ns += 1
             scan_ms += st["scan_ms"]; launches += st["scan_launches"]
+        steps = ns
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out = report(cfg_id, w, st, scan_ms, launches, steps, warmup, dt, st["cells"] * steps / dt / 1e9, 1, "weak")

@@ -104,8 +104,8 @@ void pool_free(void* p, size_t granted) {
     if (pool_enabled() && granted <= kPoolMaxBlock && dev < Pool::kMaxDev && (granted & (granted - 1)) == 0) {
         size_t r; const int c = size_class(granted, &r);
         // A full cache makes room by letting its OLDEST blocks go: the block coming back was in use a moment ago, what has sat
-        // here longest belongs to batches that are gone.  (Round 6: after the 1M-read batch and config 4 had filled the cache,
-        // every temporary of config 5's steps went hipMalloc -> hipFree -- 1.8 ms per step against 0.7 on its own.)
+        // here longest belongs to batches that are gone.  (It used to refuse the block coming back: once bigger batches had
+        // filled the cache, every temporary of a later batch's steps went hipMalloc -> hipFree.)
         std::vector<void*> evict;
         {
             std::lock_guard<std::mutex> g(pool().mu);
