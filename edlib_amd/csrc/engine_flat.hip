@@ -519,14 +519,22 @@ int Batch::buildFlatView()
     // A PATH batch whose caller asked for CIGARs after an earlier run gets them made NOW, on the side stream, while the op
     // bytes travel: the run-length encoding of both formats (0.16 ms of kernels for config 5) overlaps the 10 MB copy
     // instead of following it, and shares its synchronisations.  (The first request of a session is served on demand.)
-    const bool prefetchCigars = cigarSticky_ && wantPath && capAln > 0;
+    bool prefetchCigars = cigarSticky_ && wantPath && capAln > 0;
     if (prefetchCigars) {
         if (!side_) EDLIB_AMD_HIP(pool_stream(&side_));
         EDLIB_AMD_HIP(evView_.create());
         EDLIB_AMD_HIP(hipEventRecord(evView_.e, stream_));
         EDLIB_AMD_HIP(hipStreamWaitEvent(side_, evView_.e, 0));
-        for (int f = 0; f < 2; ++f)
-            if (enqueueCigars(f, dv + oAln, reinterpret_cast<const long long*>(dv + oAlnOff), (size_t)(2 * capAln) + n + 64, side_)) return 1;
+        // Best effort: the prefetch sizes its character buffers for the worst case (two characters per op slot, both formats)
+        // before the totals are known.  When that does not fit the device the view is still good -- the strings are then made
+        // on demand (cigarView), sized by what there is.
+        for (int f = 0; f < 2 && prefetchCigars; ++f)
+            if (enqueueCigars(f, dv + oAln, reinterpret_cast<const long long*>(dv + oAlnOff), (size_t)(2 * capAln) + n + 64, side_)) {
+                prefetchCigars = false;
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(side_);               // (whatever of it was queued is over before its buffers are asked for again)
+                d_cigChars_.release(); d_cigChars2_.release();
+            }
     }
     // ---- the fixed part (per-unit fields, offsets, totals), then exactly as many locations / op bytes as there are
     EDLIB_AMD_HIP(hipMemcpyAsync(hv, dv, headBytes, hipMemcpyDeviceToHost, stream_));
