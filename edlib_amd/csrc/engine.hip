@@ -291,11 +291,11 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
     syms_ = tab_.sigmaT <= 4 ? 4 : (tab_.sigmaT <= 8 ? 8 : 16);
     banded_ = mode == EDLIB_MODE_HW;
     // Long HW queries against the shared target: piece filter + window verification (long_reads.hip) from kFilterFromWords
-    // words on; below that the banded groups of kernel A.  257..384 bases on the 12-word group: 50.7 / 53.5 / 59.7 ms per
-    // 16,384 reads of 257 / 300 / 384 bases against 54.6 / 73.2 / 73.0 through the filter; from 385 on (16 KB of LDS rows per
-    // wave) the two are level, and from 513 the filter wins 109 to 189.  EDLIB_AMD_FILTER=<words> moves the switch (9 = rounds
-    // 3-5: everything above 256 bases), EDLIB_AMD_FILTER=0 restores round 2's routing (groups of 12 / 16 / 24 / 32 words up
-    // to 1024 bases, kernel W above).
+    // words on; below that the banded groups of kernel A.  257..320 / 321..384 bases on the 10- / 12-word groups: 38 / 41 / 50 /
+    // 55 ms per 16,384 reads of 257 / 300 / 321 / 384 bases against 55 / 73 / 73 / 73 through the filter; from 385 on (the 14-
+    // and 16-word groups: 14 / 16 KB of LDS rows per wave) the two are level on four symbols and the filter is ahead on five
+    // to eight, and from 513 it wins 109 to 189.  EDLIB_AMD_FILTER=<words> moves the switch (9 = rounds 3-5: everything above
+    // 256 bases), EDLIB_AMD_FILTER=0 restores round 2's routing (banded groups up to 1024 bases, kernel W above).
     static const int filterFrom = [] {
         const char* e = getenv("EDLIB_AMD_FILTER");
         if (!e || !e[0]) return kFilterFromWords;
@@ -305,7 +305,7 @@ int Batch::init(const char* queries, const long long* qoff, int n, const char* t
     const bool filter = filterFrom > 0 && readsOk && banded_ && modeIn == EDLIB_MODE_HW;
     int groupWords = kMaxReadWords;              // the tallest group of kernel A that takes reads of this batch
     if (banded_ && modeIn == EDLIB_MODE_HW && syms_ <= 8)
-        for (int w : {12, 16, 24, 32})
+        for (int w : {10, 12, 14, 16, 24, 32})
             if (w <= (syms_ == 4 ? kMaxLongReadWords4 : kMaxLongReadWords) && (!filter || w < filterFrom)) groupWords = w;
     const int maxReadLen = 32 * groupWords;
     std::vector<std::vector<int>> byWords(kMaxLongReadWords4 + 1);

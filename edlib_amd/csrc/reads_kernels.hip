@@ -216,7 +216,7 @@ hipError_t launch_build_peq_reads(int nwords, int syms, const uint8_t* reads, co
     if (syms != 4 && syms != 8 && syms != 16) return hipErrorInvalidValue;
     switch (nwords) {
 #define CASE(N) case N: return launch_build_peq_t<N>(reads, qoff, perm, nslots, syms, eqtbl, tpres, kcfg, peq, qlen, kinit, alphaExtra, stream);
-        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(12) CASE(16) CASE(24) CASE(32)
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(10) CASE(12) CASE(14) CASE(16) CASE(24) CASE(32)
 #undef CASE
     }
     return hipErrorInvalidValue;

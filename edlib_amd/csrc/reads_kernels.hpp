@@ -7,13 +7,13 @@
 namespace edlib_amd {
 
 constexpr int kMaxReadWords = 8;      // queries up to 256 symbols: one kernel instance per word count, every mode
-// HW, banded kernel only: queries of 257..384 / 385..512 symbols run in groups of 12 / 16 words (targets of up to 8
-// symbols), 513..768 / 769..1024 in groups of 24 / 32 words (four symbols); the row m-1 of a lane may sit in any of
+// HW, banded kernel only: queries of 257..320 / ..384 / ..448 / ..512 symbols run in groups of 10 / 12 / 14 / 16 words (targets
+// of up to 8 symbols), 513..768 / 769..1024 in groups of 24 / 32 words (four symbols); the row m-1 of a lane may sit in any of
 // the group's last four (eight) words
 constexpr int kMaxLongReadWords = 16;       // targets of 5..8 symbols
 constexpr int kMaxLongReadWords4 = 32;      // targets of up to 4 symbols
 constexpr int kFilterFromWords = 13;        // HW queries of this many words and more take the piece filter (long_reads.hip)
-inline int read_group_words(int m) { const int w = (m + 31) / 32; return w <= kMaxReadWords ? w : (w <= 12 ? 12 : (w <= 16 ? 16 : (w <= 24 ? 24 : 32))); }
+inline int read_group_words(int m) { const int w = (m + 31) / 32; return w <= kMaxReadWords ? w : (w <= 10 ? 10 : (w <= 12 ? 12 : (w <= 14 ? 14 : (w <= 16 ? 16 : (w <= 24 ? 24 : 32))))); }
 constexpr int kLanes = 64;            // wave64, hard-coded (gfx950)
 
 // Everything the scan kernel needs; plain pointers into HBM.

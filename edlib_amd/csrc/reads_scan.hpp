@@ -306,6 +306,9 @@ static_assert(band_height_up<32>(24) == 32 && band_height_down<32>(32) == 24 && 
 // read has NWD - 4 (NWD - 8 above 16 words) full words above its last one
 static_assert(band_height_down<12>(12) <= 12 - 4 && band_height_down<16>(16) <= 16 - 4 && band_height_down<24>(24) <= 24 - 8 &&
               band_height_down<32>(32) <= 32 - 8, "bottom row inside the band only at full height");
+// (the groups of 10 / 14 words hold reads of 9..10 / 13..14 words: the bottom row sits in one of the last two)
+static_assert(band_height_up<10>(8) == 10 && band_height_down<10>(10) <= 10 - 2 && band_height_up<14>(12) == 14 && band_height_down<14>(14) <= 14 - 2,
+              "10- and 14-word ladders");
 
 struct HwTrack {            // per-lane tracking state of the banded kernel
     int best, cnt, cap;
@@ -558,7 +561,7 @@ scan_reads_banded_kernel(const ReadScanArgs a)
                 bandWork += (unsigned int)NA * (unsigned int)(b * 4 + q - q0);                                  \
             }                                                                                                   \
             break;
-            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(12) CASE(16) CASE(24) CASE(32)
+            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(10) CASE(12) CASE(14) CASE(16) CASE(24) CASE(32)
 #undef CASE
 #undef ADVANCE
 #undef QUAD
