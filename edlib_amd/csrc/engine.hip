@@ -1015,7 +1015,7 @@ int Batch::resultsView(EdlibAmdResultsView* out)
     if (!haveResults_) { set_error("results before a successful run()"); return 1; }
     DeviceGuard guard(device_);
     EDLIB_AMD_HIP(guard.status);
-    if (!viewReady_ && (lastRunFlat_ ? buildFlatView() : buildHostView())) return 1;
+    if (!viewReady_ && (lastRunFlat_ ? buildFlatView() : (readsViewOnDevice() ? buildReadsView() : buildHostView()))) return 1;
     if (out) *out = view_;
     return 0;
 }

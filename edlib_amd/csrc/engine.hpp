@@ -342,6 +342,8 @@ private:
     std::vector<long long> flatOpsOffHost_;
     int runFlatStartsAndPaths(bool& fellBack);
     int collectPairsFlat(std::vector<UnitResult>& res);
+    bool readsViewOnDevice() const;               // a DISTANCE run of one group of reads: its view is made by flat_results.hip
+    int buildReadsView();
     // rings of 32-row words for the storing scans and walks of a flat PATH batch (ring32_kernels.hip)
     bool flatRing32_ = false; int flatG32_ = 8, flatMaxWords_ = 0;
     bool deferReadsReset_ = false;                // this run blanks the recycled records of reads-path units where it fills them (collectGroup)

@@ -634,6 +634,98 @@ int Batch::collectPairsFlat(std::vector<UnitResult>& res)
     return 0;
 }
 
+// ------------------------------------------------------ the view of a DISTANCE batch of reads
+
+// out[slots[i]] = i: the overflow index of the slots the exact second pass served (flat_results.hip: ovfAt)
+__global__ void __launch_bounds__(256)
+scatter_index_kernel(const int* __restrict__ slots, int count, int* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[slots[i]] = i;
+}
+
+// A TASK_DISTANCE run over reads-path units only leaves its results in HBM (per slot: best score, number of end locations,
+// the first 16 of them, the lists of the exact second pass).  When ONE group holds every unit in unit order (reads of one
+// word count: the north-star shape) those arrays are exactly what flat_results.hip lays out for a flat pair batch: the
+// caller-facing arrays are made on the device and come over as one block, no per-read record is built (1M reads: 44 ms of
+// records and copies before, the D2H of ~30 MB now).  results() -- per-unit malloc'd arrays -- still builds its records.
+bool Batch::readsViewOnDevice() const
+{
+    if (readsCollected_ || flatPairs_ || groups_.size() != 1 || cfg_.task != EDLIB_TASK_DISTANCE) return false;
+    if (!pairUnits_.empty() || !longUnits_.empty() || !emptyUnits_.empty()) return false;
+    const int mode = (int)cfg_.mode;
+    if (mode != EDLIB_MODE_NW && mode != EDLIB_MODE_SHW && mode != EDLIB_MODE_HW) return false;
+    const ReadGroup& g = *groups_[0];
+    if (g.zeroCopy || g.nslots < n_ || readUnits_.size() != (size_t)n_) return false;
+    return true;               // (one group of all units: makeGroup lists them in unit order, slot == unit)
+}
+
+int Batch::buildReadsView()
+{
+    if (viewReady_) return 0;
+    ReadGroup& g = *groups_[0];
+    const int mode = (int)cfg_.mode;
+    const size_t n = (size_t)n_;
+    const size_t nblocks = (n + 255) / 256;
+    const size_t novf = g.ovfSlots.size();
+    const long long ovfTotal = g.ovfOff.empty() ? 0 : g.ovfOff.back();
+    const long long capLoc = (mode == EDLIB_MODE_NW ? (long long)n : (long long)n * (kFlatPosCap + 1)) + ovfTotal;
+    size_t at = 0;
+    auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 63) & ~(size_t)63; return o; };
+    const size_t oTotals = take(16);
+    const size_t oEd = take(n * 4), oNloc = take(n * 4), oAlpha = take(n * 4);
+    const size_t oLocOff = take((n + 1) * 8), oAlnOff = take((n + 1) * 8);
+    const size_t headBytes = at;
+    const size_t oStatus = take(n * 4), oAlnLen = take(n * 4), oBlockLoc = take(nblocks * 8), oBlockAln = take(nblocks * 8);
+    const size_t oOvfAt = take(novf ? n * 4 : 4), oOvfOff = take((novf + 1) * 8), oOvfSlots = take((novf + 1) * 4);
+    const size_t hostHead = headBytes + ((n * 4 + 63) & ~(size_t)63);
+    const size_t oEnds = take((size_t)capLoc * 4), oAln = take(64);
+    EDLIB_AMD_HIP(d_view_.ensure(at));
+    if (h_view_.n < hostHead) EDLIB_AMD_HIP(h_view_.alloc(hostHead));
+    uint8_t* const dv = d_view_.p; uint8_t* const hv = h_view_.p;
+    FlatResultArgs a{};
+    a.descs = nullptr; a.qlens = g.d_qlen.p; a.sharedT = tlen(0); a.alphaBase = tab_.sigmaT;
+    a.n = n_; a.mode = mode; a.k = cfg_.k; a.wantPath = 0; a.posCap = kFlatPosCap;
+    a.score = g.d_best.p; a.count = g.d_total.p; a.pos = g.d_pos.p; a.alphabet = g.d_alphaExtra.p;
+    if (novf) {
+        // (pageable sources: the lists are a few thousand entries)
+        EDLIB_AMD_HIP(hipMemsetAsync(dv + oOvfAt, 0xff, n * 4, stream_));
+        EDLIB_AMD_HIP(hipMemcpyAsync(dv + oOvfSlots, g.ovfSlots.data(), novf * sizeof(int), hipMemcpyHostToDevice, stream_));
+        EDLIB_AMD_HIP(hipMemcpyAsync(dv + oOvfOff, g.ovfOff.data(), (novf + 1) * sizeof(long long), hipMemcpyHostToDevice, stream_));
+        hipLaunchKernelGGL(scatter_index_kernel, dim3((unsigned)((novf + 255) / 256)), dim3(256), 0, stream_,
+                           reinterpret_cast<const int*>(dv + oOvfSlots), (int)novf, reinterpret_cast<int*>(dv + oOvfAt));
+        EDLIB_AMD_HIP(hipGetLastError());
+        a.ovfAt = reinterpret_cast<const int*>(dv + oOvfAt); a.ovfOff = reinterpret_cast<const long long*>(dv + oOvfOff); a.ovfPos = g.d_ovfPool.p;
+    }
+    a.status = reinterpret_cast<int*>(dv + oStatus); a.editDistance = reinterpret_cast<int*>(dv + oEd);
+    a.numLocations = reinterpret_cast<int*>(dv + oNloc); a.alphabetLength = reinterpret_cast<int*>(dv + oAlpha);
+    a.alnLen = reinterpret_cast<int*>(dv + oAlnLen);
+    a.locOff = reinterpret_cast<long long*>(dv + oLocOff); a.alnOff = reinterpret_cast<long long*>(dv + oAlnOff);
+    a.blockLoc = reinterpret_cast<long long*>(dv + oBlockLoc); a.blockAln = reinterpret_cast<long long*>(dv + oBlockAln);
+    a.ends = reinterpret_cast<int*>(dv + oEnds); a.starts = nullptr; a.aln = dv + oAln;
+    EDLIB_AMD_HIP(launch_flat_results(a, reinterpret_cast<long long*>(dv + oTotals), stream_));
+    EDLIB_AMD_HIP(hipMemcpyAsync(hv, dv, headBytes, hipMemcpyDeviceToHost, stream_));
+    EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+    const long long nloc = reinterpret_cast<const long long*>(hv + oTotals)[0];
+    if (nloc < 0 || nloc > capLoc) { set_error("reads view: totals out of range"); return 1; }
+    const size_t varBytes = (size_t)nloc * 4 + 64;
+    if (h_viewVar_.n < varBytes) EDLIB_AMD_HIP(h_viewVar_.alloc(varBytes + varBytes / 8));
+    if (nloc) EDLIB_AMD_HIP(hipMemcpyAsync(h_viewVar_.p, dv + oEnds, (size_t)nloc * 4, hipMemcpyDeviceToHost, stream_));
+    EDLIB_AMD_HIP(hipStreamSynchronize(stream_));
+    memset(hv + headBytes, 0, n * 4);                    // status: every unit of a reads group is EDLIB_STATUS_OK
+    view_ = EdlibAmdResultsView{};
+    view_.numUnits = n_;
+    view_.status = reinterpret_cast<const int*>(hv + headBytes); view_.editDistance = reinterpret_cast<const int*>(hv + oEd);
+    view_.numLocations = reinterpret_cast<const int*>(hv + oNloc); view_.alphabetLength = reinterpret_cast<const int*>(hv + oAlpha);
+    view_.locOffsets = reinterpret_cast<const long long*>(hv + oLocOff); view_.alnOffsets = reinterpret_cast<const long long*>(hv + oAlnOff);
+    view_.endLocations = reinterpret_cast<const int*>(h_viewVar_.p);
+    view_.startLocations = nullptr; view_.alignment = nullptr;
+    viewAlnDev_ = nullptr; viewAlnOffDev_ = nullptr;
+    viewReady_ = true;
+    if (getenv("EDLIB_AMD_DEBUG")) fprintf(stderr, "[edlib_amd] reads view made on the device: %d units, %lld locations, %zu lists of the exact pass\n", n_, nloc, novf);
+    return 0;
+}
+
 int Batch::ensureCollected()
 {
     if (readsCollected_ && pairsCollected_) return 0;

@@ -45,8 +45,7 @@ flat_counts_kernel(const FlatResultArgs a)
     const int u = blockIdx.x * 256 + threadIdx.x;
     long long nloc = 0, alen = 0;
     if (u < a.n) {
-        const PairDesc d = a.descs[u];
-        const int m = d.qlen;
+        const int m = a.descs ? a.descs[u].qlen : a.qlens[u];
         const int score = a.score[u];
         int ed = -1;
         if (a.mode == 0) {                                           // NW (edlib.cpp:744-747, 917; end location T - 1: :221-225)
@@ -62,7 +61,7 @@ flat_counts_kernel(const FlatResultArgs a)
         a.editDistance[u] = ed;
         a.numLocations[u] = (int)nloc;
         a.status[u] = 0;
-        if (a.alphabet) a.alphabetLength[u] = a.alphabet[u];
+        if (a.alphabet) a.alphabetLength[u] = a.alphabet[u] + a.alphaBase;
         if (a.wantPath && ed >= 0 && nloc > 0) {
             // the path of the FIRST location (:276-289); an empty window -- the first location is the empty prefix -- is m inserts (:1168-1175)
             const int W = ((m + 63) / 64) * 64 - m;
@@ -114,11 +113,10 @@ flat_write_kernel(const FlatResultArgs a)
         a.locOff[u] = lo; a.alnOff[u] = ao;
         if (u == a.n - 1) { a.locOff[a.n] = lo + nloc; a.alnOff[a.n] = ao + alen; }
     }
-    const PairDesc d = a.descs[u];
-    const int m = d.qlen;
+    const int m = a.descs ? a.descs[u].qlen : a.qlens[u];
     if (nloc > 0) {
         if (a.mode == 0) {
-            if (lane == 0) { a.ends[lo] = d.tlen - 1; if (a.starts) a.starts[lo] = 0; }
+            if (lane == 0) { a.ends[lo] = (a.descs ? a.descs[u].tlen : a.sharedT) - 1; if (a.starts) a.starts[lo] = 0; }
         } else {
             const int W = ((m + 63) / 64) * 64 - m;
             const int lead = (W > 0 && ed == m) ? 1 : 0;             // position -1 comes first

@@ -6,7 +6,9 @@
 namespace edlib_amd {
 
 struct FlatResultArgs {
-    const PairDesc* descs;      // the batch's resident descriptors (qlen, tlen)
+    const PairDesc* descs;      // the batch's resident descriptors (qlen, tlen); null: a batch of reads against one shared target --
+    const int* qlens; int sharedT;   // -- whose query lengths are an array and whose target length is one number
+    int alphaBase;              // added to alphabet[u] (the reads path counts what a query adds to the target's alphabet)
     int n, mode, k, wantPath, posCap;
     // what the scans left: score / count per unit, posCap end positions per unit, HW start locations (or null)
     const int* score; const int* count; const int* pos; const int* devStarts;
