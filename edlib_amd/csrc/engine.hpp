@@ -342,7 +342,7 @@ private:
     std::vector<long long> flatOpsOffHost_;
     int runFlatStartsAndPaths(bool& fellBack);
     int collectPairsFlat(std::vector<UnitResult>& res);
-    bool readsViewOnDevice() const;               // a DISTANCE run of one group of reads: its view is made by flat_results.hip
+    bool readsViewOnDevice() const;               // a DISTANCE run over read groups only: its view is made by flat_results.hip
     int buildReadsView();
     // rings of 32-row words for the storing scans and walks of a flat PATH batch (ring32_kernels.hip)
     bool flatRing32_ = false; int flatG32_ = 8, flatMaxWords_ = 0;

@@ -644,31 +644,48 @@ scatter_index_kernel(const int* __restrict__ slots, int count, int* __restrict__
     if (i < count) out[slots[i]] = i;
 }
 
-// A TASK_DISTANCE run over reads-path units only leaves its results in HBM (per slot: best score, number of end locations,
-// the first 16 of them, the lists of the exact second pass).  When ONE group holds every unit in unit order (reads of one
-// word count: the north-star shape) those arrays are exactly what flat_results.hip lays out for a flat pair batch: the
-// caller-facing arrays are made on the device and come over as one block, no per-read record is built (1M reads: 44 ms of
-// records and copies before, the D2H of ~30 MB now).  results() -- per-unit malloc'd arrays -- still builds its records.
+// slot -> unit order: what flat_results.hip reads per unit, gathered from one group's per-slot arrays
+__global__ void __launch_bounds__(256)
+gather_group_kernel(const int* __restrict__ perm, int nslots, const int* __restrict__ best, const int* __restrict__ total,
+                    const int* __restrict__ qlen, const int* __restrict__ extra, const int* __restrict__ pos, int posCap,
+                    int* __restrict__ uScore, int* __restrict__ uCount, int* __restrict__ uQlen, int* __restrict__ uAlpha,
+                    int* __restrict__ uPos)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslots) return;
+    const int u = perm[s];
+    if (u < 0) return;
+    uScore[u] = best[s]; uCount[u] = total[s]; uQlen[u] = qlen[s]; uAlpha[u] = extra[s];
+    // (a small group's arrays are views into pinned host memory at an odd offset: no vector loads)
+    for (int i = 0; i < posCap; ++i) uPos[(size_t)u * posCap + i] = pos[(size_t)s * posCap + i];
+}
+
+// A TASK_DISTANCE run over reads-path units only leaves its results in HBM (per slot of each word-count group: best score,
+// number of end locations, the first 16 of them, the lists of the exact second pass).  That is what flat_results.hip lays out
+// for a flat pair batch: the caller-facing arrays are made on the device and come over as one block, no per-read record is
+// built (1M reads: 63 ms of records and copies before, 15 now).  One group of all units (reads of one word count: the
+// north-star shape) has slot == unit and is read in place; several groups are first gathered into unit order.  results() --
+// per-unit malloc'd arrays -- still builds its records.
 bool Batch::readsViewOnDevice() const
 {
-    if (readsCollected_ || flatPairs_ || groups_.size() != 1 || cfg_.task != EDLIB_TASK_DISTANCE) return false;
-    if (!pairUnits_.empty() || !longUnits_.empty() || !emptyUnits_.empty()) return false;
+    if (readsCollected_ || flatPairs_ || groups_.empty() || cfg_.task != EDLIB_TASK_DISTANCE) return false;
+    if (!pairUnits_.empty() || !longUnits_.empty() || !emptyUnits_.empty() || readUnits_.size() != (size_t)n_) return false;
     const int mode = (int)cfg_.mode;
     if (mode != EDLIB_MODE_NW && mode != EDLIB_MODE_SHW && mode != EDLIB_MODE_HW) return false;
-    const ReadGroup& g = *groups_[0];
-    if (g.zeroCopy || g.nslots < n_ || readUnits_.size() != (size_t)n_) return false;
-    return true;               // (one group of all units: makeGroup lists them in unit order, slot == unit)
+    if (groups_.size() == 1 && groups_[0]->zeroCopy) return false;          // (a handful of reads: their results are on the host already)
+    return true;
 }
 
 int Batch::buildReadsView()
 {
     if (viewReady_) return 0;
-    ReadGroup& g = *groups_[0];
     const int mode = (int)cfg_.mode;
     const size_t n = (size_t)n_;
     const size_t nblocks = (n + 255) / 256;
-    const size_t novf = g.ovfSlots.size();
-    const long long ovfTotal = g.ovfOff.empty() ? 0 : g.ovfOff.back();
+    const bool inPlace = groups_.size() == 1;          // slot == unit (makeGroup lists a group's units in unit order)
+    size_t novf = 0; long long ovfTotal = 0;
+    for (auto& gp : groups_) { novf += gp->ovfSlots.size(); ovfTotal += gp->ovfOff.empty() ? 0 : gp->ovfOff.back(); }
+    const int posCap = mode == EDLIB_MODE_NW ? 0 : kFlatPosCap;
     const long long capLoc = (mode == EDLIB_MODE_NW ? (long long)n : (long long)n * (kFlatPosCap + 1)) + ovfTotal;
     size_t at = 0;
     auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 63) & ~(size_t)63; return o; };
@@ -677,26 +694,57 @@ int Batch::buildReadsView()
     const size_t oLocOff = take((n + 1) * 8), oAlnOff = take((n + 1) * 8);
     const size_t headBytes = at;
     const size_t oStatus = take(n * 4), oAlnLen = take(n * 4), oBlockLoc = take(nblocks * 8), oBlockAln = take(nblocks * 8);
-    const size_t oOvfAt = take(novf ? n * 4 : 4), oOvfOff = take((novf + 1) * 8), oOvfSlots = take((novf + 1) * 4);
+    const size_t oOvfAt = take(novf ? n * 4 : 4), oOvfOff = take((novf + 1) * 8), oOvfUnits = take((novf + 1) * 4);
+    const size_t oOvfPool = take(inPlace ? 4 : (size_t)ovfTotal * 4 + 4);
+    const size_t oUScore = take(inPlace ? 4 : n * 4), oUCount = take(inPlace ? 4 : n * 4), oUQlen = take(inPlace ? 4 : n * 4), oUAlpha = take(inPlace ? 4 : n * 4);
+    const size_t oUPos = take(inPlace ? 4 : n * (size_t)posCap * 4 + 4);
     const size_t hostHead = headBytes + ((n * 4 + 63) & ~(size_t)63);
     const size_t oEnds = take((size_t)capLoc * 4), oAln = take(64);
     EDLIB_AMD_HIP(d_view_.ensure(at));
     if (h_view_.n < hostHead) EDLIB_AMD_HIP(h_view_.alloc(hostHead));
     uint8_t* const dv = d_view_.p; uint8_t* const hv = h_view_.p;
     FlatResultArgs a{};
-    a.descs = nullptr; a.qlens = g.d_qlen.p; a.sharedT = tlen(0); a.alphaBase = tab_.sigmaT;
+    a.descs = nullptr; a.sharedT = tlen(0); a.alphaBase = tab_.sigmaT;
     a.n = n_; a.mode = mode; a.k = cfg_.k; a.wantPath = 0; a.posCap = kFlatPosCap;
-    a.score = g.d_best.p; a.count = g.d_total.p; a.pos = g.d_pos.p; a.alphabet = g.d_alphaExtra.p;
-    if (novf) {
-        // (pageable sources: the lists are a few thousand entries)
-        EDLIB_AMD_HIP(hipMemsetAsync(dv + oOvfAt, 0xff, n * 4, stream_));
-        EDLIB_AMD_HIP(hipMemcpyAsync(dv + oOvfSlots, g.ovfSlots.data(), novf * sizeof(int), hipMemcpyHostToDevice, stream_));
-        EDLIB_AMD_HIP(hipMemcpyAsync(dv + oOvfOff, g.ovfOff.data(), (novf + 1) * sizeof(long long), hipMemcpyHostToDevice, stream_));
-        hipLaunchKernelGGL(scatter_index_kernel, dim3((unsigned)((novf + 255) / 256)), dim3(256), 0, stream_,
-                           reinterpret_cast<const int*>(dv + oOvfSlots), (int)novf, reinterpret_cast<int*>(dv + oOvfAt));
-        EDLIB_AMD_HIP(hipGetLastError());
-        a.ovfAt = reinterpret_cast<const int*>(dv + oOvfAt); a.ovfOff = reinterpret_cast<const long long*>(dv + oOvfOff); a.ovfPos = g.d_ovfPool.p;
+    // ---- the per-unit inputs: in place, or gathered from the groups
+    std::vector<int> ovfUnits; std::vector<long long> ovfOffAll;
+    if (inPlace) {
+        ReadGroup& g = *groups_[0];
+        a.qlens = g.d_qlen.p; a.score = g.d_best.p; a.count = g.d_total.p; a.pos = g.d_pos.p; a.alphabet = g.d_alphaExtra.p;
+        a.ovfPos = g.d_ovfPool.p;
+        ovfUnits = g.ovfSlots; ovfOffAll = g.ovfOff;
+    } else {
+        int* uScore = reinterpret_cast<int*>(dv + oUScore); int* uCount = reinterpret_cast<int*>(dv + oUCount);
+        int* uQlen = reinterpret_cast<int*>(dv + oUQlen); int* uAlpha = reinterpret_cast<int*>(dv + oUAlpha);
+        int* uPos = reinterpret_cast<int*>(dv + oUPos); int* pool = reinterpret_cast<int*>(dv + oOvfPool);
+        ovfOffAll.push_back(0);
+        long long poolAt = 0;
+        for (auto& gp : groups_) {
+            ReadGroup& g = *gp;
+            hipLaunchKernelGGL(gather_group_kernel, dim3((unsigned)((g.nslots + 255) / 256)), dim3(256), 0, stream_,
+                               g.d_perm.p, g.nslots, g.d_best.p, g.d_total.p, g.d_qlen.p, g.d_alphaExtra.p, g.d_pos.p, posCap,
+                               uScore, uCount, uQlen, uAlpha, uPos);
+            EDLIB_AMD_HIP(hipGetLastError());
+            for (size_t i = 0; i < g.ovfSlots.size(); ++i) {
+                ovfUnits.push_back(g.perm[g.ovfSlots[i]]);
+                ovfOffAll.push_back(poolAt + g.ovfOff[i + 1]);
+            }
+            const long long mine = g.ovfOff.empty() ? 0 : g.ovfOff.back();
+            if (mine) EDLIB_AMD_HIP(hipMemcpyAsync(pool + poolAt, g.d_ovfPool.p, (size_t)mine * sizeof(int), hipMemcpyDeviceToDevice, stream_));
+            poolAt += mine;
+        }
+        a.qlens = uQlen; a.score = uScore; a.count = uCount; a.pos = uPos; a.alphabet = uAlpha; a.ovfPos = pool;
     }
+    if (novf) {
+        // (pageable sources: the lists are a few thousand entries; the stream is synchronised below before they go out of scope)
+        EDLIB_AMD_HIP(hipMemsetAsync(dv + oOvfAt, 0xff, n * 4, stream_));
+        EDLIB_AMD_HIP(hipMemcpyAsync(dv + oOvfUnits, ovfUnits.data(), novf * sizeof(int), hipMemcpyHostToDevice, stream_));
+        EDLIB_AMD_HIP(hipMemcpyAsync(dv + oOvfOff, ovfOffAll.data(), (novf + 1) * sizeof(long long), hipMemcpyHostToDevice, stream_));
+        hipLaunchKernelGGL(scatter_index_kernel, dim3((unsigned)((novf + 255) / 256)), dim3(256), 0, stream_,
+                           reinterpret_cast<const int*>(dv + oOvfUnits), (int)novf, reinterpret_cast<int*>(dv + oOvfAt));
+        EDLIB_AMD_HIP(hipGetLastError());
+        a.ovfAt = reinterpret_cast<const int*>(dv + oOvfAt); a.ovfOff = reinterpret_cast<const long long*>(dv + oOvfOff);
+    } else a.ovfPos = nullptr;
     a.status = reinterpret_cast<int*>(dv + oStatus); a.editDistance = reinterpret_cast<int*>(dv + oEd);
     a.numLocations = reinterpret_cast<int*>(dv + oNloc); a.alphabetLength = reinterpret_cast<int*>(dv + oAlpha);
     a.alnLen = reinterpret_cast<int*>(dv + oAlnLen);
@@ -722,7 +770,7 @@ int Batch::buildReadsView()
     view_.startLocations = nullptr; view_.alignment = nullptr;
     viewAlnDev_ = nullptr; viewAlnOffDev_ = nullptr;
     viewReady_ = true;
-    if (getenv("EDLIB_AMD_DEBUG")) fprintf(stderr, "[edlib_amd] reads view made on the device: %d units, %lld locations, %zu lists of the exact pass\n", n_, nloc, novf);
+    if (getenv("EDLIB_AMD_DEBUG")) fprintf(stderr, "[edlib_amd] reads view made on the device: %d units in %zu group(s), %lld locations, %zu lists of the exact pass\n", n_, groups_.size(), nloc, novf);
     return 0;
 }
 

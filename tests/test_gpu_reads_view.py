@@ -54,16 +54,33 @@ def test_view_of_a_distance_batch_of_reads(engine, mode, k):
     _compare(engine, reads, target, mode, k)
 
 
-def test_mixed_word_counts_keep_the_host_route(engine):
-    """two groups (reads of 100 and of 150 bases): slot != unit, the view is assembled from the records as before"""
-    target = synth.random_dna(404, 120_000)
-    reads = _reads(target, [100, 150] * 700, 405, unrelated_every=7, max_err=0.05)
-    b = engine.SharedBatch(reads, target, mode="HW", task="distance", k=-1)
+@pytest.mark.parametrize("mode,k", [("HW", -1), ("HW", 4), ("SHW", -1), ("NW", -1)])
+def test_several_word_count_groups_are_gathered_into_unit_order(engine, mode, k):
+    """reads of 40..160 bases in arbitrary order: five groups (one of them a handful of reads whose results sit in pinned host
+    memory), slot != unit; repeats give some of them lists of the exact pass"""
+    T = 200_000 if mode == "HW" else 150
+    target, motifs = _target_with_repeats(406, T, [30, 5]) if mode == "HW" else (synth.random_dna(406, T), [])
+    rng = np.random.default_rng(407)
+    lengths = [int(x) for x in rng.integers(40, 161, 1500)] + [20, 25, 31]            # (the last three: a group of their own)
+    if mode == "HW":
+        reads = _reads(target, lengths, 408, unrelated_every=8, max_err=0.05)
+        for motif in motifs:
+            for s0, m in ((0, 70), (50, 100), (200, 150), (10, 129)):
+                reads.append(np.ascontiguousarray(motif[s0:s0 + m]))
+    else:
+        reads = [np.resize(synth.mutate(target[:m + 8], 409, 0.03, 0.01, 0.01, stream=i)[0], m) for i, m in enumerate(lengths)]
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    b = engine.SharedBatch(reads, target, mode=mode, task="distance", k=k)
     try:
-        b.run(); got = b.results_flat()
+        b.run(); got = b.results_flat(); rec = b.results(raw=True)
     finally:
         b.close()
     qoff = np.zeros(len(reads) + 1, dtype=np.int64); qoff[1:] = np.cumsum([len(r) for r in reads])
-    ref = O.pool_align(np.concatenate(reads), qoff, target, np.array([0, len(target)], dtype=np.int64), True, "HW", "distance", -1)
-    for f in ("status", "editDistance", "numLocations", "alphabetLength", "locOff", "ends"):
-        assert np.array_equal(got[f], ref[f]), f
+    ref = O.pool_align(np.concatenate(reads), qoff, target, np.array([0, len(target)], dtype=np.int64), True, mode, "distance", k)
+    for f in ("status", "editDistance", "numLocations", "alphabetLength", "locOff", "ends", "alnOff"):
+        assert np.array_equal(got[f], ref[f]), (mode, k, f)
+    lo = got["locOff"]
+    for u in range(len(reads)):
+        assert rec[u]["editDistance"] == got["editDistance"][u]
+        assert list(rec[u]["endLocations"] or []) == list(got["ends"][lo[u]:lo[u + 1]]), (mode, k, u)
