@@ -461,11 +461,13 @@ def measure_collection(cfg_id, batch, ms_per_step):
 
 
 def collection_note(collect_ms, ms_per_step):
-    """A step (`Batch.run()`) ends with the results resident in HBM; bringing them to the host (download, per-unit records,
-    flat arrays) happens in `results_flat()`, once per call whatever the number of steps.  Reported beside the step so that
-    the lazily collected paths (reads path, flat pair batches incl. their op strings) do not hide that work."""
+    """A step (`Batch.run()`) ends with the results resident in HBM; bringing them to the host happens in `results_flat()`, once
+    per call whatever the number of steps (DISTANCE batches of reads and flat pair batches: the caller-facing arrays are laid
+    out by device kernels and come over as one block; other batches: download, per-unit records, flat arrays).  Reported beside
+    the step so that the lazily collected paths do not hide that work."""
     return {"results_flat_ms": round(collect_ms, 3), "ms_per_step_plus_one_collection": round(ms_per_step + collect_ms, 3),
-            "what": "results_flat() after the timed steps: D2H of what run() left in HBM + per-unit records + flat arrays"}
+            "what": "results_flat(copy=False) after the timed steps: the view of what run() left in HBM (read batches with "
+                    "TASK_DISTANCE and flat pair batches: arrays made on the device, one block D2H into pinned memory)"}
 
 
 def run_step(cfg_id, batch):
