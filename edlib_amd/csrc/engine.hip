@@ -912,10 +912,25 @@ int Batch::results(EdlibAlignResult* out)
         o.numLocations = 0; o.alignment = nullptr; o.alignmentLength = 0; o.alphabetLength = 0;
     }
     if (!haveResults_) { set_error("results() before a successful run()"); return 1; }
-    if (ensureCollected()) return 1;
+    // a DISTANCE run over read groups: the arrays of the device-made view (engine_flat.hip: buildReadsView) are what the
+    // results are copied from -- no per-read record in between (an end-location array per result is the reference's contract)
+    const bool fromView = readsViewOnDevice();
+    EdlibAmdResultsView v{};
+    if (fromView ? resultsView(&v) : ensureCollected()) return 1;
     std::atomic<int> oom(0);                      // a failed malloc: the unit reports EDLIB_STATUS_ERROR, the call fails
     auto marshal = [&](int lo, int hi) {
-        for (int u = lo; u < hi; ++u) {
+        for (int u = lo; fromView && u < hi; ++u) {
+            EdlibAlignResult& o = out[u];
+            o.status = v.status[u]; o.editDistance = v.editDistance[u]; o.alphabetLength = v.alphabetLength[u];
+            o.endLocations = nullptr; o.startLocations = nullptr; o.numLocations = 0; o.alignment = nullptr; o.alignmentLength = 0;
+            if (o.editDistance < 0) continue;
+            const int nl = v.numLocations[u];
+            o.endLocations = static_cast<int*>(malloc(sizeof(int) * (size_t)std::max(nl, 1)));
+            if (!o.endLocations) { o.status = EDLIB_STATUS_ERROR; o.editDistance = -1; oom.store(1); continue; }
+            if (nl) memcpy(o.endLocations, v.endLocations + v.locOffsets[u], (size_t)nl * sizeof(int));
+            o.numLocations = nl;
+        }
+        for (int u = lo; !fromView && u < hi; ++u) {
             const UnitResult& r = results_[u];
             EdlibAlignResult& o = out[u];
             o.status = r.status;

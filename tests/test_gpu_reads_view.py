@@ -21,9 +21,9 @@ def _compare(engine, reads, target, mode, k):
     try:
         b.run()
         got = b.results_flat()                     # the device-made view (nothing collected yet)
-        rec = b.results(raw=True)                  # ... and the records, built afterwards from the same device arrays
+        rec = b.results(raw=True)                  # ... and the per-unit malloc'd results, copied from that view
         b.run()
-        rec2 = b.results(raw=True)                 # the other order: records first, then the view (the host route)
+        rec2 = b.results(raw=True)                 # the other order: per-unit results first (copied from the same view), then the view
         got2 = b.results_flat()
     finally:
         b.close()
